@@ -1,0 +1,151 @@
+"""ctypes front-end of the CPU oracle (oracle/vms_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under video-mamba-suite_amd/ may import
+this module (tests/test_layout.py enforces it).
+
+All functions take / return numpy float32 arrays (dense, row-major); inputs in a
+16-bit I/O type are widened by the caller, outputs are rounded by the caller.
+`prec` selects the arithmetic width of the restatement: "f32" mirrors the
+reference's `.float()` arithmetic, "f64" is the tighter truth.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "libvms_oracle.so")
+_lib = None
+
+_F = ctypes.POINTER(ctypes.c_float)
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+        os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "vms_oracle.c"))
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _p(a):
+    if a is None:
+        return ctypes.cast(None, _F)
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"], (a.dtype, a.flags)
+    return a.ctypes.data_as(_F)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _bc4(B, var):
+    """(batch, N, L) -> (batch, 1, N, L) as SelectiveScanFn does (SSI:31-36)."""
+    if var and B.ndim == 3:
+        B = B[:, None]
+    return B
+
+
+def scan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, prec="f32",
+             threads=None):
+    """Returns dict(out=pre-gate y+uD, out_z (or None), x=(b,d,n_chunks,2N) checkpoints,
+    last_state=(b,d,N))."""
+    u, delta, A, B, C, D, z, delta_bias = map(_c, (u, delta, A, B, C, D, z, delta_bias))
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    var_B, var_C = B.ndim >= 3, C.ndim >= 3
+    B, C = _c(_bc4(B, var_B)), _c(_bc4(C, var_C))
+    G = B.shape[1] if var_B else (C.shape[1] if var_C else 1)
+    n_chunks = (L + 2047) // 2048
+    out = np.empty_like(u)
+    out_z = np.empty_like(u) if z is not None else None
+    x = np.zeros((batch, dim, n_chunks, 2 * N), np.float32)
+    last = np.empty((batch, dim, N), np.float32)
+    if threads:
+        os.environ["OMP_NUM_THREADS"] = str(threads)
+    fn = getattr(lib(), "vms_oracle_scan_fwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(N), ctypes.c_int(G),
+       _p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(z), _p(delta_bias),
+       ctypes.c_int(var_B), ctypes.c_int(var_C), ctypes.c_int(bool(delta_softplus)),
+       _p(out), _p(out_z), _p(x), _p(last))
+    return dict(out=out, out_z=out_z, x=x, last_state=last)
+
+
+def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=False, prec="f32"):
+    """Gradients of the final output (out_z if z is given else out) w.r.t. every input."""
+    u, delta, A, B, C, D, z, delta_bias, dout = map(_c, (u, delta, A, B, C, D, z, delta_bias, dout))
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    var_B, var_C = B.ndim >= 3, C.ndim >= 3
+    sqB, sqC = var_B and B.ndim == 3, var_C and C.ndim == 3
+    B, C = _c(_bc4(B, var_B)), _c(_bc4(C, var_C))
+    G = B.shape[1] if var_B else (C.shape[1] if var_C else 1)
+    du, ddelta = np.empty_like(u), np.empty_like(u)
+    dA = np.zeros_like(A)
+    dB, dC = np.zeros_like(B), np.zeros_like(C)
+    dD = np.zeros(dim, np.float32) if D is not None else None
+    dz = np.empty_like(u) if z is not None else None
+    dbias = np.zeros(dim, np.float32) if delta_bias is not None else None
+    fn = getattr(lib(), "vms_oracle_scan_bwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(N), ctypes.c_int(G),
+       _p(u), _p(delta), _p(A), _p(B), _p(C), _p(D), _p(z), _p(delta_bias), _p(dout),
+       ctypes.c_int(var_B), ctypes.c_int(var_C), ctypes.c_int(bool(delta_softplus)),
+       _p(du), _p(ddelta), _p(dA), _p(dB), _p(dC), _p(dD), _p(dz), _p(dbias))
+    if sqB:
+        dB = dB[:, 0]
+    if sqC:
+        dC = dC[:, 0]
+    return dict(du=du, ddelta=ddelta, dA=dA, dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)
+
+
+def conv_fwd(x, weight, bias=None, silu=False, prec="f32"):
+    x, weight, bias = map(_c, (x, weight, bias))
+    batch, dim, L = x.shape
+    W = weight.shape[1]
+    out = np.empty_like(x)
+    fn = getattr(lib(), "vms_oracle_conv_fwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(W), _p(x), _p(weight),
+       _p(bias), ctypes.c_int(bool(silu)), _p(out))
+    return out
+
+
+def conv_bwd(x, weight, bias, dout, silu=False, prec="f32"):
+    x, weight, bias, dout = map(_c, (x, weight, bias, dout))
+    batch, dim, L = x.shape
+    W = weight.shape[1]
+    dx = np.empty_like(x)
+    dw = np.zeros_like(weight)
+    db = np.zeros(dim, np.float32) if bias is not None else None
+    fn = getattr(lib(), "vms_oracle_conv_bwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(W), _p(x), _p(weight),
+       _p(bias), _p(dout), ctypes.c_int(bool(silu)), _p(dx), _p(dw), _p(db))
+    return dict(dx=dx, dweight=dw, dbias=db)
+
+
+def conv_update(x, conv_state, weight, bias=None, silu=False, prec="f32"):
+    """Returns (out, new_conv_state); conv_state is not modified in place."""
+    x, weight, bias = map(_c, (x, weight, bias))
+    cs = np.array(conv_state, dtype=np.float32, order="C", copy=True)
+    batch, dim = x.shape
+    W = weight.shape[1]
+    out = np.empty_like(x)
+    fn = getattr(lib(), "vms_oracle_conv_update_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(W), _p(x), _p(cs), _p(weight), _p(bias),
+       ctypes.c_int(bool(silu)), _p(out))
+    return out, cs

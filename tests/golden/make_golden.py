@@ -1,0 +1,273 @@
+"""Generate the golden vectors under tests/golden/ from the REFERENCE's own pure-PyTorch path.
+
+Runs only in the build container (needs /root/reference); the reference never travels
+to the GPU box -- only the .npz files written here do.  Import recipe:
+the CUDA extensions the reference imports at module top are replaced by empty stub
+modules, and the two interface files are loaded by file path, so only
+  selective_scan_ref / mamba_inner_ref / bimamba_inner_ref      (SSI:86-152, 636-709)
+  causal_conv1d_ref / causal_conv1d_update_ref                   (CCI:49-65, 87-104)
+  Mamba(use_fast_path=False) of mamba_simple.py / mamba_simple_scan_norm.py
+  Mamba.forward of mamba_new.py (DBM) over a composition of the refs
+ever execute.  Input distributions follow the reference tests
+(mamba/tests/ops/test_selective_scan.py:53-88, causal-conv1d/tests/test_causal_conv1d.py:36-50).
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    for stub in ("causal_conv1d_cuda", "selective_scan_cuda"):
+        sys.modules[stub] = types.ModuleType(stub)
+    cci = _load("causal_conv1d.causal_conv1d_interface",
+                f"{REF}/causal-conv1d/causal_conv1d/causal_conv1d_interface.py")
+    pkg = types.ModuleType("causal_conv1d")
+    pkg.causal_conv1d_fn = cci.causal_conv1d_ref  # fused fn -> pure-PyTorch ref
+    pkg.causal_conv1d_update = cci.causal_conv1d_update_ref
+    pkg.causal_conv1d_interface = cci
+    sys.modules["causal_conv1d"] = pkg
+    for name in ("mamba_ssm", "mamba_ssm.ops", "mamba_ssm.ops.triton", "mamba_ssm.modules"):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        sys.modules[name] = m
+    ssi = _load("mamba_ssm.ops.selective_scan_interface",
+                f"{REF}/mamba/mamba_ssm/ops/selective_scan_interface.py")
+    # the *_inner_ref functions call the fused names: bind them to the refs
+    ssi.causal_conv1d_fn = cci.causal_conv1d_ref
+    ssi.selective_scan_fn = ssi.selective_scan_ref
+    return cci, ssi
+
+
+def load_reference_modules(ssi):
+    """mamba_simple / scan_norm / mamba_new with every fused op bound to the refs."""
+    # triton layernorm cannot import without triton: give the modules a torch RMSNorm stand-in
+    ln = types.ModuleType("mamba_ssm.ops.triton.layernorm")
+
+    class RMSNorm(torch.nn.Module):  # same math as layernorm.py rms_norm_ref (:35-48)
+        def __init__(self, hidden_size, eps=1e-5, device=None, dtype=None):
+            super().__init__()
+            self.eps = eps
+            self.weight = torch.nn.Parameter(torch.ones(hidden_size, device=device, dtype=dtype))
+            self.register_parameter("bias", None)
+
+        def forward(self, x):
+            rstd = 1 / torch.sqrt((x.float().square()).mean(dim=-1, keepdim=True) + self.eps)
+            return (x.float() * rstd * self.weight.float()).to(x.dtype)
+
+    ln.RMSNorm, ln.layer_norm_fn, ln.rms_norm_fn = RMSNorm, None, None
+    sys.modules["mamba_ssm.ops.triton.layernorm"] = ln
+    ssu = types.ModuleType("mamba_ssm.ops.triton.selective_state_update")
+    ssu.selective_state_update = None
+    sys.modules["mamba_ssm.ops.triton.selective_state_update"] = ssu
+
+    def inner_no_out_proj_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                              C_proj_bias=None, delta_softplus=True):
+        # mamba_inner_ref (SSI:636-670) minus the final F.linear
+        eye = torch.eye(A.shape[0], dtype=xz.dtype)
+        y = ssi.mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                eye, None, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
+                                delta_softplus)
+        return y.transpose(1, 2)  # (b l d) -> (b d l)
+
+    ssi.mamba_inner_fn_no_out_proj = inner_no_out_proj_ref
+    ssi.mamba_inner_fn = ssi.mamba_inner_ref
+    ssi.bimamba_inner_fn = ssi.bimamba_inner_ref
+    mods = {}
+    for short, fname in (("simple", "mamba_simple.py"), ("norm", "mamba_simple_scan_norm.py"),
+                         ("new", "mamba_new.py")):
+        mods[short] = _load(f"mamba_ssm.modules._ref_{short}", f"{REF}/mamba/mamba_ssm/modules/{fname}")
+    return mods
+
+
+def npf(t):
+    return None if t is None else t.detach().float().numpy()
+
+
+def save(name, **arrs):
+    arrs = {k: v for k, v in arrs.items() if v is not None}
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+    print(f"  {name}.npz  {sum(np.asarray(v).nbytes for v in arrs.values()) / 1e6:.2f} MB raw")
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_scan(ssi, name, batch, dim, dstate, L, groups=1, var_B=True, var_C=True, has_D=True,
+             has_z=True, has_bias=True, softplus=True, itype=torch.float32, b3=False, seed=0):
+    """Input recipe = test_selective_scan.py:53-88."""
+    torch.random.manual_seed(seed)
+    A = (-0.5 * torch.rand(dim, dstate)).requires_grad_()
+    if not var_B:
+        Bs = (dim, dstate)
+    elif b3:
+        Bs = (batch, dstate, L)
+    else:
+        Bs = (batch, groups, dstate, L)
+    B = torch.randn(*Bs, dtype=torch.float32 if not var_B else itype).requires_grad_()
+    if not var_C:
+        Cs = (dim, dstate)
+    elif b3:
+        Cs = (batch, dstate, L)
+    else:
+        Cs = (batch, groups, dstate, L)
+    C = torch.randn(*Cs, dtype=torch.float32 if not var_C else itype).requires_grad_()
+    D = torch.randn(dim).requires_grad_() if has_D else None
+    z = torch.randn(batch, dim, L, dtype=itype).requires_grad_() if has_z else None
+    bias = (0.5 * torch.rand(dim)).requires_grad_() if has_bias else None
+    u = torch.randn(batch, dim, L, dtype=itype).requires_grad_()
+    delta = (0.5 * torch.rand(batch, dim, L, dtype=itype)).requires_grad_()
+    out, last = ssi.selective_scan_ref(u, delta, A, B, C, D, z=z, delta_bias=bias,
+                                       delta_softplus=softplus, return_last_state=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    save(name, u=npf(u), delta=npf(delta), A=npf(A), B=npf(B), C=npf(C), D=npf(D), z=npf(z),
+         delta_bias=npf(bias), softplus=np.array(int(softplus)), itype=np.array(str(itype)),
+         out=npf(out), last_state=npf(last), g=npf(g),
+         du=npf(u.grad), ddelta=npf(delta.grad), dA=npf(A.grad), dB=npf(B.grad), dC=npf(C.grad),
+         dD=npf(D.grad) if has_D else None, dz=npf(z.grad) if has_z else None,
+         ddelta_bias=npf(bias.grad) if has_bias else None)
+
+
+def gen_conv(cci, name, batch, dim, L, W, has_bias, silu, itype=torch.float32, seed=0):
+    """Input recipe = test_causal_conv1d.py:36-50 (dim reduced)."""
+    torch.random.manual_seed(seed)
+    x = torch.randn(batch, dim, L, dtype=itype).requires_grad_()
+    w = torch.randn(dim, W).requires_grad_()
+    b = torch.randn(dim).requires_grad_() if has_bias else None
+    out = cci.causal_conv1d_ref(x, w, b, activation="silu" if silu else None)
+    g = torch.randn_like(out)
+    out.backward(g)
+    save(name, x=npf(x), weight=npf(w), bias=npf(b), silu=np.array(int(silu)), itype=np.array(str(itype)),
+         out=npf(out), g=npf(g), dx=npf(x.grad), dweight=npf(w.grad),
+         dbias=npf(b.grad) if has_bias else None)
+
+
+def gen_conv_update(cci, name, batch, dim, W, has_bias, silu, seed=0):
+    """test_causal_conv1d.py:90-110."""
+    torch.random.manual_seed(seed)
+    x = torch.randn(batch, dim)
+    cs = torch.randn(batch, dim, W)
+    w = torch.randn(dim, W)
+    b = torch.randn(dim) if has_bias else None
+    cs_in = cs.clone()
+    out = cci.causal_conv1d_update_ref(x, cs, w, b, activation="silu" if silu else None)
+    save(name, x=npf(x), conv_state_in=npf(cs_in), weight=npf(w), bias=npf(b), silu=np.array(int(silu)),
+         out=npf(out), conv_state_out=npf(cs))
+
+
+def gen_inner(ssi, name, kind, batch=2, dim=32, dstate=8, dt_rank=6, L=128, W=3, seed=0):
+    """test_mamba_inner_fn recipe (test_selective_scan.py:166-200), dims reduced.
+    kind in {"out_proj", "no_out_proj", "bi"}."""
+    torch.random.manual_seed(seed)
+    xz = torch.randn(batch, 2 * dim, L).requires_grad_()
+    conv_w = torch.randn(dim, 1, W).requires_grad_()
+    conv_b = torch.randn(dim).requires_grad_()
+    x_proj_w = torch.randn(dt_rank + 2 * dstate, dim).requires_grad_()
+    dt_proj_w = torch.randn(dim, dt_rank).requires_grad_()
+    out_proj_w = torch.randn(dim // 2, dim).requires_grad_()
+    A = (-0.5 * torch.rand(dim, dstate)).requires_grad_()
+    A_b = (-0.5 * torch.rand(dim, dstate)).requires_grad_()
+    D = torch.randn(dim).requires_grad_()
+    dt_bias = (0.5 * torch.rand(dim)).requires_grad_()
+    if kind == "out_proj":
+        out = ssi.mamba_inner_ref(xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, None, A, None, None,
+                                  D, delta_bias=dt_bias, delta_softplus=True)
+    elif kind == "bi":
+        out = ssi.bimamba_inner_ref(xz, conv_w, conv_b, x_proj_w, dt_proj_w, out_proj_w, None, A, A_b,
+                                    None, None, D, delta_bias=dt_bias, delta_softplus=True)
+    else:
+        out = ssi.mamba_inner_fn_no_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, None, None, D,
+                                             delta_bias=dt_bias, delta_softplus=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    save(name, xz=npf(xz), conv1d_weight=npf(conv_w), conv1d_bias=npf(conv_b), x_proj_weight=npf(x_proj_w),
+         delta_proj_weight=npf(dt_proj_w), out_proj_weight=npf(out_proj_w), A=npf(A), A_b=npf(A_b), D=npf(D),
+         delta_bias=npf(dt_bias), out=npf(out), g=npf(g),
+         dxz=npf(xz.grad), dconv1d_weight=npf(conv_w.grad), dconv1d_bias=npf(conv_b.grad),
+         dx_proj_weight=npf(x_proj_w.grad), ddelta_proj_weight=npf(dt_proj_w.grad),
+         dout_proj_weight=npf(out_proj_w.grad) if out_proj_w.grad is not None else None,
+         dA=npf(A.grad), dA_b=npf(A_b.grad) if A_b.grad is not None else None,
+         dD=npf(D.grad), ddelta_bias=npf(dt_bias.grad))
+
+
+def gen_block(mods, name, which, d_model=32, L=33, batch=2, expand=2, d_state=8, seed=0, **kw):
+    """Reference nn.Module forward+backward on CPU; state_dict + input + output + grads."""
+    torch.random.manual_seed(seed)
+    cls = mods[which].Mamba
+    extra = dict(bimamba_type="v2") if which in ("simple", "norm") else {}
+    extra.update(kw)
+    use_fast = which == "new"  # DBM has no slow path (mamba_new.py:216); its fast path is bound to refs
+    m = cls(d_model, d_state=d_state, d_conv=4, expand=expand, use_fast_path=use_fast, **extra)
+    # move parameters off their deterministic init so that every weight matters
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            if k.endswith("A_log") or k.endswith("A_b_log"):
+                p.add_(0.3 * torch.randn_like(p))
+            elif k in ("D", "D_b") or k.endswith("norm.weight"):
+                p.add_(0.5 * torch.randn_like(p))
+    x = torch.randn(batch, L, d_model).requires_grad_()
+    y = m(x)
+    g = torch.randn_like(y)
+    y.backward(g)
+    arrs = {"sd." + k: npf(v) for k, v in m.state_dict().items()}
+    arrs.update({"grad." + k: npf(p.grad) for k, p in m.named_parameters()})
+    save(name, x=npf(x), y=npf(y), g=npf(g), dx=npf(x.grad), **arrs)
+
+
+def main():
+    torch.set_num_threads(8)
+    cci, ssi = load_reference()
+    print("scan:")
+    gen_scan(ssi, "scan_L128_g1", 2, 4, 8, 128)
+    gen_scan(ssi, "scan_L372_g2", 2, 4, 8, 372, groups=2)
+    gen_scan(ssi, "scan_L1134_plain", 2, 4, 8, 1134, has_D=False, has_z=False, has_bias=False, softplus=False)
+    gen_scan(ssi, "scan_L2048_b3", 1, 4, 8, 2048, b3=True)
+    gen_scan(ssi, "scan_L4100_long", 1, 2, 4, 4100)
+    gen_scan(ssi, "scan_cfg1", 2, 128, 16, 256)  # BASELINE.json configs[0]
+    gen_scan(ssi, "scan_constBC", 2, 4, 8, 200, var_B=False, var_C=False)
+    gen_scan(ssi, "scan_constB", 2, 4, 8, 200, var_B=False)
+    gen_scan(ssi, "scan_constC", 2, 4, 8, 200, var_C=False)
+    gen_scan(ssi, "scan_bf16_L300", 2, 4, 16, 300, itype=torch.bfloat16)
+    gen_scan(ssi, "scan_f16_L130", 2, 4, 8, 130, itype=torch.float16)
+    print("conv:")
+    for L in (8, 151, 372):
+        for W in (2, 3, 4):
+            for has_bias in (False, True):
+                for silu in (False, True):
+                    gen_conv(cci, f"conv_L{L}_W{W}_b{int(has_bias)}_s{int(silu)}", 2, 6, L, W, has_bias, silu)
+    gen_conv(cci, "conv_L1134_W4_b1_s1", 2, 10, 1134, 4, True, True)
+    gen_conv(cci, "conv_bf16_L200_W4_b1_s1", 2, 6, 200, 4, True, True, itype=torch.bfloat16)
+    for W in (2, 3, 4):
+        gen_conv_update(cci, f"convupd_W{W}", 2, 24, W, True, True)
+    gen_conv_update(cci, "convupd_W4_plain", 2, 24, 4, False, False)
+    print("inner:")
+    mods = load_reference_modules(ssi)
+    gen_inner(ssi, "inner_out_proj", "out_proj")
+    gen_inner(ssi, "inner_no_out_proj", "no_out_proj")
+    gen_inner(ssi, "inner_bi", "bi")
+    print("blocks:")
+    gen_block(mods, "block_vim", "simple")
+    gen_block(mods, "block_vim_div", "simple", if_devide_out=True, L=257, batch=1)
+    gen_block(mods, "block_vim_norm", "norm", if_devide_out=True)
+    gen_block(mods, "block_dbm", "new", expand=1)
+
+
+if __name__ == "__main__":
+    main()

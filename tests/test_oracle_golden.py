@@ -1,0 +1,89 @@
+"""Pins the CPU oracle (oracle/vms_oracle.c) against the golden vectors produced by the
+reference's own pure-PyTorch path (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+
+
+def close(a, b, rtol, atol, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b) - (atol + rtol * np.abs(b))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert err.max() <= 0, f"{what}: max abs diff {np.abs(a - b).max():.3e} (rtol {rtol}, atol {atol})"
+
+
+def tol_for(g):
+    it = str(g["itype"])
+    if "bfloat16" in it:
+        return 2e-2, 2e-2      # golden outputs/grads were rounded to bf16 by the reference
+    if "float16" in it:
+        return 3e-3, 3e-3
+    return 2e-4, 2e-5          # fp32: restatement vs torch differ only by summation order
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_scan_oracle_matches_reference(oracle, name, prec):
+    g = load_golden(name)
+    rtol, atol = tol_for(g)
+    sp = bool(g["softplus"])
+    r = oracle.scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                        g.get("delta_bias"), sp, prec=prec)
+    out = r["out_z"] if "z" in g else r["out"]
+    close(out, g["out"], rtol, atol * 10, "out")
+    close(r["last_state"], g["last_state"], rtol, atol * 10, "last_state")
+    # checkpoints: last chunk's odd slots are the last state (SSI:40)
+    close(r["x"][:, :, -1, 1::2], g["last_state"], rtol, atol * 10, "x[-1,1::2]")
+    b = oracle.scan_bwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                        g.get("delta_bias"), g["g"], sp, prec=prec)
+    L = g["u"].shape[-1]
+    scale = max(1.0, L / 256)  # sums over L of O(1) terms: absolute noise grows with L
+    for k in ("du", "ddelta", "dB", "dC", "dz"):
+        if k in g:
+            close(b[k], g[k], rtol, atol * 50, k)
+    for k in ("dA", "dD", "ddelta_bias"):
+        if k in g:
+            close(b[k], g[k], rtol * 5, atol * 50 * scale, k)
+
+
+def test_scan_oracle_mid_checkpoint(oracle):
+    """x[c, 2n] is the state after the first 1024 elements of chunk c; check against a
+    second oracle run on the truncated sequence."""
+    g = load_golden("scan_L4100_long")
+    sp = bool(g["softplus"])
+    full = oracle.scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                           g.get("delta_bias"), sp, prec="f64")
+    for c, cut in ((0, 1024), (1, 2048 + 1024), (2, 4100)):
+        t = oracle.scan_fwd(g["u"][..., :cut], g["delta"][..., :cut], g["A"], g["B"][..., :cut],
+                            g["C"][..., :cut], g.get("D"), g["z"][..., :cut], g.get("delta_bias"), sp,
+                            prec="f64")
+        close(full["x"][:, :, c, 0::2], t["last_state"], 1e-6, 1e-7, f"mid ckpt chunk {c}")
+    for c, cut in ((0, 2048), (1, 4096), (2, 4100)):
+        t = oracle.scan_fwd(g["u"][..., :cut], g["delta"][..., :cut], g["A"], g["B"][..., :cut],
+                            g["C"][..., :cut], g.get("D"), g["z"][..., :cut], g.get("delta_bias"), sp,
+                            prec="f64")
+        close(full["x"][:, :, c, 1::2], t["last_state"], 1e-6, 1e-7, f"end ckpt chunk {c}")
+
+
+@pytest.mark.parametrize("name", golden_names("conv_"))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_conv_oracle_matches_reference(oracle, name, prec):
+    g = load_golden(name)
+    rtol, atol = tol_for(g)
+    silu = bool(g["silu"])
+    out = oracle.conv_fwd(g["x"], g["weight"], g.get("bias"), silu, prec=prec)
+    close(out, g["out"], rtol, atol * 10, "out")
+    b = oracle.conv_bwd(g["x"], g["weight"], g.get("bias"), g["g"], silu, prec=prec)
+    close(b["dx"], g["dx"], rtol, atol * 10, "dx")
+    close(b["dweight"], g["dweight"], rtol * 5, atol * 100, "dweight")
+    if "dbias" in g:
+        close(b["dbias"], g["dbias"], rtol * 5, atol * 100, "dbias")
+
+
+@pytest.mark.parametrize("name", golden_names("convupd_"))
+def test_conv_update_oracle_matches_reference(oracle, name):
+    g = load_golden(name)
+    out, cs = oracle.conv_update(g["x"], g["conv_state_in"], g["weight"], g.get("bias"), bool(g["silu"]))
+    assert np.array_equal(cs, g["conv_state_out"])  # state roll is exact (test_causal_conv1d.py:113)
+    close(out, g["out"], 1e-5, 1e-6, "out")
