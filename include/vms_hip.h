@@ -1,0 +1,155 @@
+/*
+ * vms_hip.h -- C ABI of libvms_hip.so, the MI355X (gfx950) selective-scan /
+ * causal-conv1d hot path of the Video Mamba Suite.
+ *
+ * This is the drop-in boundary.  Each entry point replaces one function of the
+ * reference's two pybind extensions (paths relative to the reference tree):
+ *
+ *   vms_selective_scan_fwd   <- selective_scan_cuda.fwd
+ *        mamba/csrc/selective_scan/selective_scan.cpp:226-336  (host)
+ *        mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:67-345
+ *   vms_selective_scan_bwd   <- selective_scan_cuda.bwd
+ *        mamba/csrc/selective_scan/selective_scan.cpp:338-492
+ *        mamba/csrc/selective_scan/selective_scan_bwd_kernel.cuh:75-531
+ *   vms_causal_conv1d_fwd    <- causal_conv1d_cuda.causal_conv1d_fwd
+ *        causal-conv1d/csrc/causal_conv1d.cpp:130-189, causal_conv1d_fwd.cu
+ *   vms_causal_conv1d_bwd    <- causal_conv1d_cuda.causal_conv1d_bwd
+ *        causal-conv1d/csrc/causal_conv1d.cpp:191-268, causal_conv1d_bwd.cu
+ *   vms_causal_conv1d_update <- causal_conv1d_cuda.causal_conv1d_update
+ *        causal-conv1d/csrc/causal_conv1d.cpp:270-327, causal_conv1d_update.cu
+ *
+ * Conventions
+ *   - plain C: POD parameter blocks, raw device pointers, sizes; no torch types.
+ *   - every stride is in ELEMENTS of the tensor's own dtype and 64-bit (the
+ *     reference stores 32-bit strides, selective_scan.h:27).
+ *   - the library never allocates, never synchronises and keeps no state: all
+ *     outputs (and accumulators that must start at zero, marked [zeroed]) are
+ *     provided by the caller, exactly the tensors the reference host functions
+ *     allocate.  Calls are re-entrant and are enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the null stream).
+ *   - return value: VMS_OK or a negative vms_status; vms_last_error() gives a
+ *     thread-local message naming the failed check (the reference raises
+ *     RuntimeError from TORCH_CHECK with the failing expression).
+ */
+#ifndef VMS_HIP_H
+#define VMS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMS_ABI_VERSION 1
+
+typedef enum {
+    VMS_OK = 0,
+    VMS_ERR_INVALID_ARG = -1,   /* a shape / dtype / stride / NULL check failed          */
+    VMS_ERR_UNSUPPORTED = -2,   /* valid in the reference but not built here (complex A)  */
+    VMS_ERR_LAUNCH = -3         /* hipGetLastError() after the launch was not hipSuccess  */
+} vms_status;
+
+typedef enum { VMS_F32 = 0, VMS_F16 = 1, VMS_BF16 = 2 } vms_dtype;
+
+/* ---- selective scan ------------------------------------------------------------------
+ * u, delta, z, out, out_z : (batch, dim, seqlen), unit seqlen stride, free batch/dim strides
+ * A                       : (dim, dstate) fp32 (real A only; complex -> VMS_ERR_UNSUPPORTED)
+ * B, C variable           : (batch, n_groups, dstate, seqlen) in `dtype`, unit seqlen stride
+ * B, C constant           : (dim, dstate) fp32
+ * D, delta_bias           : (dim) fp32 or NULL
+ * x                       : (batch, dim, n_chunks, 2*dstate) fp32 contiguous,
+ *                           n_chunks = ceil(seqlen / 2048) (selective_scan.cpp:307,313).
+ *                           slot [c][2n+1] = state after chunk c (as the reference;
+ *                           last_state = x[:, :, -1, 1::2]); slot [c][2n] = state after the
+ *                           first 1024 elements of chunk c (the reference stores the running
+ *                           product of exp(delta*A) there, which nothing reads back).
+ */
+typedef struct {
+    int32_t batch, dim, seqlen, dstate, n_groups, n_chunks;
+    int32_t dtype;            /* vms_dtype of u, delta, z, out, out_z and variable B/C */
+    int32_t is_variable_B, is_variable_C, delta_softplus;
+    const void *u, *delta, *A, *B, *C, *D, *z, *delta_bias;
+    void *out, *out_z, *x;
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t z_batch_stride, z_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t out_z_batch_stride, out_z_d_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_d_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_d_stride, C_dstate_stride;
+} vms_scan_fwd_params;
+
+/* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).
+ * out (the pre-gate forward output) is required iff z != NULL (selective_scan.cpp:424-429).
+ * x is required iff n_chunks > 1 (:449).  dz: required iff z != NULL (may be a view into a
+ * larger tensor, SSI:244-248).  out_z: optional recompute target (:440-442).
+ * dA (dim,dstate) fp32 [zeroed]; dB, dC: variable -> (batch,n_groups,dstate,seqlen) FP32
+ * [zeroed] (the reference accumulates in fp32 and casts afterwards, :461-462, 488);
+ * constant -> (dim,dstate) fp32 [zeroed]; dD, ddelta_bias (dim) fp32 [zeroed] or NULL. */
+typedef struct {
+    vms_scan_fwd_params f;    /* f.out = pre-gate out (read), f.out_z = optional recompute (write) */
+    const void *dout;
+    void *du, *ddelta, *dz;
+    float *dA, *dB, *dC, *dD, *ddelta_bias;
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    int64_t dz_batch_stride, dz_d_stride;
+    int64_t dA_d_stride, dA_dstate_stride;
+    int64_t dB_batch_stride, dB_group_stride, dB_d_stride, dB_dstate_stride;
+    int64_t dC_batch_stride, dC_group_stride, dC_d_stride, dC_dstate_stride;
+} vms_scan_bwd_params;
+
+int vms_selective_scan_fwd(const vms_scan_fwd_params *p, void *stream);
+int vms_selective_scan_bwd(const vms_scan_bwd_params *p, void *stream);
+
+/* ---- causal depthwise conv1d ---------------------------------------------------------
+ * x, out, dout, dx : (batch, dim, seqlen); either unit seqlen stride (any batch/channel
+ *                    stride) or unit channel stride ("channel-last", causal_conv1d.cpp:151-156)
+ * weight           : (dim, width), 2 <= width <= 4 (:157); bias (dim) or NULL; both wdtype
+ * dweight (dim,width), dbias (dim): FP32 [zeroed] accumulators (:247-249)
+ * conv_state       : (batch, dim, width) in `dtype`, updated in place by _update
+ */
+typedef struct {
+    int32_t batch, dim, seqlen, width;
+    int32_t dtype;            /* vms_dtype of x, out, dout, dx, conv_state */
+    int32_t wdtype;           /* vms_dtype of weight and bias              */
+    int32_t silu_activation;
+    const void *x, *weight, *bias;
+    void *out;
+    int64_t x_batch_stride, x_c_stride, x_l_stride;
+    int64_t weight_c_stride, weight_width_stride;
+    int64_t out_batch_stride, out_c_stride, out_l_stride;
+    /* update only */
+    void *conv_state;
+    int64_t conv_state_batch_stride, conv_state_c_stride, conv_state_l_stride;
+} vms_conv_fwd_params;
+
+typedef struct {
+    vms_conv_fwd_params f;    /* f.out unused */
+    const void *dout;
+    void *dx;
+    float *dweight, *dbias;
+    int64_t dout_batch_stride, dout_c_stride, dout_l_stride;
+    int64_t dx_batch_stride, dx_c_stride, dx_l_stride;
+    int64_t dweight_c_stride, dweight_width_stride;
+} vms_conv_bwd_params;
+
+int vms_causal_conv1d_fwd(const vms_conv_fwd_params *p, void *stream);
+int vms_causal_conv1d_bwd(const vms_conv_bwd_params *p, void *stream);
+int vms_causal_conv1d_update(const vms_conv_fwd_params *p, void *stream);
+
+/* ---- misc ---------------------------------------------------------------------------- */
+int vms_abi_version(void);
+const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
+/* sizes of the parameter blocks as compiled, so a binding can verify its mirror */
+int vms_sizeof_scan_fwd_params(void);
+int vms_sizeof_scan_bwd_params(void);
+int vms_sizeof_conv_fwd_params(void);
+int vms_sizeof_conv_bwd_params(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMS_HIP_H */

@@ -1,0 +1,393 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI (ctypes -> libvms_hip.so), against
+ (a) the committed golden vectors produced by the reference's PyTorch path, and
+ (b) the CPU oracle (oracle/vms_oracle.c, f64 arithmetic) on the same seeded inputs,
+plus size-independent checks at BASELINE.json's full size.
+
+Tolerances (BASELINE.json north_star): 1e-3 for fp32 I/O, 1e-2 for bf16 I/O, relative to the
+tensor's scale (max |ref|); reductions over L*batch (dA, dD, dbias, dweight) get the factor the
+reference's own tests give them (test_selective_scan.py:137-149)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 3e-3}
+
+
+def G(a, dtype=torch.float32, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=dtype, device=DEV)
+    return t.requires_grad_() if grad else t
+
+
+def rel_err(a, ref):
+    a = a.detach().float().cpu().numpy().astype(np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-6)
+
+
+def check(a, ref, tol, what):
+    e = rel_err(a, ref)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
+
+
+def itype_of(g):
+    s = str(g.get("itype", "torch.float32"))
+    return torch.bfloat16 if "bfloat16" in s else (torch.float16 if "float16" in s else torch.float32)
+
+
+# =================================================================================================
+# selective scan
+# =================================================================================================
+def run_scan(g, itype, oracle):
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    var_B, var_C = g["B"].ndim >= 3, g["C"].ndim >= 3
+    u = G(g["u"], itype, True)
+    delta = G(g["delta"], itype, True)
+    A = G(g["A"], grad=True)
+    B = G(g["B"], itype if var_B else torch.float32, True)
+    C = G(g["C"], itype if var_C else torch.float32, True)
+    D = G(g["D"], grad=True) if "D" in g else None
+    z = G(g["z"], itype, True) if "z" in g else None
+    bias = G(g["delta_bias"], grad=True) if "delta_bias" in g else None
+    sp = bool(g["softplus"])
+    out, last = selective_scan_fn(u, delta, A, B, C, D, z=z, delta_bias=bias, delta_softplus=sp,
+                                  return_last_state=True)
+    out.backward(G(g["g"], itype))
+    got = dict(out=out, last_state=last, du=u.grad, ddelta=delta.grad, dA=A.grad, dB=B.grad, dC=C.grad,
+               dD=D.grad if D is not None else None, dz=z.grad if z is not None else None,
+               ddelta_bias=bias.grad if bias is not None else None)
+    # oracle on exactly the (rounded) values the kernel saw
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy()
+    o = oracle.scan_fwd(f(u), f(delta), f(A), f(B), f(C), f(D), f(z), f(bias), sp, prec="f64")
+    ob = oracle.scan_bwd(f(u), f(delta), f(A), f(B), f(C), f(D), f(z), f(bias), g["g"], sp, prec="f64")
+    want = dict(out=o["out_z"] if z is not None else o["out"], last_state=o["last_state"], **ob)
+    return got, want
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+def test_scan_vs_oracle_and_golden(oracle, name):
+    g = load_golden(name)
+    itype = itype_of(g)
+    tol = TOL[itype]
+    got, want = run_scan(g, itype, oracle)
+    L = g["u"].shape[-1]
+    wide = 5 if L * g["u"].shape[0] > 512 else 2  # sums over batch*L
+    for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
+        if want.get(k) is not None:
+            check(got[k], want[k], tol * (2 if k != "out" else 1), f"{name}:{k} vs oracle")
+            check(got[k], g[k], tol * 3 if itype == torch.float32 else tol * 4, f"{name}:{k} vs golden")
+    for k in ("dA", "dD", "ddelta_bias"):
+        if want.get(k) is not None:
+            check(got[k], want[k], tol * wide, f"{name}:{k} vs oracle")
+            check(got[k], g[k], tol * wide * 2, f"{name}:{k} vs golden")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 1), (1, 6, 16, 1024, 1), (2, 12, 16, 1025, 2), (1, 4, 8, 2048, 1),
+                                   (2, 4, 16, 3000, 1), (1, 5, 4, 5000, 1), (1, 3, 32, 777, 3), (1, 2, 256, 96, 1)])
+@pytest.mark.parametrize("has_z", [True, False])
+def test_scan_random_vs_oracle(oracle, shape, itype, has_z):
+    """Reference test recipe (test_selective_scan.py:53-88) at shapes covering every chunk /
+    checkpoint boundary case, odd lengths (scalar I/O path), groups and large dstate."""
+    batch, dim, N, L, groups = shape
+    torch.manual_seed(0)
+    g = dict(u=torch.randn(batch, dim, L), delta=0.5 * torch.rand(batch, dim, L), A=-0.5 * torch.rand(dim, N),
+             B=torch.randn(batch, groups, N, L), C=torch.randn(batch, groups, N, L), D=torch.randn(dim),
+             delta_bias=0.5 * torch.rand(dim), g=torch.randn(batch, dim, L), softplus=1)
+    if has_z:
+        g["z"] = torch.randn(batch, dim, L)
+    g = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in g.items()}
+    tol = TOL[itype]
+    got, want = run_scan(g, itype, oracle)
+    for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
+        if want.get(k) is not None:
+            check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k}")
+    for k in ("dA", "dD", "ddelta_bias"):
+        check(got[k], want[k], tol * 5, k)
+
+
+def test_scan_strided_views_and_checkpoints(oracle):
+    """u/z are channel halves of one xz buffer, delta is d-slowest, out inherits delta's layout,
+    dz is written into a slice of a pre-allocated dxz (SSI:175, 182, 244-248); raw extension ABI."""
+    import selective_scan_cuda
+    torch.manual_seed(1)
+    b, d, N, L = 2, 16, 16, 2500
+    xz = torch.randn(b, 2 * d, L, device=DEV)
+    u, z = xz[:, :d], xz[:, d:]
+    delta = (0.5 * torch.rand(d, b, L, device=DEV)).permute(1, 0, 2)
+    A = -0.5 * torch.rand(d, N, device=DEV)
+    B = torch.randn(b, 1, N, L, device=DEV)
+    C = torch.randn(b, 1, N, L, device=DEV)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
+    assert out.stride() == delta.stride() and x.shape == (b, d, 2, 2 * N)
+    f = lambda t: t.detach().float().cpu().numpy()
+    o = oracle.scan_fwd(f(u), f(delta), f(A), f(B), f(C), f(D), f(z), f(bias), True, prec="f64")
+    check(out, o["out"], 1e-3, "out")
+    check(out_z, o["out_z"], 1e-3, "out_z")
+    check(x, o["x"], 1e-3, "x checkpoints (mid + end slots)")
+    dout = torch.randn(b, d, L, device=DEV)
+    dxz = torch.full_like(xz, float("nan"))
+    dz_view = dxz[:, d:]
+    res = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, dz_view, True, True)
+    du, ddelta, dA, dB, dC, dD, dbias, dz, out_z2 = res
+    assert dz.data_ptr() == dz_view.data_ptr() and ddelta.stride() == delta.stride()
+    assert torch.isnan(dxz[:, :d]).all() and not torch.isnan(dxz[:, d:]).any()
+    ob = oracle.scan_bwd(f(u), f(delta), f(A), f(B), f(C), f(D), f(z), f(bias), f(dout), True, prec="f64")
+    for k, v in (("du", du), ("ddelta", ddelta), ("dB", dB), ("dC", dC), ("dz", dz)):
+        check(v, ob[k], 2e-3, k)
+    for k, v in (("dA", dA), ("dD", dD), ("ddelta_bias", dbias)):
+        check(v, ob[k], 5e-3, k)
+    check(out_z2, o["out_z"], 1e-3, "recomputed out_z")
+
+
+def test_scan_extension_error_behaviour():
+    import selective_scan_cuda
+    u = torch.randn(1, 4, 16, device=DEV)
+    A = -torch.rand(4, 8, device=DEV)
+    B = torch.randn(1, 1, 8, 16, device=DEV)
+    with pytest.raises(RuntimeError):  # dtype mismatch (selective_scan.cpp:242)
+        selective_scan_cuda.fwd(u, u.half(), A, B, B, None, None, None, False)
+    with pytest.raises(RuntimeError):  # dstate > 256 (:265)
+        selective_scan_cuda.fwd(u, u, -torch.rand(4, 300, device=DEV), torch.randn(1, 1, 300, 16, device=DEV),
+                                torch.randn(1, 1, 300, 16, device=DEV), None, None, None, False)
+    with pytest.raises(RuntimeError):  # complex A is a declared non-goal: loud error, no fallback
+        selective_scan_cuda.fwd(u, u, torch.randn(4, 8, device=DEV, dtype=torch.complex64), B, B, None, None, None, False)
+    with pytest.raises(RuntimeError):  # x required when n_chunks > 1 (:449)
+        L = 4096
+        u2 = torch.randn(1, 4, L, device=DEV)
+        B2 = torch.randn(1, 1, 8, L, device=DEV)
+        selective_scan_cuda.bwd(u2, u2, A, B2, B2, None, None, None, u2, None, None, None, False, False)
+
+
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+def test_scan_full_size_rows_vs_oracle(oracle, itype):
+    """BASELINE.json config 2 size (8, 8192, 1024, 16): the oracle cannot run all 8192 rows in
+    seconds, but rows are independent given (B, C) -- check a spread of rows fwd and bwd, plus a
+    checksum-style property: dB/dC are sums over rows, so they must equal the sum of the
+    per-row-block results computed by separate launches on row subsets."""
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    torch.manual_seed(0)
+    b, d, N, L = 8, 1024, 16, 8192
+    u = torch.randn(b, d, L, device=DEV, dtype=itype)
+    delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
+    z = torch.randn(b, d, L, device=DEV, dtype=itype)
+    A = -0.5 * torch.rand(d, N, device=DEV)
+    B = torch.randn(b, 1, N, L, device=DEV, dtype=itype)
+    C = torch.randn(b, 1, N, L, device=DEV, dtype=itype)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    for t in (u, delta, z, A, B, C, D, bias):
+        t.requires_grad_()
+    out = selective_scan_fn(u, delta, A, B, C, D, z=z, delta_bias=bias, delta_softplus=True)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    rows = [0, 1, 511, 1023]
+    batches = [0, 7]
+    f = lambda t: t.detach().float().cpu().numpy()
+    tol = TOL[itype]
+    for bi in batches:
+        sl = (slice(bi, bi + 1), rows)
+        o = oracle.scan_fwd(f(u[sl]), f(delta[sl]), f(A[rows]), f(B[bi:bi + 1]), f(C[bi:bi + 1]), f(D[rows]),
+                            f(z[sl]), f(bias[rows]), True, prec="f64")
+        check(out[sl], o["out_z"], tol, f"out rows batch {bi}")
+        ob = oracle.scan_bwd(f(u[sl]), f(delta[sl]), f(A[rows]), f(B[bi:bi + 1]), f(C[bi:bi + 1]), f(D[rows]),
+                             f(z[sl]), f(bias[rows]), f(gout[sl]), True, prec="f64")
+        check(u.grad[sl], ob["du"], tol * 2, "du rows")
+        check(delta.grad[sl], ob["ddelta"], tol * 2, "ddelta rows")
+        check(z.grad[sl], ob["dz"], tol * 2, "dz rows")
+    # additivity of the group sums: rerun batch 0 in two halves of the rows
+    dB_full = B.grad[0:1].float()
+    parts = []
+    for lo, hi in ((0, d // 2), (d // 2, d)):
+        args = [t[0:1, lo:hi].detach().clone().requires_grad_() for t in (u, delta)]
+        Bp, Cp = B[0:1].detach().clone().requires_grad_(), C[0:1].detach().clone().requires_grad_()
+        o2 = selective_scan_fn(args[0], args[1], A[lo:hi].detach(), Bp, Cp, D[lo:hi].detach(),
+                               z=z[0:1, lo:hi].detach(), delta_bias=bias[lo:hi].detach(), delta_softplus=True)
+        o2.backward(gout[0:1, lo:hi])
+        parts.append(Bp.grad.float())
+    check(parts[0] + parts[1], f(dB_full), 2e-2 if itype == torch.bfloat16 else 2e-3, "dB additivity over row blocks")
+
+
+# =================================================================================================
+# causal conv1d
+# =================================================================================================
+@pytest.mark.parametrize("name", golden_names("conv_"))
+def test_conv_vs_oracle_and_golden(oracle, name):
+    from causal_conv1d import causal_conv1d_fn
+    g = load_golden(name)
+    itype = itype_of(g)
+    tol = TOL[itype]
+    x = G(g["x"], itype, True)
+    w = G(g["weight"], grad=True)
+    b = G(g["bias"], grad=True) if "bias" in g else None
+    act = "silu" if g["silu"] else None
+    out = causal_conv1d_fn(x, w, b, act)
+    out.backward(G(g["g"], itype))
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy()
+    o = oracle.conv_fwd(f(x), f(w), f(b), bool(g["silu"]), prec="f64")
+    ob = oracle.conv_bwd(f(x), f(w), f(b), g["g"], bool(g["silu"]), prec="f64")
+    check(out, o, tol, "out vs oracle")
+    check(out, g["out"], tol * 2, "out vs golden")
+    check(x.grad, ob["dx"], tol, "dx vs oracle")
+    check(x.grad, g["dx"], tol * 2, "dx vs golden")
+    check(w.grad, ob["dweight"], tol * 2, "dweight vs oracle")
+    check(w.grad, g["dweight"], tol * 3, "dweight vs golden")
+    if b is not None:
+        check(b.grad, ob["dbias"], tol * 2, "dbias vs oracle")
+
+
+@pytest.mark.parametrize("channel_last", [False, True])
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("silu", [False, True])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("seqlen", [8, 151, 512, 1134, 4096])
+def test_conv_reference_grid(oracle, seqlen, width, silu, itype, channel_last):
+    """The reference's own grid (test_causal_conv1d.py:14-75): x is a channel slice of a wider
+    tensor (non-trivial batch stride), both memory layouts, every width; dim reduced 4128 -> 264."""
+    from causal_conv1d import causal_conv1d_fn
+    torch.manual_seed(0)
+    batch, dim = 2, 264
+    if not channel_last:
+        x = torch.randn(batch, 64 + dim + 24, seqlen, device=DEV, dtype=itype)[:, 64:64 + dim, :].requires_grad_()
+    else:
+        x = torch.randn(batch, seqlen, 64 + dim + 24, device=DEV, dtype=itype)[:, :, 64:64 + dim].transpose(1, 2).requires_grad_()
+    w = torch.randn(dim, width, device=DEV, requires_grad=True)
+    b = torch.randn(dim, device=DEV, requires_grad=True)
+    out = causal_conv1d_fn(x, w, b, "silu" if silu else None)
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    f = lambda t: t.detach().float().cpu().numpy()
+    tol = TOL[itype]
+    check(out, oracle.conv_fwd(f(x), f(w), f(b), silu, prec="f64"), tol, "out")
+    ob = oracle.conv_bwd(f(x), f(w), f(b), f(gout), silu, prec="f64")
+    check(x.grad, ob["dx"], tol, "dx")
+    check(w.grad, ob["dweight"], tol * 3, "dweight")
+    check(b.grad, ob["dbias"], tol * 3, "dbias")
+
+
+@pytest.mark.parametrize("name", golden_names("convupd_"))
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+def test_conv_update(oracle, name, itype):
+    from causal_conv1d import causal_conv1d_update
+    g = load_golden(name)
+    x = G(g["x"], itype)
+    cs = G(g["conv_state_in"], itype)
+    w = G(g["weight"])
+    b = G(g["bias"]) if "bias" in g else None
+    cs_in = cs.clone()
+    out = causal_conv1d_update(x, cs, w, b, "silu" if g["silu"] else None)
+    # state roll must be bit-exact (test_causal_conv1d.py:113)
+    want_cs = torch.cat([cs_in[:, :, 1:], x[:, :, None]], dim=-1)
+    assert torch.equal(cs, want_cs)
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy()
+    o, _ = oracle.conv_update(f(x), f(cs_in), f(w), f(b), bool(g["silu"]), prec="f64")
+    check(out, o, TOL[itype], "out")
+    if itype == torch.float32:
+        check(out, g["out"], 1e-3, "out vs golden")
+
+
+def test_conv_deterministic_outputs():
+    """test_causal_conv1d_race_condition (test_causal_conv1d.py:117-173), shortened: out and dx are
+    bit-identical across repeats; dweight/dbias (fp32 atomics) agree to 1e-4 relative."""
+    from causal_conv1d import causal_conv1d_fn
+    torch.manual_seed(0)
+    x = torch.randn(2, 2048, 512 + 8, device=DEV, dtype=torch.bfloat16)[:, :, :512].transpose(1, 2).requires_grad_()
+    w = torch.randn(512, 4, device=DEV, requires_grad=True)
+    b = torch.randn(512, device=DEV, requires_grad=True)
+    g = torch.randn(2, 512, 2048, device=DEV, dtype=torch.bfloat16)
+    outs = []
+    for _ in range(20):
+        for t in (x, w, b):
+            t.grad = None
+        out = causal_conv1d_fn(x, w, b, "silu")
+        out.backward(g)
+        outs.append((out.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for o, dx, dw, db in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(dx, outs[0][1])
+        assert (dw - outs[0][2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
+        assert (db - outs[0][3]).abs().max() <= 1e-4 * outs[0][3].abs().max()
+
+
+# =================================================================================================
+# fused nodes and modules vs golden (reference CPU path)
+# =================================================================================================
+INNER_KEYS = ("xz", "conv1d_weight", "conv1d_bias", "x_proj_weight", "delta_proj_weight", "out_proj_weight",
+              "A", "A_b", "D", "delta_bias")
+
+
+@pytest.mark.parametrize("kind", ["no_out_proj", "out_proj", "bi"])
+def test_fused_inner_vs_golden(kind):
+    from mamba_ssm.ops import selective_scan_interface as ssi
+    g = load_golden("inner_" + kind)
+    t = {k: G(g[k], grad=True) for k in INNER_KEYS}
+    if kind == "no_out_proj":
+        out = ssi.mamba_inner_fn_no_out_proj(t["xz"], t["conv1d_weight"], t["conv1d_bias"], t["x_proj_weight"],
+                                             t["delta_proj_weight"], t["A"], None, None, t["D"],
+                                             delta_bias=t["delta_bias"], delta_softplus=True)
+    elif kind == "out_proj":
+        out = ssi.mamba_inner_fn(t["xz"], t["conv1d_weight"], t["conv1d_bias"], t["x_proj_weight"],
+                                 t["delta_proj_weight"], t["out_proj_weight"], None, t["A"], None, None, t["D"],
+                                 delta_bias=t["delta_bias"], delta_softplus=True)
+    else:
+        out = ssi.bimamba_inner_fn(t["xz"], t["conv1d_weight"], t["conv1d_bias"], t["x_proj_weight"],
+                                   t["delta_proj_weight"], t["out_proj_weight"], None, t["A"], t["A_b"], None, None,
+                                   t["D"], delta_bias=t["delta_bias"], delta_softplus=True)
+    check(out, g["out"], 2e-3, "out")
+    out.backward(G(g["g"]))
+    for k in INNER_KEYS:
+        if "d" + k in g:
+            check(t[k].grad, g["d" + k], 5e-3, "d" + k)
+
+
+@pytest.mark.parametrize("name,which,kw", [
+    ("block_vim", "mamba_simple", dict(bimamba_type="v2")),
+    ("block_vim_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),
+    ("block_vim_norm", "mamba_simple_scan_norm", dict(bimamba_type="v2", if_devide_out=True)),
+    ("block_dbm", "mamba_new", dict(expand=1)),
+])
+@pytest.mark.parametrize("fast", [True, False])
+def test_block_vs_golden(name, which, kw, fast):
+    import importlib
+    if which == "mamba_new" and not fast:
+        pytest.skip("DBM has no slow path (reference mamba_new.py:216)")
+    g = load_golden(name)
+    Mamba = importlib.import_module("mamba_ssm.modules." + which).Mamba
+    sd = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")}
+    m = Mamba(g["x"].shape[-1], d_state=8, d_conv=4, use_fast_path=fast, **({"expand": 2} | kw))
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    x = G(g["x"], grad=True)
+    y = m(x)
+    check(y, g["y"], 2e-3, "y")
+    y.backward(G(g["g"]))
+    check(x.grad, g["dx"], 5e-3, "dx")
+    for k, p in m.named_parameters():
+        check(p.grad, g["grad." + k], 1e-2, "grad " + k)
+
+
+def test_block_bf16_autocast_runs_and_matches_fp32():
+    """The suite trains under autocast(bf16) (run_class_finetuning.py:570-582): same module, bf16
+    autocast vs fp32, agree to bf16 accuracy."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(128, expand=1, bimamba_type="v2").to(DEV)
+    x = torch.randn(2, 300, 128, device=DEV, requires_grad=True)
+    y32 = m(x)
+    y32.float().square().mean().backward()
+    g32 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y16 = m(x)
+        loss = y16.float().square().mean()
+    loss.backward()
+    assert y16.dtype == torch.bfloat16
+    check(y16, y32.detach().float().cpu().numpy(), 3e-2, "autocast output")
+    for k, p in m.named_parameters():
+        check(p.grad, g32[k].float().cpu().numpy(), 8e-2, "autocast grad " + k)

@@ -1,0 +1,340 @@
+// selective_scan_bwd.hip -- backward selective scan for gfx950 (wave64).
+//
+// Replaces selective_scan_bwd_kernel (mamba/csrc/selective_scan/selective_scan_bwd_kernel.cuh:
+// 75-489), BlockReverseScan (reverse_scan.cuh:202-401) and the launcher (:491-531).
+// Design (DESIGN.md "scan backward"):
+//   * same decomposition as the forward: one wave = one (batch, dim) row, 64*K-element chunks
+//     walked from the END of the sequence to the start, lane j owns K consecutive elements.
+//   * per state n the forward recurrence is re-scanned from the 1024-element checkpoints the
+//     forward wrote into x (vms_hip.h), then the adjoint recurrence
+//         g_l = C_l dy_l + a_{l+1} g_{l+1}
+//     is scanned right-to-left with a DPP suffix scan; both keep their K values in registers.
+//   * dB / dC (sums over the dims of a group) are first reduced over the 4 rows of the
+//     workgroup in a padded LDS tile (ds_add_f32), then flushed with coalesced fp32 global
+//     atomics -- 4x fewer L2 atomics than one per (row, state, position) as in the reference
+//     (selective_scan_bwd_kernel.cuh:297-316).
+//   * dA, dD, ddelta_bias, constant-B/C gradients: wave reduction, one atomic per row.
+#include "vms_common.cuh"
+
+namespace vms {
+
+int validate_scan_common(const vms_scan_fwd_params& p);
+bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
+
+constexpr int kBwdRows = 4;
+constexpr int kTilePad = 65;  // tile index = i * 65 + lane : conflict-free ds_add, 2-way flush
+
+template <typename T, int K, bool VB, bool VC, bool HZ, bool VEC>
+__global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_scan_bwd_params q) {
+    const vms_scan_fwd_params& p = q.f;
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = (p.dim + kBwdRows - 1) / kBwdRows;
+    const int b = blockIdx.x / tiles;
+    const int d0 = (blockIdx.x - b * tiles) * kBwdRows;
+    const int dpg = p.dim / p.n_groups;
+    const bool row_ok = d0 + wave < p.dim;
+    const int d = row_ok ? d0 + wave : p.dim - 1;
+    const int g = d / dpg;
+    // all rows of this workgroup in one group -> dB/dC can be pre-reduced in LDS
+    const int d_last = min(d0 + kBwdRows, p.dim) - 1;
+    const bool same_group = (d0 / dpg) == (d_last / dpg);
+    const int g0 = d0 / dpg;
+    const int L = p.seqlen, N = p.dstate;
+    constexpr int CS = kWave * K;
+    constexpr int TILE = K * kTilePad;
+
+    // LDS carve: [2 buffers][dB tile | dC tile] shared by the WG, then per-wave state arrays
+    lds_f32* tiles_lds = (lds_f32*)smem;                                     // 2 * 2 * TILE floats
+    volatile lds_f32* wv = (lds_f32*)smem + 4 * TILE + wave * (5 * N);       // per wave state arrays
+    volatile lds_f32* gcarry = wv;          // adjoint entering from the right, per state
+    volatile lds_f32* anext = wv + N;       // a of the first element of the chunk to the right
+    volatile lds_f32* dA_acc = wv + 2 * N;  // dA accumulated over chunks
+    volatile lds_f32* dBc_acc = wv + 3 * N; // gradient of a constant (dim, dstate) B
+    volatile lds_f32* dCc_acc = wv + 4 * N; // gradient of a constant (dim, dstate) C
+    for (int n = lane; n < N; n += kWave) {
+        gcarry[n] = 0.f;
+        anext[n] = 1.f;
+        dA_acc[n] = 0.f;
+        dBc_acc[n] = 0.f;
+        dCc_acc[n] = 0.f;
+    }
+    for (int i = threadIdx.x; i < 4 * TILE; i += blockDim.x) tiles_lds[i] = 0.f;
+    __syncthreads();
+
+    const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
+    const T* dt = static_cast<const T*>(p.delta) + (int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride;
+    const T* dout = static_cast<const T*>(q.dout) + (int64_t)b * q.dout_batch_stride + (int64_t)d * q.dout_d_stride;
+    T* du = static_cast<T*>(q.du) + (int64_t)b * q.du_batch_stride + (int64_t)d * q.du_d_stride;
+    T* ddelta = static_cast<T*>(q.ddelta) + (int64_t)b * q.ddelta_batch_stride + (int64_t)d * q.ddelta_d_stride;
+    const T* z = HZ ? static_cast<const T*>(p.z) + (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride : nullptr;
+    const T* outp = HZ ? static_cast<const T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride : nullptr;
+    T* dz = HZ ? static_cast<T*>(q.dz) + (int64_t)b * q.dz_batch_stride + (int64_t)d * q.dz_d_stride : nullptr;
+    T* out_z = (HZ && p.out_z) ? static_cast<T*>(p.out_z) + (int64_t)b * p.out_z_batch_stride + (int64_t)d * p.out_z_d_stride : nullptr;
+    const float* A = static_cast<const float*>(p.A) + (int64_t)d * p.A_d_stride;
+    const T* Bv = VB ? static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride : nullptr;
+    const T* Cv = VC ? static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride : nullptr;
+    const float* Bc = !VB ? static_cast<const float*>(p.B) + (int64_t)d * p.B_d_stride : nullptr;
+    const float* Cc = !VC ? static_cast<const float*>(p.C) + (int64_t)d * p.C_d_stride : nullptr;
+    const float* xck = p.x ? static_cast<const float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * 2 * N : nullptr;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+    float* dBg = VB ? q.dB + (int64_t)b * q.dB_batch_stride : nullptr;  // + group, state, l below
+    float* dCg = VC ? q.dC + (int64_t)b * q.dC_batch_stride : nullptr;
+
+    float dD_acc = 0.f, dbias_acc = 0.f;
+    int buf = 0;  // LDS tile double buffer, flips once per (chunk, state)
+
+    const int n_kchunks = (L + CS - 1) / CS;
+    for (int c = n_kchunks - 1; c >= 0; --c) {
+        const int l0 = c * CS + lane * K;
+        const int nv = row_ok ? L - l0 : 0;
+        float uv[K], dl[K], dy[K], duv[K], ddl[K];
+        load_blocked<T, K, VEC>(u + l0, nv, uv);
+        load_blocked<T, K, VEC>(dt + l0, nv, dl);
+        load_blocked<T, K, VEC>(dout + l0, nv, dy);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            float t = dl[i] + bias;
+            if (p.delta_softplus) t = softplusf_(t);
+            dl[i] = i < nv ? t : 0.f;
+        }
+        if (HZ) {
+            float zv[K], ov[K];
+            load_blocked<T, K, VEC>(z + l0, nv, zv);
+            load_blocked<T, K, VEC>(outp + l0, nv, ov);
+            float dzv[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float s = sigmoidf_(zv[i]);
+                const float silu = zv[i] * s;
+                dzv[i] = dy[i] * ov[i] * s * (1.f + zv[i] * (1.f - s));
+                dy[i] *= silu;
+                ov[i] *= silu;
+            }
+            store_blocked<T, K, VEC>(dz + l0, nv, dzv);
+            if (out_z) store_blocked<T, K, VEC>(out_z + l0, nv, ov);
+        }
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            duv[i] = Dd * dy[i];
+            dD_acc = fmaf(dy[i], uv[i], dD_acc);
+            ddl[i] = 0.f;
+        }
+        // checkpoint holding the state at the start of this chunk (position c*CS)
+        const int pos0 = c * CS;
+        const float* xin = nullptr;
+        int xoff = 0;
+        if (pos0 > 0) {
+            const int blk = pos0 / 2048;
+            if (pos0 % 2048 == 0) { xin = xck + (int64_t)(blk - 1) * 2 * N; xoff = 1; }
+            else { xin = xck + (int64_t)blk * 2 * N; xoff = 0; }  // pos0 % 2048 == 1024
+        }
+        for (int n = 0; n < N; ++n) {
+            const float Araw = A[n * p.A_dstate_stride];
+            const float An = Araw * kLog2e;
+            float Bn[K], Cn[K];
+            if (VB) load_blocked<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride + l0, nv, Bn);
+            if (VC) load_blocked<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride + l0, nv, Cn);
+            const float bconst = VB ? 1.f : Bc[n * p.B_dstate_stride];
+            const float cconst = VC ? 1.f : Cc[n * p.C_dstate_stride];
+            // ---- forward re-scan: x_i for the lane's K elements ----
+            float a[K], xs[K];
+            float pa = 1.f, px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                a[i] = fast_exp2(dl[i] * An);
+                const float bxi = dl[i] * uv[i] * (VB ? Bn[i] : bconst);
+                px = fmaf(a[i], px, bxi);
+                pa *= a[i];
+            }
+            wave_scan_inclusive(pa, px);
+            const float ea = dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa);
+            const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
+            const float hin = xin ? xin[2 * n + xoff] : 0.f;
+            float xrun = fmaf(ea, hin, ex);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float bxi = dl[i] * uv[i] * (VB ? Bn[i] : bconst);
+                xrun = fmaf(a[i], xrun, bxi);
+                xs[i] = xrun;
+            }
+            // ---- adjoint scan, right to left: g_i = C_i dy_i + alpha_i g_{i+1}, alpha_i = a_{i+1}
+            const float a_right_lane = dpp_mov<DPP_WAVE_SHL1, 0xf>(anext[n], a[0]);  // lane 63 <- next chunk
+            float gl[K];
+            float ra = 1.f, rg = 0.f;
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                const float alpha = i == K - 1 ? a_right_lane : a[i + 1];
+                const float ci = dy[i] * (VC ? Cn[i] : cconst);
+                rg = fmaf(alpha, rg, ci);
+                ra *= alpha;
+            }
+            wave_scan_inclusive_reverse(ra, rg);
+            const float esa = dpp_mov<DPP_WAVE_SHL1, 0xf>(1.f, ra);
+            const float esx = dpp_mov<DPP_WAVE_SHL1, 0xf>(0.f, rg);
+            const float gin = gcarry[n];
+            float grun = fmaf(esa, gin, esx);
+            const float gout = fmaf(readlane_f(ra, 0), gin, readlane_f(rg, 0));
+            const float a_first = readlane_f(a[0], 0);
+            if (lane == 0) {
+                gcarry[n] = gout;
+                anext[n] = a_first;
+            }
+            float dA_loc = 0.f, dBc_loc = 0.f, dCc_loc = 0.f;
+            lds_f32* tb = tiles_lds + buf * 2 * TILE;
+            lds_f32* tc = tb + TILE;
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                const float alpha = i == K - 1 ? a_right_lane : a[i + 1];
+                const float ci = dy[i] * (VC ? Cn[i] : cconst);
+                grun = fmaf(alpha, grun, ci);
+                gl[i] = grun;
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float gx = gl[i];
+                const float du_i = dl[i] * uv[i];
+                const float Bi = VB ? Bn[i] : bconst;
+                const float ddelta_u = gx * Bi;
+                const float ax = xs[i] - du_i * Bi;  // a_i * x_{i-1}
+                duv[i] = fmaf(ddelta_u, dl[i], duv[i]);
+                ddl[i] = fmaf(ddelta_u, uv[i], ddl[i]);
+                ddl[i] = fmaf(gx * Araw, ax, ddl[i]);
+                dA_loc = fmaf(gx * dl[i], ax, dA_loc);
+                const float dBi = gx * du_i;
+                const float dCi = dy[i] * xs[i];
+                if (VB) {
+                    if (same_group) { if (i < nv) lds_atomic_add(&tb[i * kTilePad + lane], dBi); }
+                    else if (i < nv) atomicAdd(dBg + (int64_t)g * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + l0 + i, dBi);
+                } else {
+                    dBc_loc += dBi;
+                }
+                if (VC) {
+                    if (same_group) { if (i < nv) lds_atomic_add(&tc[i * kTilePad + lane], dCi); }
+                    else if (i < nv) atomicAdd(dCg + (int64_t)g * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + l0 + i, dCi);
+                } else {
+                    dCc_loc += dCi;
+                }
+            }
+            const float dA_tot = wave_sum(dA_loc);
+            if (lane == 0) dA_acc[n] += dA_tot;
+            if (!VB) {
+                const float t = wave_sum(dBc_loc);
+                if (lane == 0) dBc_acc[n] += t;
+            }
+            if (!VC) {
+                const float t = wave_sum(dCc_loc);
+                if (lane == 0) dCc_acc[n] += t;
+            }
+            if ((VB || VC) && same_group) {
+                __syncthreads();  // every row's contribution to (chunk, state) is in tile `buf`
+                const int lim = min(CS, L - c * CS);
+                for (int j = threadIdx.x; j < lim; j += blockDim.x) {
+                    const int ti = (j % K) * kTilePad + (j / K);
+                    if (VB) {
+                        atomicAdd(dBg + (int64_t)g0 * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + c * CS + j, tb[ti]);
+                        tb[ti] = 0.f;
+                    }
+                    if (VC) {
+                        atomicAdd(dCg + (int64_t)g0 * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + c * CS + j, tc[ti]);
+                        tc[ti] = 0.f;
+                    }
+                }
+                buf ^= 1;  // the other buffer was flushed+zeroed one barrier ago
+            }
+        }
+        // softplus chain (bwd_kernel.cuh:439-452) and stores
+        {
+            float raw[K];
+            load_blocked<T, K, VEC>(dt + l0, nv, raw);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                if (p.delta_softplus) {
+                    const float r = raw[i] + bias;
+                    ddl[i] = r <= 20.f ? ddl[i] * sigmoidf_(r) : ddl[i];
+                }
+                if (i < nv) dbias_acc += ddl[i];
+            }
+        }
+        store_blocked<T, K, VEC>(du + l0, nv, duv);
+        store_blocked<T, K, VEC>(ddelta + l0, nv, ddl);
+    }
+    if (row_ok) {
+        if (q.dD) {
+            const float t = wave_sum(dD_acc);
+            if (lane == 0) atomicAdd(q.dD + d, t);
+        }
+        if (q.ddelta_bias) {
+            const float t = wave_sum(dbias_acc);
+            if (lane == 0) atomicAdd(q.ddelta_bias + d, t);
+        }
+        for (int n = lane; n < N; n += kWave) {
+            atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)n * q.dA_dstate_stride, dA_acc[n]);
+            if (!VB) atomicAdd(q.dB + (int64_t)d * q.dB_d_stride + (int64_t)n * q.dB_dstate_stride, dBc_acc[n]);
+            if (!VC) atomicAdd(q.dC + (int64_t)d * q.dC_d_stride + (int64_t)n * q.dC_dstate_stride, dCc_acc[n]);
+        }
+    }
+}
+
+template <typename T, int K, bool VB, bool VC, bool HZ>
+static int launch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t stream) {
+    const vms_scan_fwd_params& p = q.f;
+    const int tiles = (p.dim + kBwdRows - 1) / kBwdRows;
+    dim3 grid(p.batch * tiles), block(kBwdRows * kWave);
+    const size_t smem = sizeof(float) * (4 * K * kTilePad + kBwdRows * 5 * p.dstate);
+    if (vec)
+        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, true>), grid, block, smem, stream, q);
+    else
+        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, false>), grid, block, smem, stream, q);
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+
+template <typename T, int K>
+static int dispatch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t s) {
+    const bool vb = q.f.is_variable_B, vc = q.f.is_variable_C, hz = q.f.z != nullptr;
+#define VMS_CASE(B_, C_, Z_) \
+    if (vb == B_ && vc == C_ && hz == Z_) return launch_bwd<T, K, B_, C_, Z_>(q, vec, s);
+    VMS_CASE(true, true, true)
+    VMS_CASE(true, true, false)
+    VMS_CASE(true, false, true)
+    VMS_CASE(true, false, false)
+    VMS_CASE(false, true, true)
+    VMS_CASE(false, true, false)
+    VMS_CASE(false, false, true)
+    VMS_CASE(false, false, false)
+#undef VMS_CASE
+    return VMS_ERR_INVALID_ARG;
+}
+
+}  // namespace vms
+
+using namespace vms;
+
+extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* stream) {
+    VMS_CHECK(qq != nullptr, "null params");
+    const vms_scan_bwd_params& q = *qq;
+    const vms_scan_fwd_params& p = q.f;
+    if (int rc = validate_scan_common(p)) return rc;
+    VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
+    VMS_CHECK(p.x != nullptr || p.seqlen <= 1024, "x (scan checkpoints) is required when seqlen > 1024");
+    if (p.z) {
+        VMS_CHECK(p.out != nullptr, "out is required when z is given");
+        VMS_CHECK(q.dz != nullptr, "dz is required when z is given");
+    }
+    VMS_CHECK((p.D == nullptr) == (q.dD == nullptr), "dD must be given iff D is given");
+    VMS_CHECK((p.delta_bias == nullptr) == (q.ddelta_bias == nullptr), "ddelta_bias must be given iff delta_bias is given");
+    const int es = p.dtype == VMS_F32 ? 4 : 2;
+    bool vec = scan_fwd_vec_ok(p) && aligned16(q.dout) && aligned16(q.du) && aligned16(q.ddelta) &&
+               mult16(q.dout_batch_stride, es) && mult16(q.dout_d_stride, es) && mult16(q.du_batch_stride, es) &&
+               mult16(q.du_d_stride, es) && mult16(q.ddelta_batch_stride, es) && mult16(q.ddelta_d_stride, es);
+    if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (p.dtype) {
+        case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);
+        case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);
+        default: return dispatch_bwd<bf16_t, 16>(q, vec, s);
+    }
+}

@@ -1,0 +1,217 @@
+// selective_scan_fwd.hip -- forward selective scan for gfx950 (wave64).
+//
+// Replaces selective_scan_fwd_kernel (mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:
+// 67-303) and its launcher (:305-345).  Design (DESIGN.md "scan forward"):
+//   * one WAVE owns one (batch, dim) row; a 256-thread workgroup = 4 rows of the same batch.
+//     No __syncthreads anywhere: the scan is carried entirely by wave64 DPP primitives.
+//   * the row is walked in chunks of 64*K elements; lane j owns the K consecutive elements
+//     [j*K, (j+1)*K) of the chunk (16/32-byte vector loads per lane).
+//   * per state n: serial in-register scan of the lane's K elements -> 64-lane DPP scan of
+//     the lane aggregates -> seeded second pass that also contracts with C.  a = exp2(delta *
+//     A * log2e) is evaluated once and kept in registers between the two passes.
+//   * the running state of the 16.. dstate recurrences lives in LDS (one float per state per
+//     wave, wave-private), so dstate is a runtime value (<= 256 as in the reference).
+//   * checkpoints x[b,d,c,:] are written every 1024 elements (vms_hip.h).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vms_common.cuh"
+
+namespace vms {
+
+namespace {
+thread_local char g_err[512] = "";
+}
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+constexpr int kRowsPerWG = 4;
+
+template <typename T, int K, bool VB, bool VC, bool HZ, bool VEC>
+__global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_scan_fwd_params p) {
+    extern __shared__ float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tiles = (p.dim + kRowsPerWG - 1) / kRowsPerWG;
+    const int b = blockIdx.x / tiles;
+    const int d = (blockIdx.x - b * tiles) * kRowsPerWG + wave;
+    if (d >= p.dim) return;
+    const int g = d / (p.dim / p.n_groups);
+    const int L = p.seqlen, N = p.dstate;
+    constexpr int CS = kWave * K;  // elements per wave-chunk
+
+    volatile lds_f32* h = (lds_f32*)smem + wave * N;  // running state per n (wave-private)
+    for (int n = lane; n < N; n += kWave) h[n] = 0.f;
+
+    const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
+    const T* dt = static_cast<const T*>(p.delta) + (int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride;
+    T* out = static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride;
+    const T* z = HZ ? static_cast<const T*>(p.z) + (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride : nullptr;
+    T* out_z = HZ ? static_cast<T*>(p.out_z) + (int64_t)b * p.out_z_batch_stride + (int64_t)d * p.out_z_d_stride : nullptr;
+    const float* A = static_cast<const float*>(p.A) + (int64_t)d * p.A_d_stride;
+    const T* Bv = VB ? static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride : nullptr;
+    const T* Cv = VC ? static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride : nullptr;
+    const float* Bc = !VB ? static_cast<const float*>(p.B) + (int64_t)d * p.B_d_stride : nullptr;
+    const float* Cc = !VC ? static_cast<const float*>(p.C) + (int64_t)d * p.C_d_stride : nullptr;
+    float* xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * 2 * N;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+
+    const int n_kchunks = (L + CS - 1) / CS;
+    for (int c = 0; c < n_kchunks; ++c) {
+        const int l0 = c * CS + lane * K;
+        const int nv = L - l0;  // valid elements from l0 (may be <= 0 or >= K)
+        float uv[K], dl[K], du[K], y[K];
+        load_blocked<T, K, VEC>(u + l0, nv, uv);
+        load_blocked<T, K, VEC>(dt + l0, nv, dl);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            float t = dl[i] + bias;
+            if (p.delta_softplus) t = softplusf_(t);
+            // positions past the end must be the identity (a=1, b=0): delta = 0 does both
+            dl[i] = i < nv ? t : 0.f;
+            du[i] = dl[i] * uv[i];
+            y[i] = Dd * uv[i];
+        }
+        for (int n = 0; n < N; ++n) {
+            const float An = A[n * p.A_dstate_stride] * kLog2e;
+            float Bn[K], Cn[K];
+            if (VB) load_blocked<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride + l0, nv, Bn);
+            if (VC) load_blocked<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride + l0, nv, Cn);
+            const float bconst = VB ? 1.f : Bc[n * p.B_dstate_stride];
+            const float cconst = VC ? 1.f : Cc[n * p.C_dstate_stride];
+            float a[K], bx[K];
+            float pa = 1.f, px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                a[i] = fast_exp2(dl[i] * An);
+                bx[i] = VB ? du[i] * Bn[i] : du[i] * bconst;
+                px = fmaf(a[i], px, bx[i]);
+                pa *= a[i];
+            }
+            wave_scan_inclusive(pa, px);
+            // exclusive prefix of this lane, then seed with the state carried from earlier chunks
+            const float ea = dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa);
+            const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
+            const float hin = h[n];
+            float xs = fmaf(ea, hin, ex);
+            const float hout = fmaf(readlane_f(pa, 63), hin, readlane_f(px, 63));
+            if (lane == 0) h[n] = hout;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                xs = fmaf(a[i], xs, bx[i]);
+                y[i] = fmaf(VC ? Cn[i] : cconst, xs, y[i]);
+            }
+        }
+        store_blocked<T, K, VEC>(out + l0, nv, y);
+        if (HZ) {
+            float zv[K];
+            load_blocked<T, K, VEC>(z + l0, nv, zv);
+#pragma unroll
+            for (int i = 0; i < K; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
+            store_blocked<T, K, VEC>(out_z + l0, nv, y);
+        }
+        // checkpoints every 1024 elements (and at the end of the sequence)
+        const int pos = (c + 1) * CS;
+        const bool last = c == n_kchunks - 1;
+        if ((pos & 1023) == 0 || last) {
+            const int blk = last ? (L - 1) / 2048 : (pos - 1) / 2048;
+            const int r = (last ? L : pos) - blk * 2048;  // elements of block blk seen so far
+            float* xb = xck + (int64_t)blk * 2 * N;
+            const bool w_even = r <= 1024, w_odd = r == 2048 || last;
+            for (int n = lane; n < N; n += kWave) {
+                const float s = h[n];
+                if (w_even) xb[2 * n] = s;
+                if (w_odd) xb[2 * n + 1] = s;
+            }
+        }
+    }
+}
+
+template <typename T, int K, bool VB, bool VC, bool HZ>
+static int launch_fwd(const vms_scan_fwd_params& p, bool vec, hipStream_t stream) {
+    const int tiles = (p.dim + kRowsPerWG - 1) / kRowsPerWG;
+    dim3 grid(p.batch * tiles), block(kRowsPerWG * kWave);
+    const size_t smem = sizeof(float) * kRowsPerWG * p.dstate;
+    if (vec)
+        hipLaunchKernelGGL((scan_fwd_kernel<T, K, VB, VC, HZ, true>), grid, block, smem, stream, p);
+    else
+        hipLaunchKernelGGL((scan_fwd_kernel<T, K, VB, VC, HZ, false>), grid, block, smem, stream, p);
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+
+template <typename T, int K>
+static int dispatch_fwd(const vms_scan_fwd_params& p, bool vec, hipStream_t s) {
+    const bool vb = p.is_variable_B, vc = p.is_variable_C, hz = p.z != nullptr;
+#define VMS_CASE(B_, C_, Z_) \
+    if (vb == B_ && vc == C_ && hz == Z_) return launch_fwd<T, K, B_, C_, Z_>(p, vec, s);
+    VMS_CASE(true, true, true)
+    VMS_CASE(true, true, false)
+    VMS_CASE(true, false, true)
+    VMS_CASE(true, false, false)
+    VMS_CASE(false, true, true)
+    VMS_CASE(false, true, false)
+    VMS_CASE(false, false, true)
+    VMS_CASE(false, false, false)
+#undef VMS_CASE
+    return VMS_ERR_INVALID_ARG;
+}
+
+int validate_scan_common(const vms_scan_fwd_params& p) {
+    VMS_CHECK(p.dtype == VMS_F32 || p.dtype == VMS_F16 || p.dtype == VMS_BF16, "input dtype must be fp32/fp16/bf16");
+    VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0 && p.dstate > 0, "empty problem");
+    VMS_CHECK(p.dstate <= 256, "selective_scan only supports state dimension <= 256");
+    VMS_CHECK(p.n_groups >= 1 && p.dim % p.n_groups == 0, "dim must be divisible by n_groups");
+    VMS_CHECK(p.n_chunks == (p.seqlen + 2047) / 2048, "n_chunks must be ceil(seqlen / 2048)");
+    VMS_CHECK(p.u && p.delta && p.A && p.B && p.C, "u, delta, A, B, C are required");
+    return VMS_OK;
+}
+
+bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
+    const int es = p.dtype == VMS_F32 ? 4 : 2;
+    bool ok = aligned16(p.u) && aligned16(p.delta) && aligned16(p.out) && mult16(p.u_batch_stride, es) &&
+              mult16(p.u_d_stride, es) && mult16(p.delta_batch_stride, es) && mult16(p.delta_d_stride, es) &&
+              mult16(p.out_batch_stride, es) && mult16(p.out_d_stride, es);
+    if (p.z)
+        ok = ok && aligned16(p.z) && aligned16(p.out_z) && mult16(p.z_batch_stride, es) &&
+             mult16(p.z_d_stride, es) && mult16(p.out_z_batch_stride, es) && mult16(p.out_z_d_stride, es);
+    if (p.is_variable_B)
+        ok = ok && aligned16(p.B) && mult16(p.B_batch_stride, es) && mult16(p.B_group_stride, es) &&
+             mult16(p.B_dstate_stride, es);
+    if (p.is_variable_C)
+        ok = ok && aligned16(p.C) && mult16(p.C_batch_stride, es) && mult16(p.C_group_stride, es) &&
+             mult16(p.C_dstate_stride, es);
+    return ok;
+}
+
+}  // namespace vms
+
+using namespace vms;
+
+extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* stream) {
+    VMS_CHECK(pp != nullptr, "null params");
+    const vms_scan_fwd_params& p = *pp;
+    if (int rc = validate_scan_common(p)) return rc;
+    VMS_CHECK(p.out && p.x, "out and x must be provided by the caller");
+    VMS_CHECK((p.z == nullptr) == (p.out_z == nullptr), "out_z must be given iff z is given");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool vec = scan_fwd_vec_ok(p);
+    switch (p.dtype) {
+        case VMS_F32: return dispatch_fwd<float, 16>(p, vec, s);
+        case VMS_F16: return dispatch_fwd<f16_t, 16>(p, vec, s);
+        default: return dispatch_fwd<bf16_t, 16>(p, vec, s);
+    }
+}
+
+extern "C" const char* vms_last_error(void) { return vms::last_error(); }
+extern "C" int vms_abi_version(void) { return VMS_ABI_VERSION; }
+extern "C" int vms_sizeof_scan_fwd_params(void) { return (int)sizeof(vms_scan_fwd_params); }
+extern "C" int vms_sizeof_scan_bwd_params(void) { return (int)sizeof(vms_scan_bwd_params); }
+extern "C" int vms_sizeof_conv_fwd_params(void) { return (int)sizeof(vms_conv_fwd_params); }
+extern "C" int vms_sizeof_conv_bwd_params(void) { return (int)sizeof(vms_conv_bwd_params); }

@@ -1,0 +1,275 @@
+"""Shared implementation of the three `Mamba` module variants of the suite plus `Block`.
+
+  variant "vim"       mamba_ssm/modules/mamba_simple.py            ViM "v2": two parameter sets, two scans
+                      (reference mamba/mamba_ssm/modules/mamba_simple.py:34-155, 201-290)
+  variant "vim_norm"  mamba_ssm/modules/mamba_simple_scan_norm.py  = vim + RMSNorm before out_proj when
+                      if_devide_out (reference mamba_simple_scan_norm.py:154-155, 263-265, 290-292)
+  variant "dbm"       mamba_ssm/modules/mamba_new.py               DBM: shared weights, forward and reversed
+                      sequence stacked on the batch axis (reference mamba_new.py:34-122, 168-229)
+
+What is preserved: constructor arguments, attribute / state-dict names and shapes, init rules
+(dt_proj weight U(+-dt_rank^-0.5 * dt_scale); dt bias = softplus^-1 of log-uniform[dt_min, dt_max],
+flagged _no_reinit; A_log = log(1..d_state) fp32 flagged _no_weight_decay; D = 1), the order in
+which parameters are created (so a seed gives the same initial weights), forward semantics.
+"""
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
+from mamba_ssm.ops.selective_scan_interface import (mamba_inner_fn, mamba_inner_fn_no_out_proj,
+                                                    selective_scan_fn)
+from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
+from mamba_ssm.ops.triton.selective_state_update import selective_state_update
+
+
+def _s4d_real_log(d_inner, d_state, device):
+    A = torch.arange(1, d_state + 1, dtype=torch.float32, device=device).repeat(d_inner, 1).contiguous()
+    return torch.log(A)
+
+
+class MambaCore(nn.Module):
+    variant = "vim"
+
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=True, layer_idx=None, device=None, dtype=None, bimamba_type="none",
+                 if_devide_out=False, init_layer_scale=None):
+        factory_kwargs = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model = d_model
+        self.d_state = d_state
+        self.d_conv = d_conv
+        self.expand = expand
+        self.d_inner = int(self.expand * self.d_model)
+        self.dt_rank = math.ceil(self.d_model / 16) if dt_rank == "auto" else dt_rank
+        self.use_fast_path = use_fast_path
+        self.layer_idx = layer_idx
+        dbm = self.variant == "dbm"
+        if not dbm:
+            self.bimamba_type = bimamba_type
+            self.if_devide_out = if_devide_out
+
+        # DBM emits (x, z) for both directions from one projection: 4 * d_inner channels
+        self.in_proj = nn.Linear(self.d_model, self.d_inner * (4 if dbm else 2), bias=bias, **factory_kwargs)
+        self.conv1d = self._make_conv(conv_bias, factory_kwargs)
+        self.activation = "silu"
+        self.act = nn.SiLU()
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+
+        dt_init_std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(self.dt_proj.weight, dt_init_std)
+        elif dt_init == "random":
+            nn.init.uniform_(self.dt_proj.weight, -dt_init_std, dt_init_std)
+        else:
+            raise NotImplementedError
+        # bias such that softplus(bias) is log-uniform in [dt_min, dt_max]
+        dt = torch.exp(torch.rand(self.d_inner, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        inv_dt = dt + torch.log(-torch.expm1(-dt))
+        with torch.no_grad():
+            self.dt_proj.bias.copy_(inv_dt)
+        self.dt_proj.bias._no_reinit = True
+
+        self.A_log = nn.Parameter(_s4d_real_log(self.d_inner, self.d_state, device))  # fp32
+        self.A_log._no_weight_decay = True
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))  # fp32
+        self.D._no_weight_decay = True
+
+        if not dbm:
+            assert bimamba_type == "v2"
+            # second, independent parameter set for the reversed direction
+            self.A_b_log = nn.Parameter(_s4d_real_log(self.d_inner, self.d_state, device))
+            self.A_b_log._no_weight_decay = True
+            self.conv1d_b = self._make_conv(conv_bias, factory_kwargs)
+            self.x_proj_b = nn.Linear(self.d_inner, self.dt_rank + self.d_state * 2, bias=False, **factory_kwargs)
+            self.dt_proj_b = nn.Linear(self.dt_rank, self.d_inner, bias=True, **factory_kwargs)
+            self.D_b = nn.Parameter(torch.ones(self.d_inner, device=device))
+            self.D_b._no_weight_decay = True
+
+        self.out_proj = nn.Linear(self.d_inner * (2 if dbm else 1), self.d_model, bias=bias, **factory_kwargs)
+        if self.variant == "vim_norm":
+            self.norm = RMSNorm(self.d_inner, eps=1e-5, **factory_kwargs)
+
+    def _make_conv(self, conv_bias, factory_kwargs):
+        return nn.Conv1d(in_channels=self.d_inner, out_channels=self.d_inner, bias=conv_bias,
+                         kernel_size=self.d_conv, groups=self.d_inner, padding=self.d_conv - 1, **factory_kwargs)
+
+    # ---- pieces ---------------------------------------------------------------------------------
+    def _in_projection(self, hidden_states):
+        """(B, L, d_model) -> xz (B, C, L): GEMM and BLH->HBL transpose in one step."""
+        batch, seqlen, _ = hidden_states.shape
+        w = self.in_proj.weight
+        xz = (w @ hidden_states.reshape(batch * seqlen, -1).t()).view(w.shape[0], batch, seqlen).permute(1, 0, 2)
+        if self.in_proj.bias is not None:
+            xz = xz + self.in_proj.bias.to(dtype=xz.dtype)[:, None]
+        return xz
+
+    def python_mamba_inner_fn_no_out_proj(self, xz, A, conv_state, ssm_state, seqlen, conv1d, x_proj, dt_proj, D,
+                                          use_pytorch_conv=False):
+        """Unfused path (use_fast_path=False): separate conv, projections and scan ops."""
+        x, z = xz.chunk(2, dim=1)
+        if conv_state is not None:
+            conv_state.copy_(x[:, :, -self.d_conv:])
+        if causal_conv1d_fn is None or use_pytorch_conv:
+            x = self.act(conv1d(x)[..., :seqlen])
+        else:
+            assert self.activation in ["silu", "swish"]
+            x = causal_conv1d_fn(x, conv1d.weight.squeeze(1), conv1d.bias, self.activation)
+        batch = x.shape[0]
+        x_dbl = x_proj(x.transpose(1, 2).reshape(batch * seqlen, -1))
+        dt, B, C = torch.split(x_dbl, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = (dt_proj.weight @ dt.t()).view(-1, batch, seqlen).permute(1, 0, 2)
+        B = B.view(batch, seqlen, -1).transpose(1, 2).contiguous()
+        C = C.view(batch, seqlen, -1).transpose(1, 2).contiguous()
+        y = selective_scan_fn(x, dt, A, B, C, D.float(), z=z, delta_bias=dt_proj.bias.float(),
+                              delta_softplus=True, return_last_state=ssm_state is not None)
+        if ssm_state is not None:
+            y, last_state = y
+            ssm_state.copy_(last_state)
+        return y
+
+    def _direction(self, xz, suffix):
+        """One fused direction of the ViM block with parameter set `suffix` ('' or '_b')."""
+        g = lambda name: getattr(self, name + suffix)
+        A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
+        return mamba_inner_fn_no_out_proj(
+            xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A,
+            None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
+
+    def _merge_and_project(self, out, out_b):
+        y = (out + out_b.flip([-1])).transpose(1, 2)  # (B, L, d_inner)
+        if self.if_devide_out:
+            y = self.norm(y) if self.variant == "vim_norm" else y / 2
+        return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+
+    # ---- forward --------------------------------------------------------------------------------
+    def forward(self, hidden_states, inference_params=None):
+        """hidden_states: (B, L, D) -> same shape"""
+        batch, seqlen, _ = hidden_states.shape
+        conv_state, ssm_state = None, None
+        if inference_params is not None:
+            conv_state, ssm_state = self._get_states_from_cache(inference_params, batch)
+            if inference_params.seqlen_offset > 0:
+                out, _, _ = self.step(hidden_states, conv_state, ssm_state)
+                return out
+        xz = self._in_projection(hidden_states)
+        if self.variant == "dbm":
+            return self._forward_dbm(xz, inference_params)
+        fast = self.use_fast_path and inference_params is None
+        if self.bimamba_type == "v2":
+            if fast:
+                out = self._direction(xz, "")
+                out_b = self._direction(xz.flip([-1]), "_b")
+            else:
+                A = -torch.exp(self.A_log.float())
+                A_b = -torch.exp(self.A_b_log.float())
+                out = self.python_mamba_inner_fn_no_out_proj(xz, A, conv_state, ssm_state, seqlen, self.conv1d,
+                                                             self.x_proj, self.dt_proj, self.D, use_pytorch_conv=True)
+                out_b = self.python_mamba_inner_fn_no_out_proj(xz.flip([-1]), A_b, conv_state, ssm_state, seqlen,
+                                                               self.conv1d_b, self.x_proj_b, self.dt_proj_b,
+                                                               self.D_b, use_pytorch_conv=True)
+            return self._merge_and_project(out, out_b)
+        # unidirectional (not constructible today: __init__ asserts "v2", as the reference does)
+        A = -torch.exp(self.A_log.float())
+        if fast:
+            return mamba_inner_fn(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight,
+                                  self.dt_proj.weight, self.out_proj.weight, self.out_proj.bias, A, None, None,
+                                  self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+        y = self.python_mamba_inner_fn_no_out_proj(xz, A, conv_state, ssm_state, seqlen, self.conv1d, self.x_proj,
+                                                   self.dt_proj, self.D)
+        return self.out_proj(y.transpose(1, 2))
+
+    def _forward_dbm(self, xz, inference_params):
+        assert self.use_fast_path and inference_params is None, "Not implemented"  # reference mamba_new.py:216
+        xz_f, xz_b = torch.chunk(xz, 2, dim=1)
+        # the reversed sequence rides along as extra batch entries: one fused call, shared weights
+        stacked = torch.cat([xz_f, xz_b.flip([-1])], dim=0)
+        out = self._direction(stacked, "")
+        out_f, out_b = out.chunk(2)
+        y = torch.cat([out_f, out_b.flip([-1])], dim=1).transpose(1, 2)  # (B, L, 2*d_inner)
+        return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+
+    # ---- autoregressive decode (not used by any video task; kept for API completeness) ----------
+    def step(self, hidden_states, conv_state, ssm_state):
+        dtype = hidden_states.dtype
+        assert hidden_states.shape[1] == 1, "Only support decoding with 1 token at a time for now"
+        xz = self.in_proj(hidden_states.squeeze(1))
+        x, z = xz.chunk(2, dim=-1)
+        if causal_conv1d_update is None or not x.is_cuda:
+            conv_state.copy_(torch.roll(conv_state, shifts=-1, dims=-1))
+            conv_state[:, :, -1] = x
+            x = torch.sum(conv_state * self.conv1d.weight.squeeze(1), dim=-1)
+            if self.conv1d.bias is not None:
+                x = x + self.conv1d.bias
+            x = self.act(x).to(dtype=dtype)
+        else:
+            x = causal_conv1d_update(x, conv_state, self.conv1d.weight.squeeze(1), self.conv1d.bias, self.activation)
+        x_db = self.x_proj(x)
+        dt, B, C = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
+        dt = F.linear(dt, self.dt_proj.weight)  # bias is added inside the state update
+        A = -torch.exp(self.A_log.float())
+        y = selective_state_update(ssm_state, x, dt, A, B, C, self.D, z=z, dt_bias=self.dt_proj.bias,
+                                   dt_softplus=True)
+        out = self.out_proj(y)
+        return out.unsqueeze(1), conv_state, ssm_state
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        device = self.out_proj.weight.device
+        conv_dtype = self.conv1d.weight.dtype if dtype is None else dtype
+        conv_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_conv, device=device, dtype=conv_dtype)
+        ssm_dtype = self.dt_proj.weight.dtype if dtype is None else dtype
+        ssm_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_state, device=device, dtype=ssm_dtype)
+        return conv_state, ssm_state
+
+    def _get_states_from_cache(self, inference_params, batch_size, initialize_states=False):
+        assert self.layer_idx is not None
+        if self.layer_idx not in inference_params.key_value_memory_dict:
+            conv_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_conv,
+                                     device=self.conv1d.weight.device, dtype=self.conv1d.weight.dtype)
+            ssm_state = torch.zeros(batch_size, self.d_model * self.expand, self.d_state,
+                                    device=self.dt_proj.weight.device, dtype=self.dt_proj.weight.dtype)
+            inference_params.key_value_memory_dict[self.layer_idx] = (conv_state, ssm_state)
+        else:
+            conv_state, ssm_state = inference_params.key_value_memory_dict[self.layer_idx]
+            if initialize_states:
+                conv_state.zero_()
+                ssm_state.zero_()
+        return conv_state, ssm_state
+
+
+class Block(nn.Module):
+    def __init__(self, dim, mixer_cls, norm_cls=nn.LayerNorm, fused_add_norm=False, residual_in_fp32=False):
+        """Add -> Norm -> Mixer, returning (mixer output, residual stream); the residual add is
+        fused with the norm of the NEXT block (reference mamba_simple.py:381-437)."""
+        super().__init__()
+        self.residual_in_fp32 = residual_in_fp32
+        self.fused_add_norm = fused_add_norm
+        self.mixer = mixer_cls(dim)
+        self.norm = norm_cls(dim)
+        if self.fused_add_norm:
+            assert RMSNorm is not None, "RMSNorm import fails"
+            assert isinstance(self.norm, (nn.LayerNorm, RMSNorm)), \
+                "Only LayerNorm and RMSNorm are supported for fused_add_norm"
+
+    def forward(self, hidden_states: Tensor, residual: Optional[Tensor] = None, inference_params=None):
+        if not self.fused_add_norm:
+            residual = (hidden_states + residual) if residual is not None else hidden_states
+            hidden_states = self.norm(residual.to(dtype=self.norm.weight.dtype))
+            if self.residual_in_fp32:
+                residual = residual.to(torch.float32)
+        else:
+            fused = rms_norm_fn if isinstance(self.norm, RMSNorm) else layer_norm_fn
+            hidden_states, residual = fused(hidden_states, self.norm.weight, self.norm.bias, residual=residual,
+                                            prenorm=True, residual_in_fp32=self.residual_in_fp32, eps=self.norm.eps)
+        hidden_states = self.mixer(hidden_states, inference_params=inference_params)
+        return hidden_states, residual
+
+    def allocate_inference_cache(self, batch_size, max_seqlen, dtype=None, **kwargs):
+        return self.mixer.allocate_inference_cache(batch_size, max_seqlen, dtype=dtype, **kwargs)

@@ -1,0 +1,471 @@
+"""`mamba_ssm.ops.selective_scan_interface` on top of the MI355X HIP kernels.
+
+Public surface (signatures, argument meaning, returned gradients) mirrors the reference file
+mamba/mamba_ssm/ops/selective_scan_interface.py:
+  selective_scan_fn / SelectiveScanFn                      (:14-83)
+  mamba_inner_fn_no_out_proj / MambaInnerFnNoOutProj       (:155-289, 627-633)  <- what the suite runs
+  mamba_inner_fn / MambaInnerFn                            (:292-434, 606-614)
+  bimamba_inner_fn / BiMambaInnerFn                        (:437-603, 616-624)
+  selective_scan_ref, mamba_inner_ref, bimamba_inner_ref   (:86-152, 636-709)   pure PyTorch, any device
+
+The three fused nodes share one implementation here (`_inner_forward` / `_inner_backward`):
+conv1d+SiLU -> x_proj GEMM -> dt_proj GEMM -> selective scan (+z gate) [-> out_proj], with the
+reference's recompute policy (checkpoint_lvl=1: conv output and delta are rebuilt in backward,
+SSI:218-219, 238-241) and its layout contract (delta and the scan output are "d-slowest",
+dx/dz are written straight into the halves of one dxz buffer, SSI:244-248, 281-283).
+"""
+import torch
+import torch.nn.functional as F
+
+import causal_conv1d_cuda
+import selective_scan_cuda
+from causal_conv1d import causal_conv1d_fn
+
+try:  # torch >= 2.4
+    from torch.amp import custom_bwd as _custom_bwd, custom_fwd as _custom_fwd
+
+    def custom_fwd(fn):
+        return _custom_fwd(fn, device_type="cuda")
+
+    def custom_bwd(fn):
+        return _custom_bwd(fn, device_type="cuda")
+except ImportError:  # pragma: no cover
+    from torch.cuda.amp import custom_bwd, custom_fwd
+
+
+def _last_dim_contiguous(t):
+    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+
+
+# =================================================================================================
+# selective_scan_fn
+# =================================================================================================
+class SelectiveScanFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        u, delta, B, C, z = map(_last_dim_contiguous, (u, delta, B, C, z))
+        if D is not None:
+            D = D.contiguous()
+        # (batch, dstate, L) means one group: promote to (batch, 1, dstate, L) for the kernel
+        ctx.squeeze_B = B.dim() == 3
+        ctx.squeeze_C = C.dim() == 3
+        if ctx.squeeze_B:
+            B = B.unsqueeze(1)
+        if ctx.squeeze_C:
+            C = C.unsqueeze(1)
+        out, x, *rest = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        ctx.delta_softplus = delta_softplus
+        ctx.has_z = z is not None
+        ctx.has_D = D is not None
+        ctx.has_bias = delta_bias is not None
+        ctx.save_for_backward(u, delta, A, B, C, D, z, delta_bias, x, out if ctx.has_z else None)
+        result = rest[0] if ctx.has_z else out
+        if not return_last_state:
+            return result
+        last_state = x[:, :, -1, 1::2]  # (batch, dim, dstate): state after the last chunk
+        ctx.mark_non_differentiable(last_state)
+        return result, last_state
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        u, delta, A, B, C, D, z, delta_bias, x, out = ctx.saved_tensors
+        dout = _last_dim_contiguous(dout)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias, *rest = selective_scan_cuda.bwd(
+            u, delta, A, B, C, D, z, delta_bias, dout, x, out, None, ctx.delta_softplus, False)
+        dz = rest[0] if ctx.has_z else None
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        return (du, ddelta, dA, dB, dC, dD if ctx.has_D else None, dz,
+                ddelta_bias if ctx.has_bias else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """if return_last_state is True, returns (out, last_state)
+    last_state has shape (batch, dim, dstate). Note that the gradient of the last state is
+    not considered in the backward pass.
+    """
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                       return_last_state=False):
+    """Pure-PyTorch statement of the selective scan (runs on any device, differentiable).
+
+    u, delta, z: (B, D, L);  A: (D, N) real or complex;  D, delta_bias: (D,)
+    B, C: (D, N) constant, or input dependent (B, N, L) / (B, G, N, L) (last dim 2L if A is complex)
+    returns out (B, D, L) in u's dtype [, last_state (B, D, N)]
+    """
+    in_dtype = u.dtype
+    u = u.float()
+    dt = delta.float()
+    if delta_bias is not None:
+        dt = dt + delta_bias.float()[:, None]
+    if delta_softplus:
+        dt = F.softplus(dt)
+    batch, dim, seqlen = u.shape
+    dstate = A.shape[1]
+    var_B, var_C = B.dim() >= 3, C.dim() >= 3
+
+    def per_dim(M, var):
+        """-> accessor l -> (batch|1, dim, dstate) slice of B or C at position l"""
+        if not var:
+            Mc = M if A.is_complex() else M.float()
+            return lambda l: Mc[None]
+        M = M.float()
+        if A.is_complex():  # interleaved (re, im) pairs along L
+            M = torch.view_as_complex(M.reshape(*M.shape[:-1], seqlen, 2).contiguous())
+        if M.dim() == 3:
+            return lambda l: M[:, None, :, l]
+        rep = dim // M.shape[1]
+        return lambda l: M[:, :, :, l].repeat_interleave(rep, dim=1)
+
+    B_at, C_at = per_dim(B, var_B), per_dim(C, var_C)
+    state = A.new_zeros((batch, dim, dstate))
+    ys = []
+    for l in range(seqlen):
+        dt_l = dt[:, :, l, None]
+        state = torch.exp(dt_l * A) * state + (dt_l * u[:, :, l, None]) * B_at(l)
+        y = (state * C_at(l)).sum(dim=-1)
+        ys.append(2 * y.real if y.is_complex() else y)
+    y = torch.stack(ys, dim=2)
+    out = y if D is None else y + u * D[:, None]
+    if z is not None:
+        out = out * F.silu(z.float())
+    out = out.to(dtype=in_dtype)
+    return (out, state) if return_last_state else out
+
+
+# =================================================================================================
+# fused Mamba inner nodes
+# =================================================================================================
+def _autocast_weights(*ws):
+    if not torch.is_autocast_enabled():
+        return ws
+    dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+    return tuple(w.to(dtype=dt) if w is not None else None for w in ws)
+
+
+def _conv_and_projections(xz, conv_w, conv_b, x_proj_w, dt_proj_w):
+    """conv1d+SiLU on the x half of xz, then the two small GEMMs.
+    Returns conv_out (b, d, l), x_dbl (b*l, R+2N), delta (b, d, l) with d as the slowest axis."""
+    batch, _, L = xz.shape
+    d_inner = conv_w.shape[0]
+    R = dt_proj_w.shape[1]
+    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True)
+    x_dbl = F.linear(conv_out.transpose(1, 2).reshape(batch * L, d_inner), x_proj_w)
+    delta = _delta_from(x_dbl, dt_proj_w, batch, L)
+    return conv_out, x_dbl, delta
+
+
+def _delta_from(x_dbl, dt_proj_w, batch, L):
+    R = dt_proj_w.shape[1]
+    # (d, b*l) GEMM output viewed as (b, d, l): strides (l, b*l, 1) -- no transpose copy (SSI:178-182)
+    return (dt_proj_w @ x_dbl[:, :R].t()).view(dt_proj_w.shape[0], batch, L).permute(1, 0, 2)
+
+
+def _bc_from_x_dbl(x_dbl, lo, hi, bias, batch, L, is_complex):
+    """x_dbl[:, lo:hi] (b*l, n) -> (b, 1, n, l) contiguous (complex: (b, 1, n/2, 2l))."""
+    M = x_dbl[:, lo:hi]
+    if bias is not None:
+        M = M + bias.to(dtype=M.dtype)
+    n = hi - lo
+    if not is_complex:
+        return M.view(batch, L, n).permute(0, 2, 1).contiguous().unsqueeze(1)
+    return M.view(batch, L, n // 2, 2).permute(0, 2, 1, 3).reshape(batch, 1, n // 2, 2 * L).contiguous()
+
+
+def _bc_grad_to_x_dbl(dM, batch, L, is_complex):
+    """inverse layout of _bc_from_x_dbl for a gradient: (b, 1, n, l) -> (b*l, n)."""
+    if not is_complex:
+        return dM.squeeze(1).permute(0, 2, 1).reshape(batch * L, -1)
+    n2 = dM.shape[2]
+    return dM.view(batch, n2, L, 2).permute(0, 2, 1, 3).reshape(batch * L, 2 * n2)
+
+
+def _flip_l(t):
+    return t.flip([-1])
+
+
+def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                   out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
+                   checkpoint_lvl):
+    """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A."""
+    assert checkpoint_lvl in (0, 1)
+    batch, _, L = xz.shape
+    R = delta_proj_weight.shape[1]
+    is_complex = A.is_complex()
+    d_state = A.shape[-1] * (2 if is_complex else 1)
+    out_w = out_bias = None
+    if out_proj is not None:
+        x_proj_weight, delta_proj_weight, out_w, out_bias = _autocast_weights(
+            x_proj_weight, delta_proj_weight, out_proj[0], out_proj[1])
+    else:
+        x_proj_weight, delta_proj_weight = _autocast_weights(x_proj_weight, delta_proj_weight)
+    xz = _last_dim_contiguous(xz)
+    conv_w = conv1d_weight.squeeze(1)  # (d, 1, w) -> (d, w)
+    conv_b = conv1d_bias.contiguous() if conv1d_bias is not None else None
+    d_inner = conv_w.shape[0]
+    z = xz[:, d_inner:]
+    conv_out, x_dbl, delta = _conv_and_projections(xz, conv_w, conv_b, x_proj_weight, delta_proj_weight)
+
+    ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
+    ctx.has_B_proj_bias, ctx.has_C_proj_bias = B_proj_bias is not None, C_proj_bias is not None
+    if B is None:
+        B = _bc_from_x_dbl(x_dbl, R, R + d_state, B_proj_bias, batch, L, is_complex)
+    else:
+        B = _last_dim_contiguous(B)
+    if C is None:
+        C = _bc_from_x_dbl(x_dbl, x_dbl.shape[1] - d_state, x_dbl.shape[1], C_proj_bias, batch, L, is_complex)
+    else:
+        C = _last_dim_contiguous(C)
+    if D is not None:
+        D = D.contiguous()
+
+    out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus)
+    saved_b = (None, None, None)
+    if A_b is not None:
+        assert not A_b.is_complex(), "A should not be complex!!"
+        flip = lambda t: _flip_l(t) if t.dim() >= 3 else t  # constant (dim, dstate) B/C have no L axis
+        out_b, ckpt_b, out_z_b = selective_scan_cuda.fwd(
+            _flip_l(conv_out), _flip_l(delta), A_b, flip(B), flip(C), D, _flip_l(z), delta_bias, delta_softplus)
+        out_z = out_z + _flip_l(out_z_b)
+        saved_b = (A_b, ckpt_b, out_b)
+
+    ctx.delta_softplus = delta_softplus
+    ctx.checkpoint_lvl = checkpoint_lvl
+    ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
+    ctx.has_out_proj = out_proj is not None
+    ctx.has_out_proj_bias = out_bias is not None
+    ctx.bidirectional = A_b is not None
+    if checkpoint_lvl >= 1:  # rebuilt in backward from xz and x_dbl
+        conv_out, delta = None, None
+    ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_w,
+                          conv_out, delta, A, B, C, D, delta_bias, ckpt, out, *saved_b)
+    if out_proj is None:
+        return out_z  # (b, d, l), d-slowest like delta
+    return F.linear(out_z.transpose(1, 2), out_w, out_bias)
+
+
+def _inner_backward(ctx, dout):
+    (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_w, conv_out, delta,
+     A, B, C, D, delta_bias, ckpt, out, A_b, ckpt_b, out_b) = ctx.saved_tensors
+    batch, _, L = xz.shape
+    R = delta_proj_weight.shape[1]
+    is_complex = A.is_complex()
+    d_state = A.shape[-1] * (2 if is_complex else 1)
+    d_inner = conv_w.shape[0]
+    x, z = xz[:, :d_inner], xz[:, d_inner:]
+    dout = _last_dim_contiguous(dout)
+    if ctx.checkpoint_lvl == 1:
+        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True)
+        delta = _delta_from(x_dbl, delta_proj_weight, batch, L)
+    dxz = torch.empty_like(xz)
+    dx, dz = dxz[:, :d_inner], dxz[:, d_inner:]
+
+    dout_2d = None
+    if ctx.has_out_proj:  # dout: (b, l, e)
+        dout_2d = dout.reshape(batch * L, -1).t()                       # (e, b*l)
+        dy = (out_w.t() @ dout_2d).view(d_inner, batch, L).permute(1, 0, 2)  # (b, d, l) d-slowest
+    else:
+        dy = dout
+    dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_cuda.bwd(
+        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True)
+    dA_b = None
+    if ctx.bidirectional:
+        flip = lambda t: _flip_l(t) if t.dim() >= 3 else t
+        dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, out_z_b = selective_scan_cuda.bwd(
+            _flip_l(conv_out), _flip_l(delta), A_b, flip(B), flip(C), D, _flip_l(z), delta_bias, _flip_l(dy),
+            ckpt_b, out_b, torch.empty_like(dz), ctx.delta_softplus, True)
+        dconv_out = dconv_out + _flip_l(dconv_b)
+        ddelta = ddelta + _flip_l(ddelta_b)
+        dB = dB + flip(dB_b)
+        dC = dC + flip(dC_b)
+        if dD is not None:
+            dD = dD + dD_b
+        if ddelta_bias is not None:
+            ddelta_bias = ddelta_bias + ddelta_bias_b
+        dz.add_(_flip_l(dz_b))
+        out_z = out_z + _flip_l(out_z_b)
+
+    dout_proj_weight = dout_proj_bias = None
+    if ctx.has_out_proj:
+        dout_proj_weight = dout_2d @ out_z.transpose(1, 2).reshape(batch * L, d_inner)   # (e, d)
+        if ctx.has_out_proj_bias:
+            dout_proj_bias = dout.sum(dim=(0, 1))
+
+    dx_dbl = torch.empty_like(x_dbl)
+    dB_proj_bias = dC_proj_bias = None
+    if ctx.is_variable_B:
+        dB2 = _bc_grad_to_x_dbl(dB, batch, L, is_complex)
+        if ctx.has_B_proj_bias:
+            dB_proj_bias = dB2.sum(0)
+        dx_dbl[:, R:R + d_state] = dB2
+        dB = None
+    if ctx.is_variable_C:
+        dC2 = _bc_grad_to_x_dbl(dC, batch, L, is_complex)
+        if ctx.has_C_proj_bias:
+            dC_proj_bias = dC2.sum(0)
+        dx_dbl[:, x_dbl.shape[1] - d_state:] = dC2
+        dC = None
+    ddelta_2d = ddelta.permute(1, 0, 2).reshape(d_inner, batch * L)       # view when d-slowest
+    ddelta_proj_weight = ddelta_2d @ x_dbl[:, :R]                          # (d, R)
+    dx_dbl[:, :R] = ddelta_2d.t() @ delta_proj_weight                      # (b*l, R)
+    dconv_2d = dconv_out.permute(1, 0, 2).reshape(d_inner, batch * L)     # (d, b*l) (copy if b-major)
+    dx_proj_weight = dx_dbl.t() @ conv_out.transpose(1, 2).reshape(batch * L, d_inner)  # (R+2N, d)
+    dconv_2d = torch.addmm(dconv_2d, x_proj_weight.t(), dx_dbl.t())       # + x_proj^T dx_dbl^T
+    dconv_out = dconv_2d.view(d_inner, batch, L).permute(1, 0, 2)
+    _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
+    return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
+                dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
+                dout_proj_weight=dout_proj_weight, dout_proj_bias=dout_proj_bias,
+                dA=dA, dA_b=dA_b, dB=dB, dC=dC, dD=dD if ctx.has_D else None,
+                ddelta_bias=ddelta_bias if ctx.has_delta_bias else None,
+                dB_proj_bias=dB_proj_bias, dC_proj_bias=dC_proj_bias)
+
+
+class MambaInnerFnNoOutProj(torch.autograd.Function):
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1):
+        """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)"""
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              None, A, None, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
+                              delta_softplus, checkpoint_lvl)
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
+                g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
+                None, None)
+
+
+class MambaInnerFn(torch.autograd.Function):
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                out_proj_weight, out_proj_bias,
+                A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1):
+        """xz: (batch, 2*dim, seqlen) -> (batch, seqlen, out_features)"""
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              (out_proj_weight, out_proj_bias), A, None, B, C, D, delta_bias,
+                              B_proj_bias, C_proj_bias, delta_softplus, checkpoint_lvl)
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
+                g["dout_proj_weight"], g["dout_proj_bias"],
+                g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
+                None, None)
+
+
+class BiMambaInnerFn(torch.autograd.Function):
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                out_proj_weight, out_proj_bias,
+                A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1):
+        """Two scans (A forward in time, A_b on the flipped sequence) sharing everything else."""
+        return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              (out_proj_weight, out_proj_bias), A, A_b, B, C, D, delta_bias,
+                              B_proj_bias, C_proj_bias, delta_softplus, checkpoint_lvl)
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        g = _inner_backward(ctx, dout)
+        return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
+                g["dout_proj_weight"], g["dout_proj_bias"],
+                g["dA"], g["dA_b"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"],
+                g["dB_proj_bias"], g["dC_proj_bias"], None, None)
+
+
+def mamba_inner_fn(
+    xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+    out_proj_weight, out_proj_bias,
+    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+    C_proj_bias=None, delta_softplus=True
+):
+    return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                              out_proj_weight, out_proj_bias,
+                              A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def bimamba_inner_fn(
+    xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+    out_proj_weight, out_proj_bias,
+    A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+    C_proj_bias=None, delta_softplus=True
+):
+    return BiMambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                out_proj_weight, out_proj_bias,
+                                A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+def mamba_inner_fn_no_out_proj(
+    xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+    C_proj_bias=None, delta_softplus=True
+):
+    return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+
+
+# ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------
+def _inner_ref_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                           B_proj_bias, C_proj_bias):
+    batch, _, L = xz.shape
+    R = delta_proj_weight.shape[1]
+    is_complex = A.is_complex()
+    d_state = A.shape[-1] * (2 if is_complex else 1)
+    x, z = xz.chunk(2, dim=1)
+    x = causal_conv1d_fn(x, conv1d_weight.squeeze(1), conv1d_bias, "silu")
+    x_dbl = F.linear(x.transpose(1, 2).reshape(batch * L, -1), x_proj_weight)
+    delta = _delta_from(x_dbl, delta_proj_weight, batch, L)
+    if B is None:
+        B = _bc_from_x_dbl(x_dbl, R, R + d_state, B_proj_bias, batch, L, is_complex).squeeze(1)
+    if C is None:
+        C = _bc_from_x_dbl(x_dbl, x_dbl.shape[1] - d_state, x_dbl.shape[1], C_proj_bias, batch, L,
+                           is_complex).squeeze(1)
+    return x, z, delta, B, C
+
+
+def mamba_inner_ref(
+    xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+    out_proj_weight, out_proj_bias,
+    A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+    C_proj_bias=None, delta_softplus=True
+):
+    x, z, delta, B, C = _inner_ref_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight,
+                                               delta_proj_weight, A, B, C, B_proj_bias, C_proj_bias)
+    y = selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=True)
+    return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
+
+
+def bimamba_inner_ref(
+    xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
+    out_proj_weight, out_proj_bias,
+    A, A_b, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+    C_proj_bias=None, delta_softplus=True
+):
+    x, z, delta, B, C = _inner_ref_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight,
+                                               delta_proj_weight, A, B, C, B_proj_bias, C_proj_bias)
+    y = selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=True)
+    y_b = selective_scan_fn(_flip_l(x), _flip_l(delta), A_b, _flip_l(B), _flip_l(C), D, _flip_l(z),
+                            delta_bias, delta_softplus=True)
+    return F.linear((y + _flip_l(y_b)).transpose(1, 2), out_proj_weight, out_proj_bias)

@@ -1,0 +1,128 @@
+"""Drop-in for the reference's pybind extension `selective_scan_cuda`
+(mamba/csrc/selective_scan/selective_scan.cpp:494-497): same two entry points, same argument
+order, same returned tensor lists, same checks (raised as RuntimeError, as TORCH_CHECK does).
+The work is done by the gfx950 kernels behind the C ABI in include/vms_hip.h.
+
+Differences that are visible only to someone poking at the raw extension:
+  * complex A (weight_t = complex<float>) is not built: RuntimeError (SURVEY.md 8a a-excl).
+  * x[b, d, c, 2n] holds the state after the first 1024 elements of chunk c instead of the
+    running product of exp(delta A); x[b, d, c, 2n+1] (what `last_state` slices) is unchanged.
+  * 64-bit strides: no 2^32-element limit on batch_stride * batch.
+"""
+import torch
+
+import vms_hip as _k
+
+_lib = _k.lib()  # fail at import time if the HIP library is missing, like a missing .so would
+
+_ITYPES = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def _check(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
+    """selective_scan.cpp:233-305."""
+    _check(u.dtype in _ITYPES, f"selective_scan: input dtype {u.dtype} not supported")
+    if A.is_complex():
+        raise RuntimeError("selective_scan: complex A is not supported by the MI355X HIP path")
+    _check(A.dtype == torch.float32, "selective_scan: A must be float32")
+    var_B, var_C = B.dim() >= 3, C.dim() >= 3
+    _check(delta.dtype == u.dtype, "delta.scalar_type() == input_type")
+    _check(B.dtype == (u.dtype if var_B else A.dtype), "B.scalar_type() == (!is_variable_B ? weight_type : input_type)")
+    _check(C.dtype == (u.dtype if var_C else A.dtype), "C.scalar_type() == (!is_variable_C ? weight_type : input_type)")
+    for name, t in (("u", u), ("delta", delta), ("A", A), ("B", B), ("C", C)):
+        _check(t.is_cuda, f"{name}.is_cuda()")
+    _check(u.dim() == 3, "u must be (batch, dim, seqlen)")
+    _check(u.stride(-1) == 1, "u.stride(-1) == 1")
+    _check(delta.stride(-1) == 1, "delta.stride(-1) == 1")
+    batch, dim, seqlen = u.shape
+    dstate = A.shape[1]
+    n_groups = B.shape[1] if var_B else 1
+    _check(dstate <= 256, "selective_scan only supports state dimension <= 256")
+    _check(tuple(delta.shape) == (batch, dim, seqlen), "delta must have shape (batch, dim, seqlen)")
+    _check(tuple(A.shape) == (dim, dstate), "A must have shape (dim, dstate)")
+    if not var_B:
+        _check(tuple(B.shape) == (dim, dstate), "B must have shape (dim, dstate)")
+    else:
+        _check(B.dim() == 4 and tuple(B.shape) == (batch, n_groups, dstate, seqlen),
+               "B must have shape (batch, n_groups, dstate, seqlen)")
+        _check(B.stride(-1) == 1, "B.stride(-1) == 1")
+    if not var_C:
+        _check(tuple(C.shape) == (dim, dstate), "C must have shape (dim, dstate)")
+    else:
+        _check(C.dim() == 4 and tuple(C.shape) == (batch, C.shape[1], dstate, seqlen) and
+               C.shape[1] == (n_groups if var_B else C.shape[1]),
+               "C must have shape (batch, n_groups, dstate, seqlen)")
+        _check(C.stride(-1) == 1, "C.stride(-1) == 1")
+    for name, t in (("D", D_), ("delta_bias", delta_bias_)):
+        if t is not None:
+            _check(t.dtype == torch.float32, f"{name} must be float32")
+            _check(t.is_cuda, f"{name}.is_cuda()")
+            _check(t.stride(-1) == 1, f"{name}.stride(-1) == 1")
+            _check(tuple(t.shape) == (dim,), f"{name} must have shape (dim,)")
+    if z_ is not None:
+        _check(z_.dtype == u.dtype, "z.scalar_type() == input_type")
+        _check(z_.is_cuda, "z.is_cuda()")
+        _check(z_.stride(-1) == 1, "z.stride(-1) == 1")
+        _check(tuple(z_.shape) == (batch, dim, seqlen), "z must have shape (batch, dim, seqlen)")
+    return batch, dim, seqlen, dstate, var_B, var_C
+
+
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
+    """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)"""
+    batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    n_chunks = (seqlen + 2047) // 2048
+    out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
+    out_z = torch.empty_like(z_) if z_ is not None else None
+    x = torch.empty(batch, dim, n_chunks, dstate * 2, device=u.device, dtype=A.dtype)
+    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus)
+    return [out, x] + ([out_z] if z_ is not None else [])
+
+
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z):
+    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)"""
+    batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
+    _check(dout.is_cuda, "dout.is_cuda()")
+    _check(dout.stride(-1) == 1, "dout.stride(-1) == 1")
+    _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have shape (batch, dim, seqlen)")
+    out = dz = out_z = None
+    if z_ is not None:
+        _check(out_ is not None, "out_.has_value()")
+        out = out_
+        _check(out.dtype == u.dtype and out.is_cuda and out.stride(-1) == 1 and
+               tuple(out.shape) == (batch, dim, seqlen), "out must be (batch, dim, seqlen), input dtype, unit last stride")
+        if dz_ is not None:
+            dz = dz_
+            _check(dz.dtype == u.dtype and dz.is_cuda and dz.stride(-1) == 1 and
+                   tuple(dz.shape) == (batch, dim, seqlen), "dz must be (batch, dim, seqlen), input dtype, unit last stride")
+        else:
+            dz = torch.empty_like(z_)
+        if recompute_out_z:
+            out_z = torch.empty_like(out)
+    n_chunks = (seqlen + 2047) // 2048
+    if n_chunks > 1:
+        _check(x_ is not None, "x_.has_value()")
+    if x_ is not None:
+        _check(x_.dtype == A.dtype and x_.is_cuda and x_.is_contiguous() and
+               tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate), "x must be contiguous (batch, dim, n_chunks, 2*dstate)")
+    else:
+        _check(seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024")
+    du = torch.empty_like(u)
+    ddelta = torch.empty_like(delta)
+    dA = torch.zeros_like(A)
+    dB = torch.zeros_like(B, dtype=torch.float32)
+    dC = torch.zeros_like(C, dtype=torch.float32)
+    dD = torch.zeros_like(D_) if D_ is not None else None
+    ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
+    _k.scan_bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
+                ddelta_bias, dz, delta_softplus)
+    result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+    if z_ is not None:
+        result.append(dz)
+    if recompute_out_z:
+        result.append(out_z)
+    return result

@@ -1,0 +1,248 @@
+"""ctypes binding of libvms_hip.so (C ABI: include/vms_hip.h).
+
+PyTorch is used only as plumbing here: device memory (`data_ptr()`), element strides and the
+current HIP stream.  There is NO fallback: if the library is missing, or a tensor is not on a
+GPU, the call raises (the reference's extensions behave the same way: import error at module
+import, TORCH_CHECK(x.is_cuda()) at call time -- selective_scan.cpp:246-250).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvms_hip.so")
+
+VMS_F32, VMS_F16, VMS_BF16 = 0, 1, 2
+_DTYPE = {torch.float32: VMS_F32, torch.float16: VMS_F16, torch.bfloat16: VMS_BF16}
+
+_i32, _i64, _vp, _fp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p
+
+
+class ScanFwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "dstate", "n_groups", "n_chunks", "dtype",
+                             "is_variable_B", "is_variable_C", "delta_softplus")]
+        + [(n, _vp) for n in ("u", "delta", "A", "B", "C", "D", "z", "delta_bias", "out", "out_z", "x")]
+        + [(n, _i64) for n in (
+            "u_batch_stride", "u_d_stride", "delta_batch_stride", "delta_d_stride",
+            "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride",
+            "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
+            "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
+            "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride")]
+    )
+
+
+class ScanBwdParams(ctypes.Structure):
+    _fields_ = (
+        [("f", ScanFwdParams), ("dout", _vp), ("du", _vp), ("ddelta", _vp), ("dz", _vp),
+         ("dA", _fp), ("dB", _fp), ("dC", _fp), ("dD", _fp), ("ddelta_bias", _fp)]
+        + [(n, _i64) for n in (
+            "dout_batch_stride", "dout_d_stride", "du_batch_stride", "du_d_stride",
+            "ddelta_batch_stride", "ddelta_d_stride", "dz_batch_stride", "dz_d_stride",
+            "dA_d_stride", "dA_dstate_stride",
+            "dB_batch_stride", "dB_group_stride", "dB_d_stride", "dB_dstate_stride",
+            "dC_batch_stride", "dC_group_stride", "dC_d_stride", "dC_dstate_stride")]
+    )
+
+
+class ConvFwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "wdtype", "silu_activation")]
+        + [(n, _vp) for n in ("x", "weight", "bias", "out")]
+        + [(n, _i64) for n in ("x_batch_stride", "x_c_stride", "x_l_stride", "weight_c_stride",
+                               "weight_width_stride", "out_batch_stride", "out_c_stride", "out_l_stride")]
+        + [("conv_state", _vp)]
+        + [(n, _i64) for n in ("conv_state_batch_stride", "conv_state_c_stride", "conv_state_l_stride")]
+    )
+
+
+class ConvBwdParams(ctypes.Structure):
+    _fields_ = (
+        [("f", ConvFwdParams), ("dout", _vp), ("dx", _vp), ("dweight", _fp), ("dbias", _fp)]
+        + [(n, _i64) for n in ("dout_batch_stride", "dout_c_stride", "dout_l_stride",
+                               "dx_batch_stride", "dx_c_stride", "dx_l_stride",
+                               "dweight_c_stride", "dweight_width_stride")]
+    )
+
+
+EXPORTS = (
+    "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
+    "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
+    "vms_sizeof_scan_bwd_params", "vms_sizeof_conv_fwd_params", "vms_sizeof_conv_bwd_params",
+)
+
+_lib = None
+
+# Optional per-call device timing (used by bench.py): when a list is installed here every C-ABI
+# call is bracketed by two events on the stream the kernel is launched on.
+_timing = None
+
+
+def start_timing():
+    global _timing
+    _timing = []
+
+
+def stop_timing():
+    """-> {entry point: [milliseconds per call]}; synchronises the device."""
+    global _timing
+    rec, _timing = _timing, None
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1 in rec or []:
+        out.setdefault(name, []).append(e0.elapsed_time(e1))
+    return out
+
+
+def lib():
+    """Load libvms_hip.so once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP library first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C video-mamba-suite_amd/csrc)")
+        L = ctypes.CDLL(LIB_PATH)
+        L.vms_last_error.restype = ctypes.c_char_p
+        for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
+                         ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams)):
+            n = getattr(L, f"vms_sizeof_{name}_params")()
+            if n != ctypes.sizeof(st):
+                raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
+                                  f"{ctypes.sizeof(st)} in the binding")
+        for fn in EXPORTS[:5]:
+            getattr(L, fn).restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _call(fn_name, params, ref_tensor):
+    L = lib()
+    if not ref_tensor.is_cuda:
+        raise RuntimeError(f"{fn_name}: tensors must be on a GPU (no CPU path in this library)")
+    with torch.cuda.device(ref_tensor.device):
+        cur = torch.cuda.current_stream()
+        if _timing is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(cur.cuda_stream))
+        if _timing is not None:
+            e1.record(cur)
+            _timing.append((fn_name, e0, e1))
+    if rc != 0:
+        raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dtype_code(t):
+    try:
+        return _DTYPE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
+
+
+def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus):
+    batch, dim, seqlen = u.shape
+    dstate = A.shape[1]
+    var_B, var_C = B.dim() >= 3, C.dim() >= 3
+    P.batch, P.dim, P.seqlen, P.dstate = batch, dim, seqlen, dstate
+    P.n_groups = B.shape[1] if var_B else (C.shape[1] if var_C else 1)
+    P.n_chunks = (seqlen + 2047) // 2048
+    P.dtype = dtype_code(u)
+    P.is_variable_B, P.is_variable_C, P.delta_softplus = int(var_B), int(var_C), int(bool(delta_softplus))
+    P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
+    P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
+    P.out, P.out_z, P.x = _ptr(out), _ptr(out_z), _ptr(x)
+    P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
+    P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
+    if z is not None:
+        P.z_batch_stride, P.z_d_stride = z.stride(0), z.stride(1)
+    if out is not None:
+        P.out_batch_stride, P.out_d_stride = out.stride(0), out.stride(1)
+    if out_z is not None:
+        P.out_z_batch_stride, P.out_z_d_stride = out_z.stride(0), out_z.stride(1)
+    P.A_d_stride, P.A_dstate_stride = A.stride(0), A.stride(1)
+    if var_B:
+        P.B_batch_stride, P.B_group_stride, P.B_dstate_stride = B.stride(0), B.stride(1), B.stride(2)
+    else:
+        P.B_d_stride, P.B_dstate_stride = B.stride(0), B.stride(1)
+    if var_C:
+        P.C_batch_stride, P.C_group_stride, P.C_dstate_stride = C.stride(0), C.stride(1), C.stride(2)
+    else:
+        P.C_d_stride, P.C_dstate_stride = C.stride(0), C.stride(1)
+
+
+def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus):
+    P = ScanFwdParams()
+    fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus)
+    _call("vms_selective_scan_fwd", P, u)
+
+
+def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
+             ddelta_bias, dz, delta_softplus):
+    Q = ScanBwdParams()
+    fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus)
+    Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
+    Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
+    Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
+    Q.du_batch_stride, Q.du_d_stride = du.stride(0), du.stride(1)
+    Q.ddelta_batch_stride, Q.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
+    if dz is not None:
+        Q.dz_batch_stride, Q.dz_d_stride = dz.stride(0), dz.stride(1)
+    Q.dA_d_stride, Q.dA_dstate_stride = dA.stride(0), dA.stride(1)
+    if B.dim() >= 3:
+        Q.dB_batch_stride, Q.dB_group_stride, Q.dB_dstate_stride = dB.stride(0), dB.stride(1), dB.stride(2)
+    else:
+        Q.dB_d_stride, Q.dB_dstate_stride = dB.stride(0), dB.stride(1)
+    if C.dim() >= 3:
+        Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1), dC.stride(2)
+    else:
+        Q.dC_d_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1)
+    _call("vms_selective_scan_bwd", Q, u)
+
+
+def fill_conv_fwd(P, x, weight, bias, out, silu):
+    P.batch, P.dim, P.seqlen = x.shape
+    P.width = weight.shape[-1]
+    P.dtype, P.wdtype = dtype_code(x), dtype_code(weight)
+    P.silu_activation = int(bool(silu))
+    P.x, P.weight, P.bias, P.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(out)
+    P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride()
+    P.weight_c_stride, P.weight_width_stride = weight.stride()
+    if out is not None:
+        P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride()
+
+
+def conv_fwd(x, weight, bias, out, silu):
+    P = ConvFwdParams()
+    fill_conv_fwd(P, x, weight, bias, out, silu)
+    _call("vms_causal_conv1d_fwd", P, x)
+
+
+def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu):
+    Q = ConvBwdParams()
+    fill_conv_fwd(Q.f, x, weight, bias, None, silu)
+    Q.dout, Q.dx, Q.dweight, Q.dbias = _ptr(dout), _ptr(dx), _ptr(dweight), _ptr(dbias)
+    Q.dout_batch_stride, Q.dout_c_stride, Q.dout_l_stride = dout.stride()
+    Q.dx_batch_stride, Q.dx_c_stride, Q.dx_l_stride = dx.stride()
+    Q.dweight_c_stride, Q.dweight_width_stride = dweight.stride()
+    _call("vms_causal_conv1d_bwd", Q, x)
+
+
+def conv_update(x, conv_state, weight, bias, out, silu):
+    P = ConvFwdParams()
+    P.batch, P.dim = x.shape
+    P.seqlen, P.width = 1, weight.shape[-1]
+    P.dtype, P.wdtype = dtype_code(x), dtype_code(weight)
+    P.silu_activation = int(bool(silu))
+    P.x, P.weight, P.bias, P.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(out)
+    P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride(0), x.stride(1), 1
+    P.weight_c_stride, P.weight_width_stride = weight.stride()
+    P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride(0), out.stride(1), 1
+    P.conv_state = _ptr(conv_state)
+    P.conv_state_batch_stride, P.conv_state_c_stride, P.conv_state_l_stride = conv_state.stride()
+    _call("vms_causal_conv1d_update", P, x)
