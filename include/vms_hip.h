@@ -78,6 +78,13 @@ typedef struct {
     int64_t A_d_stride, A_dstate_stride;
     int64_t B_batch_stride, B_group_stride, B_d_stride, B_dstate_stride;
     int64_t C_batch_stride, C_group_stride, C_d_stride, C_dstate_stride;
+    /* x row pitch: elements between x[b,d,c,:] and x[b,d,c+1,:]; 0 means 2*dstate (dense).
+     * x_has_sub != 0: the pitch is >= 18*dstate and x[b,d,c, 2*dstate + s*dstate + n], s = 0..15,
+     * holds the state after the first 128*(s+1) elements of chunk c (finer checkpoints that let the
+     * backward kernel walk 128-element chunks; they live in the same allocation, behind the
+     * reference-shaped (.., 2*dstate) view the Python layer hands out). */
+    int64_t x_chunk_stride;
+    int32_t x_has_sub, reserved0;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).

@@ -1,0 +1,49 @@
+"""Kernel-level timing of the four hot kernels at BASELINE config 2 (8, 8192, 1024, 16) bf16.
+usage: python tools/kbench.py [fwd] [bwd] [conv]   (env VMS_DEBUG passes profiling knobs)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "video-mamba-suite_amd")); sys.path.insert(0, ROOT)
+import torch
+import selective_scan_cuda, causal_conv1d_cuda
+from bench import algorithmic_bytes
+
+def timeit(fn, n=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+def main():
+    which = sys.argv[1:] or ["fwd", "bwd", "conv"]
+    dt = torch.bfloat16 if os.environ.get("KB_DTYPE", "bf16") == "bf16" else torch.float32
+    b, d, L, N = [int(x) for x in os.environ.get("KB_SHAPE", "8,1024,8192,16").split(",")]
+    dev = "cuda"
+    torch.manual_seed(0)
+    xz = torch.randn(b, 2 * d, L, device=dev, dtype=dt)
+    u, z = xz[:, :d], xz[:, d:]
+    delta = (0.5 * torch.rand(d, b, L, device=dev)).to(dt).permute(1, 0, 2)
+    A = -torch.arange(1, N + 1, device=dev, dtype=torch.float32).repeat(d, 1).contiguous()
+    B = torch.randn(b, 1, N, L, device=dev, dtype=dt); C = torch.randn(b, 1, N, L, device=dev, dtype=dt)
+    D = torch.ones(d, device=dev); bias = torch.randn(d, device=dev) - 4.0
+    ab = algorithmic_bytes(b, d, L, N, 2 if dt == torch.bfloat16 else 4)
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
+    if "fwd" in which:
+        t = timeit(lambda: selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True))
+        print(f"scan_fwd  {t*1e3:9.1f} us  {ab['vms_selective_scan_fwd']/t/1e6:8.1f} GB/s  {ab['vms_selective_scan_fwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
+    if "bwd" in which:
+        dout = torch.randn(b, d, L, device=dev, dtype=dt)
+        dxz = torch.empty_like(xz); dz = dxz[:, d:]
+        t = timeit(lambda: selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, dz, True, True))
+        print(f"scan_bwd  {t*1e3:9.1f} us  {ab['vms_selective_scan_bwd']/t/1e6:8.1f} GB/s  {ab['vms_selective_scan_bwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
+    if "conv" in which:
+        w = torch.randn(d, 4, device=dev); cb = torch.randn(d, device=dev)
+        t = timeit(lambda: causal_conv1d_cuda.causal_conv1d_fwd(u, w, cb, True))
+        print(f"conv_fwd  {t*1e3:9.1f} us  {ab['vms_causal_conv1d_fwd']/t/1e6:8.1f} GB/s  {ab['vms_causal_conv1d_fwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
+        dout = torch.randn(b, d, L, device=dev, dtype=dt); dx = torch.empty_like(xz)[:, :d]
+        t = timeit(lambda: causal_conv1d_cuda.causal_conv1d_bwd(u, w, cb, dout, dx, True))
+        print(f"conv_bwd  {t*1e3:9.1f} us  {ab['vms_causal_conv1d_bwd']/t/1e6:8.1f} GB/s  {ab['vms_causal_conv1d_bwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
+
+main()

@@ -14,18 +14,22 @@
 //     atomics -- 4x fewer L2 atomics than one per (row, state, position) as in the reference
 //     (selective_scan_bwd_kernel.cuh:297-316).
 //   * dA, dD, ddelta_bias, constant-B/C gradients: wave reduction, one atomic per row.
+#include <stdlib.h>
+
 #include "vms_common.cuh"
 
 namespace vms {
 
 int validate_scan_common(const vms_scan_fwd_params& p);
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
+bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
+int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
 constexpr int kBwdRows = 4;
 constexpr int kTilePad = 65;  // tile index = i * 65 + lane : conflict-free ds_add, 2-way flush
 
 template <typename T, int K, bool VB, bool VC, bool HZ, bool VEC>
-__global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_scan_bwd_params q) {
+__global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_scan_bwd_params q, const int dbg) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ float smem[];
     const int lane = threadIdx.x & 63;
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
     const T* Cv = VC ? static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride : nullptr;
     const float* Bc = !VB ? static_cast<const float*>(p.B) + (int64_t)d * p.B_d_stride : nullptr;
     const float* Cc = !VC ? static_cast<const float*>(p.C) + (int64_t)d * p.C_d_stride : nullptr;
-    const float* xck = p.x ? static_cast<const float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * 2 * N : nullptr;
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
+    const float* xck = p.x ? static_cast<const float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * xpitch : nullptr;
     const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
     float* dBg = VB ? q.dB + (int64_t)b * q.dB_batch_stride : nullptr;  // + group, state, l below
@@ -128,8 +133,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
         int xoff = 0;
         if (pos0 > 0) {
             const int blk = pos0 / 2048;
-            if (pos0 % 2048 == 0) { xin = xck + (int64_t)(blk - 1) * 2 * N; xoff = 1; }
-            else { xin = xck + (int64_t)blk * 2 * N; xoff = 0; }  // pos0 % 2048 == 1024
+            if (pos0 % 2048 == 0) { xin = xck + (int64_t)(blk - 1) * xpitch; xoff = 1; }
+            else { xin = xck + (int64_t)blk * xpitch; xoff = 0; }  // pos0 % 2048 == 1024
         }
         for (int n = 0; n < N; ++n) {
             const float Araw = A[n * p.A_dstate_stride];
@@ -206,13 +211,13 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 const float dBi = gx * du_i;
                 const float dCi = dy[i] * xs[i];
                 if (VB) {
-                    if (same_group) { if (i < nv) lds_atomic_add(&tb[i * kTilePad + lane], dBi); }
+                    if (same_group) { if (i < nv && !(dbg & 2)) lds_atomic_add(&tb[i * kTilePad + lane], dBi); }
                     else if (i < nv) atomicAdd(dBg + (int64_t)g * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + l0 + i, dBi);
                 } else {
                     dBc_loc += dBi;
                 }
                 if (VC) {
-                    if (same_group) { if (i < nv) lds_atomic_add(&tc[i * kTilePad + lane], dCi); }
+                    if (same_group) { if (i < nv && !(dbg & 2)) lds_atomic_add(&tc[i * kTilePad + lane], dCi); }
                     else if (i < nv) atomicAdd(dCg + (int64_t)g * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + l0 + i, dCi);
                 } else {
                     dCc_loc += dCi;
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 if (lane == 0) dCc_acc[n] += t;
             }
             if ((VB || VC) && same_group) {
-                __syncthreads();  // every row's contribution to (chunk, state) is in tile `buf`
-                const int lim = min(CS, L - c * CS);
+                if (!(dbg & 4)) __syncthreads();  // every row's contribution to (chunk, state) is in tile `buf`
+                const int lim = (dbg & 1) ? 0 : min(CS, L - c * CS);
                 for (int j = threadIdx.x; j < lim; j += blockDim.x) {
                     const int ti = (j % K) * kTilePad + (j / K);
                     if (VB) {
@@ -284,10 +289,11 @@ static int launch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t stream
     const int tiles = (p.dim + kBwdRows - 1) / kBwdRows;
     dim3 grid(p.batch * tiles), block(kBwdRows * kWave);
     const size_t smem = sizeof(float) * (4 * K * kTilePad + kBwdRows * 5 * p.dstate);
+    static const int dbg = getenv("VMS_DEBUG") ? atoi(getenv("VMS_DEBUG")) : 0;  // profiling knob
     if (vec)
-        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, true>), grid, block, smem, stream, q);
+        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, true>), grid, block, smem, stream, q, dbg);
     else
-        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, false>), grid, block, smem, stream, q);
+        hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, false>), grid, block, smem, stream, q, dbg);
     VMS_LAUNCH_CHECK();
     return VMS_OK;
 }
@@ -332,6 +338,8 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
                mult16(q.du_d_stride, es) && mult16(q.ddelta_batch_stride, es) && mult16(q.ddelta_d_stride, es);
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool force_generic = getenv("VMS_FORCE_GENERIC") != nullptr;  // test / profiling knob (read per call)
+    if (!force_generic && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);
         case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);

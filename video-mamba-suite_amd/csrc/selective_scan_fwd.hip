@@ -47,6 +47,7 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
 
     volatile lds_f32* h = (lds_f32*)smem + wave * N;  // running state per n (wave-private)
     for (int n = lane; n < N; n += kWave) h[n] = 0.f;
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
 
     const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
     const T* dt = static_cast<const T*>(p.delta) + (int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
     const T* Cv = VC ? static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride : nullptr;
     const float* Bc = !VB ? static_cast<const float*>(p.B) + (int64_t)d * p.B_d_stride : nullptr;
     const float* Cc = !VC ? static_cast<const float*>(p.C) + (int64_t)d * p.C_d_stride : nullptr;
-    float* xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * 2 * N;
+    float* xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * xpitch;
     const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
 
@@ -102,6 +103,12 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
             float xs = fmaf(ea, hin, ex);
             const float hout = fmaf(readlane_f(pa, 63), hin, readlane_f(px, 63));
             if (lane == 0) h[n] = hout;
+            if (p.x_has_sub && (lane & 7) == 7) {
+                // 128-element sub-checkpoints for the backward kernel: the state after this lane's
+                // last element, kept by every 8th lane (8 lanes x 16 elements = 128)
+                static_assert(CS == 1024 && K == 16, "sub-checkpoint indexing assumes 64 x 16 wave chunks");
+                xck[(int64_t)(c >> 1) * xpitch + 2 * N + ((c & 1) * 8 + (lane >> 3)) * N + n] = fmaf(pa, hin, px);
+            }
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 xs = fmaf(a[i], xs, bx[i]);
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
         if ((pos & 1023) == 0 || last) {
             const int blk = last ? (L - 1) / 2048 : (pos - 1) / 2048;
             const int r = (last ? L : pos) - blk * 2048;  // elements of block blk seen so far
-            float* xb = xck + (int64_t)blk * 2 * N;
+            float* xb = xck + (int64_t)blk * xpitch;
             const bool w_even = r <= 1024, w_odd = r == 2048 || last;
             for (int n = lane; n < N; n += kWave) {
                 const float s = h[n];

@@ -77,7 +77,9 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
     out_z = torch.empty_like(z_) if z_ is not None else None
-    x = torch.empty(batch, dim, n_chunks, dstate * 2, device=u.device, dtype=A.dtype)
+    # the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor is a view of a wider buffer whose
+    # tail carries 128-element sub-checkpoints for the backward kernel (include/vms_hip.h)
+    x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=A.dtype)[..., :dstate * 2]
     _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus)
     return [out, x] + ([out_z] if z_ is not None else [])
 
@@ -107,8 +109,10 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     if n_chunks > 1:
         _check(x_ is not None, "x_.has_value()")
     if x_ is not None:
-        _check(x_.dtype == A.dtype and x_.is_cuda and x_.is_contiguous() and
-               tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate), "x must be contiguous (batch, dim, n_chunks, 2*dstate)")
+        _check(x_.dtype == A.dtype and x_.is_cuda and tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate)
+               and x_.stride(3) == 1 and x_.stride(1) == n_chunks * x_.stride(2)
+               and x_.stride(0) == dim * x_.stride(1),
+               "x must be the (batch, dim, n_chunks, 2*dstate) checkpoint tensor returned by fwd")
     else:
         _check(seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024")
     du = torch.empty_like(u)

@@ -29,7 +29,8 @@ class ScanFwdParams(ctypes.Structure):
             "z_batch_stride", "z_d_stride", "out_batch_stride", "out_d_stride",
             "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
-            "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride")]
+            "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
+        + [("x_has_sub", _i32), ("reserved0", _i32)]
     )
 
 
@@ -157,6 +158,11 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
     P.out, P.out_z, P.x = _ptr(out), _ptr(out_z), _ptr(x)
+    if x is not None:
+        # x is either dense (.., 2N) or the (.., 2N) view of a (.., 18N) buffer carrying 128-element
+        # sub-checkpoints behind the reference-shaped slots (see include/vms_hip.h)
+        P.x_chunk_stride = x.stride(2)
+        P.x_has_sub = int(x.stride(2) >= 18 * dstate and x.stride(3) == 1)
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
     P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
     if z is not None:
