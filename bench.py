@@ -111,13 +111,14 @@ def main():
         model = torch.nn.parallel.DistributedDataParallel(block, device_ids=[local_rank], bucket_cap_mb=32,
                                                           gradient_as_bucket_view=True)
     hidden = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16)
+    # fixed upstream gradient: the step is exactly the block's forward + backward (no loss kernels)
+    gout = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16)
 
     def step():
         model.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = model(hidden)
-            loss = out.float().square().mean()
-        loss.backward()
+        out.backward(gout)
 
     for _ in range(args.warmup):
         step()

@@ -30,6 +30,9 @@
 
 namespace vms {
 
+#ifndef VMS_BWD_UNROLL
+#define VMS_BWD_UNROLL 1  // states in flight per wave (ILP: only 2 waves per SIMD exist at config 2)
+#endif
 constexpr int kMN = 16;   // dstate handled by this kernel
 constexpr int kMSG = 4;   // states between two cross-wave reductions
 
@@ -86,7 +89,11 @@ __device__ __forceinline__ void row_scan_rev(float& a, float& x) {
 }
 // value of lane (row, n) for a run-time n: byte_index = ((lane & 48) | n) * 4
 __device__ __forceinline__ float row_bcast(float v, int byte_index) {
+#ifndef VMS_ABL_NOBCAST
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
+#else
+    return v + byte_index;
+#endif
 }
 __device__ __forceinline__ float row_allsum(float v) {
     v += rdpp<DPP_ROW_ROR0 + 1>(0.f, v);
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_mfma_kernel(const vms_scan_
         // rolled on purpose: the fully unrolled 16-state body does not fit the instruction cache
         // (measured 11 ms vs < 1 ms); the per-state row broadcasts therefore use ds_bpermute
         // (run-time lane index) instead of DPP row_newbcast (immediate lane index)
-#pragma unroll 1
+#pragma unroll VMS_BWD_UNROLL
         for (int n = 0; n < N; ++n) {
             const int bsrc = ((lane & 48) | n) << 2;  // byte index of lane n of this lane's row
             const float Araw = row_bcast(A_mine, bsrc);
@@ -235,7 +242,11 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_mfma_kernel(const vms_scan_
             float Bn[K], Cn[K];
             rawB.widen(Bn);
             rawC.widen(Cn);
+#ifdef VMS_ABL_NOBCLOAD
+            if (n + 1 < N && dbg == 12345) {
+#else
             if (n + 1 < N) {  // prefetch the next state's B/C while this one computes
+#endif
                 rawB.load(Bc + (int64_t)(n + 1) * p.B_dstate_stride, jo, okb);
                 rawC.load(Cc + (int64_t)(n + 1) * p.C_dstate_stride, jo, okb);
             }
@@ -244,12 +255,18 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_mfma_kernel(const vms_scan_
             float pa = 1.f, px = 0.f;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
+#ifndef VMS_ABL_NOEXP
                 a[i] = fast_exp2(dl[i] * An);
+#else
+                a[i] = dl[i] * An + 1.f;
+#endif
                 xs[i] = dl[i] * uv[i] * Bn[i];  // b_i for now
                 px = fmaf(a[i], px, xs[i]);
                 pa *= a[i];
             }
+#ifndef VMS_ABL_NOSCAN
             row_scan(pa, px);
+#endif
             const float ea = rdpp<DPP_ROW_SHR1>(1.f, pa);
             const float ex = rdpp<DPP_ROW_SHR1>(0.f, px);
             const float hin = row_bcast(hck, bsrc);
@@ -265,7 +282,9 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_mfma_kernel(const vms_scan_
                 rg = fmaf(alpha, rg, dy[i] * Cn[i]);
                 ra *= alpha;
             }
+#ifndef VMS_ABL_NOSCAN
             row_scan_rev(ra, rg);
+#endif
             const float esa = rdpp<DPP_ROW_SHL1>(1.f, ra);
             const float esx = rdpp<DPP_ROW_SHL1>(0.f, rg);
             const float gin = row_bcast(gcar, bsrc);
@@ -296,8 +315,13 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_mfma_kernel(const vms_scan_
                 dA_loc = fmaf(dl[i], gax, dA_loc);
                 const float dBi = gx * (dl[i] * uv[i]);
                 const float dCi = dy[i] * xs[i];
+#ifndef VMS_ABL_NOMFMA
                 accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[i], dBi, accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[i], dCi, accC, 0, 0, 0);
+#else
+                accB[i & 3] += dBi * sel[i];
+                accC[i & 3] += dCi * sel[i];
+#endif
             }
             const float dA_tot = row_allsum(dA_loc);
             if (j == n) dAacc += dA_tot;

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvms_hip.so")
+LIB_PATH = os.environ.get("VMS_HIP_LIB", os.path.join(_HERE, "libvms_hip.so"))  # env: A/B builds in tools/
 
 VMS_F32, VMS_F16, VMS_BF16 = 0, 1, 2
 _DTYPE = {torch.float32: VMS_F32, torch.float16: VMS_F16, torch.bfloat16: VMS_BF16}
