@@ -165,18 +165,8 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
     float dAacc = 0.f;  // dA[d][j]
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-#ifdef VMS_PROF
-    // timeline build: raw s_memtime stamps of two waves of workgroup 3 go to the tail of dC
-    const int psel = (blockIdx.x == 3 && (wave == 0 || wave == 5)) ? (wave == 0 ? 0 : 1) : -1;
-    unsigned int* pbuf = reinterpret_cast<unsigned int*>(q.dC) + (1 << 19) + (psel > 0 ? (1 << 17) : 0);
-    int pidx = 0;
-#define VMS_T() { __builtin_amdgcn_sched_barrier(0); if (psel >= 0 && lane == 0 && pidx < (1 << 17)) pbuf[pidx] = (unsigned int)__builtin_amdgcn_s_memtime(); ++pidx; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define VMS_T()
-#endif
     const int n_c = (L + CH - 1) / CH;
     for (int c = n_c - 1; c >= 0; --c) {
-        VMS_T()  // 0: chunk top
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
         // B / C: uniform per-chunk base + lane offset; first state of this wave
@@ -237,7 +227,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
             if (half == 0) dD_acc = fmaf(dy[i], uv[i], dD_acc);
             ddl[i] = 0.f;
         }
-        VMS_T()  // 1: prologue done
         // row broadcasts for the wave's first state (later states are prefetched inside the loop)
         float bc_A, bc_h, bc_anx, bc_g;
         {
@@ -265,7 +254,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                 bc_anx = row_bcast(anx, bnext);
                 bc_g = row_bcast(gcar, bnext);
             }
-            VMS_T()  // s0: state top (loads + bpermutes issued)
             const float An = Araw * kLog2e;
             float Bn[K], Cn[K];
             curB.widen(Bn);
@@ -289,7 +277,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                 rg = fmaf(alpha, rg, Cn[i]);
                 ra *= alpha;
             }
-            VMS_T()  // s1: local scans done
             row_scan_pair(pa, px, ra, rg);
             const float ea = rdpp<DPP_ROW_SHR1>(1.f, pa);
             const float ex = rdpp<DPP_ROW_SHR1>(0.f, px);
@@ -301,7 +288,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
             const float gout = rdpp<DPP_ROW_NEWBCAST0 + 0>(0.f, fmaf(ra, gin, rg));
             const float afirst = rdpp<DPP_ROW_NEWBCAST0 + 0>(0.f, a[0]);
             if (j == n) { gcar = gout; anx = afirst; }
-            VMS_T()  // s2: row scans + seeds done
             // forward pass B: x_i (xs holds b_i on entry)
             float xrun = xseed;
 #pragma unroll
@@ -326,7 +312,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                 accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[i], gd * uv[i], accB, 0, 0, 0);
                 accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[i], dy[i] * xs[i], accC, 0, 0, 0);
             }
-            VMS_T()  // s3: pass B + outputs + MFMA issue done
             const float dA_tot = row_allsum(dA_loc);
             if (j == n) dAacc += dA_tot;
             // 4-row sums of this state -> LDS (only D rows 0..K-1, i.e. lanes < 4K, carry data)
@@ -334,7 +319,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                 slab[(((quad * NSPLIT + half) * kMSG + (ni % kMSG)) * 2 + 0) * SL + lane] = accB;
                 slab[(((quad * NSPLIT + half) * kMSG + (ni % kMSG)) * 2 + 1) * SL + lane] = accC;
             }
-            VMS_T()  // s4: slab written
             if (ni % kMSG == kMSG - 1) {
                 if (NSPLIT == 2 && ni == kMNS - 1 && half == 1) {  // hand du / ddelta partial sums to the lower half
                     xchg[(quad * 4 + 0) * 64 + lane] = f32x4{duv[0], duv[1], duv[2], duv[3]};
@@ -343,7 +327,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                     xchg[(quad * 4 + 3) * 64 + lane] = f32x4{ddl[4], ddl[5], ddl[6], ddl[7]};
                 }
                 lds_barrier();
-                VMS_T()  // g0: barrier 1 passed
                 // (half, state, tensor, slab lane) -> sum over the 8 row quads, 4 atomics per thread
                 const int t = threadIdx.x;
                 if (t < NSPLIT * kMSG * 2 * SL) {
@@ -369,9 +352,7 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                         ddl[i] += v2[i]; ddl[4 + i] += v3[i];
                     }
                 }
-                VMS_T()  // g1: reduce issued
                 lds_barrier();
-                VMS_T()  // g2: barrier 2 passed
             }
         };
         // rolled (by 2) on purpose: a fully unrolled state loop does not fit the instruction cache
@@ -381,7 +362,6 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
             do_state(ni, rawB, rawC, rawB1, rawC1);
             do_state(ni + 1, rawB1, rawC1, rawB, rawC);
         }
-        VMS_T()  // 2: states done
         if (half == 0) {
             float raw[K];
             RawVec<T, K> t0;

@@ -13,6 +13,7 @@
 //     wave, wave-private), so dstate is a runtime value (<= 256 as in the reference).
 //   * checkpoints x[b,d,c,:] are written every 1024 elements (vms_hip.h).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 
 #include "vms_common.cuh"
@@ -180,6 +181,9 @@ int validate_scan_common(const vms_scan_fwd_params& p) {
     return VMS_OK;
 }
 
+bool scan_fwd_fast_eligible(const vms_scan_fwd_params& p, bool vec);
+int launch_scan_fwd_fast(const vms_scan_fwd_params& p, hipStream_t stream);
+
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
     const int es = p.dtype == VMS_F32 ? 4 : 2;
     bool ok = aligned16(p.u) && aligned16(p.delta) && aligned16(p.out) && mult16(p.u_batch_stride, es) &&
@@ -209,6 +213,8 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     VMS_CHECK((p.z == nullptr) == (p.out_z == nullptr), "out_z must be given iff z is given");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
+    const bool force_generic = getenv("VMS_FORCE_GENERIC") != nullptr;  // test / profiling knob (read per call)
+    if (!force_generic && scan_fwd_fast_eligible(p, vec)) return launch_scan_fwd_fast(p, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_fwd<float, 16>(p, vec, s);
         case VMS_F16: return dispatch_fwd<f16_t, 16>(p, vec, s);
