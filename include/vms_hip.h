@@ -84,7 +84,12 @@ typedef struct {
      * backward kernel walk 128-element chunks; they live in the same allocation, behind the
      * reference-shaped (.., 2*dstate) view the Python layer hands out). */
     int64_t x_chunk_stride;
-    int32_t x_has_sub, reserved0;
+    int32_t x_has_sub;
+    /* reverse != 0 (an extension; the reference has no such flag): the scan runs right-to-left,
+     * i.e. the call equals flip(op(flip(every seqlen-indexed tensor))) without the copies the
+     * reference's bidirectional blocks pay (mamba_simple.py:244,258, mamba_new.py:193,213).
+     * x keeps scan order (chunk c = the c-th 2048 elements visited). */
+    int32_t reverse;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).
@@ -123,6 +128,7 @@ typedef struct {
     int32_t dtype;            /* vms_dtype of x, out, dout, dx, conv_state */
     int32_t wdtype;           /* vms_dtype of weight and bias              */
     int32_t silu_activation;
+    int32_t reverse;          /* != 0: anti-causal (flip o conv o flip); seqlen-contiguous layout only */
     const void *x, *weight, *bias;
     void *out;
     int64_t x_batch_stride, x_c_stride, x_l_stride;

@@ -30,7 +30,7 @@ def _common(x, weight, bias_):
         _check(tuple(bias_.shape) == (x.shape[1],), "bias must have shape (dim,)")
 
 
-def causal_conv1d_fwd(x, weight, bias_, silu_activation):
+def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
     """-> out   (causal_conv1d.cpp:130-189)"""
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
@@ -40,11 +40,11 @@ def causal_conv1d_fwd(x, weight, bias_, silu_activation):
     out = torch.empty_like(x)  # preserve_format keeps the unit-stride axis of x
     if (x.stride(1) == 1 and x.stride(2) > 1) and out.stride(1) != 1:
         out = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=x.dtype, device=x.device).transpose(1, 2)
-    _k.conv_fwd(x, weight, bias_, out, silu_activation)
+    _k.conv_fwd(x, weight, bias_, out, silu_activation, reverse)
     return out
 
 
-def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
+def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False):
     """-> [dx, dweight, dbias]   (causal_conv1d.cpp:191-268)"""
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
@@ -68,7 +68,7 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation):
             dx = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=x.dtype, device=x.device).transpose(1, 2)
     dweight = torch.zeros_like(weight, dtype=torch.float32)
     dbias = torch.zeros_like(bias_, dtype=torch.float32) if bias_ is not None else None
-    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation)
+    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation, reverse)
     return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]
 
 

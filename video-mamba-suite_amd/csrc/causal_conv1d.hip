@@ -330,6 +330,7 @@ static int validate_conv(const vms_conv_fwd_params& p) {
     VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0, "empty problem");
     VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
     VMS_CHECK(p.x && p.weight, "x and weight are required");
+    VMS_CHECK(!p.reverse, "reverse (anti-causal) conv1d is not implemented yet");
     return VMS_OK;
 }
 

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
     const bool same_group = (d0 / dpg) == (d_last / dpg);
     const int g0 = d0 / dpg;
     const int L = p.seqlen, N = p.dstate;
+    const bool rev = p.reverse != 0;
     constexpr int CS = kWave * K;
     constexpr int TILE = K * kTilePad;
 
@@ -95,10 +96,11 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
     for (int c = n_kchunks - 1; c >= 0; --c) {
         const int l0 = c * CS + lane * K;
         const int nv = row_ok ? L - l0 : 0;
+        const int Lr = row_ok ? L : 0;  // rows past dim read nothing
         float uv[K], dl[K], dy[K], duv[K], ddl[K];
-        load_blocked<T, K, VEC>(u + l0, nv, uv);
-        load_blocked<T, K, VEC>(dt + l0, nv, dl);
-        load_blocked<T, K, VEC>(dout + l0, nv, dy);
+        load_dir<T, K, VEC>(u, l0, Lr, rev, uv);
+        load_dir<T, K, VEC>(dt, l0, Lr, rev, dl);
+        load_dir<T, K, VEC>(dout, l0, Lr, rev, dy);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             float t = dl[i] + bias;
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
         }
         if (HZ) {
             float zv[K], ov[K];
-            load_blocked<T, K, VEC>(z + l0, nv, zv);
-            load_blocked<T, K, VEC>(outp + l0, nv, ov);
+            load_dir<T, K, VEC>(z, l0, Lr, rev, zv);
+            load_dir<T, K, VEC>(outp, l0, Lr, rev, ov);
             float dzv[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) {
@@ -118,8 +120,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 dy[i] *= silu;
                 ov[i] *= silu;
             }
-            store_blocked<T, K, VEC>(dz + l0, nv, dzv);
-            if (out_z) store_blocked<T, K, VEC>(out_z + l0, nv, ov);
+            store_dir<T, K, VEC>(dz, l0, Lr, rev, dzv);
+            if (out_z) store_dir<T, K, VEC>(out_z, l0, Lr, rev, ov);
         }
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
             const float Araw = A[n * p.A_dstate_stride];
             const float An = Araw * kLog2e;
             float Bn[K], Cn[K];
-            if (VB) load_blocked<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride + l0, nv, Bn);
-            if (VC) load_blocked<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride + l0, nv, Cn);
+            if (VB) load_dir<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride, l0, Lr, rev, Bn);
+            if (VC) load_dir<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride, l0, Lr, rev, Cn);
             const float bconst = VB ? 1.f : Bc[n * p.B_dstate_stride];
             const float cconst = VC ? 1.f : Cc[n * p.C_dstate_stride];
             // ---- forward re-scan: x_i for the lane's K elements ----
@@ -212,13 +214,13 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 const float dCi = dy[i] * xs[i];
                 if (VB) {
                     if (same_group) { if (i < nv && !(dbg & 2)) lds_atomic_add(&tb[i * kTilePad + lane], dBi); }
-                    else if (i < nv) atomicAdd(dBg + (int64_t)g * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + l0 + i, dBi);
+                    else if (i < nv) atomicAdd(dBg + (int64_t)g * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + (rev ? L - 1 - (l0 + i) : l0 + i), dBi);
                 } else {
                     dBc_loc += dBi;
                 }
                 if (VC) {
                     if (same_group) { if (i < nv && !(dbg & 2)) lds_atomic_add(&tc[i * kTilePad + lane], dCi); }
-                    else if (i < nv) atomicAdd(dCg + (int64_t)g * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + l0 + i, dCi);
+                    else if (i < nv) atomicAdd(dCg + (int64_t)g * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + (rev ? L - 1 - (l0 + i) : l0 + i), dCi);
                 } else {
                     dCc_loc += dCi;
                 }
@@ -239,11 +241,11 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 for (int j = threadIdx.x; j < lim; j += blockDim.x) {
                     const int ti = (j % K) * kTilePad + (j / K);
                     if (VB) {
-                        atomicAdd(dBg + (int64_t)g0 * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + c * CS + j, tb[ti]);
+                        atomicAdd(dBg + (int64_t)g0 * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride + (rev ? L - 1 - (c * CS + j) : c * CS + j), tb[ti]);
                         tb[ti] = 0.f;
                     }
                     if (VC) {
-                        atomicAdd(dCg + (int64_t)g0 * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + c * CS + j, tc[ti]);
+                        atomicAdd(dCg + (int64_t)g0 * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride + (rev ? L - 1 - (c * CS + j) : c * CS + j), tc[ti]);
                         tc[ti] = 0.f;
                     }
                 }
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
         // softplus chain (bwd_kernel.cuh:439-452) and stores
         {
             float raw[K];
-            load_blocked<T, K, VEC>(dt + l0, nv, raw);
+            load_dir<T, K, VEC>(dt, l0, Lr, rev, raw);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 if (p.delta_softplus) {
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 if (i < nv) dbias_acc += ddl[i];
             }
         }
-        store_blocked<T, K, VEC>(du + l0, nv, duv);
-        store_blocked<T, K, VEC>(ddelta + l0, nv, ddl);
+        store_dir<T, K, VEC>(du, l0, Lr, rev, duv);
+        store_dir<T, K, VEC>(ddelta, l0, Lr, rev, ddl);
     }
     if (row_ok) {
         if (q.dD) {
@@ -339,7 +341,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool force_generic = getenv("VMS_FORCE_GENERIC") != nullptr;  // test / profiling knob (read per call)
-    if (!force_generic && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
+    if (!force_generic && !p.reverse && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);
         case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);

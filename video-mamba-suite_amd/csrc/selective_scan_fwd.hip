@@ -44,6 +44,7 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
     if (d >= p.dim) return;
     const int g = d / (p.dim / p.n_groups);
     const int L = p.seqlen, N = p.dstate;
+    const bool rev = p.reverse != 0;
     constexpr int CS = kWave * K;  // elements per wave-chunk
 
     volatile lds_f32* h = (lds_f32*)smem + wave * N;  // running state per n (wave-private)
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
         const int l0 = c * CS + lane * K;
         const int nv = L - l0;  // valid elements from l0 (may be <= 0 or >= K)
         float uv[K], dl[K], du[K], y[K];
-        load_blocked<T, K, VEC>(u + l0, nv, uv);
-        load_blocked<T, K, VEC>(dt + l0, nv, dl);
+        load_dir<T, K, VEC>(u, l0, L, rev, uv);
+        load_dir<T, K, VEC>(dt, l0, L, rev, dl);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             float t = dl[i] + bias;
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
         for (int n = 0; n < N; ++n) {
             const float An = A[n * p.A_dstate_stride] * kLog2e;
             float Bn[K], Cn[K];
-            if (VB) load_blocked<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride + l0, nv, Bn);
-            if (VC) load_blocked<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride + l0, nv, Cn);
+            if (VB) load_dir<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride, l0, L, rev, Bn);
+            if (VC) load_dir<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride, l0, L, rev, Cn);
             const float bconst = VB ? 1.f : Bc[n * p.B_dstate_stride];
             const float cconst = VC ? 1.f : Cc[n * p.C_dstate_stride];
             float a[K], bx[K];
@@ -116,13 +117,13 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
                 y[i] = fmaf(VC ? Cn[i] : cconst, xs, y[i]);
             }
         }
-        store_blocked<T, K, VEC>(out + l0, nv, y);
+        store_dir<T, K, VEC>(out, l0, L, rev, y);
         if (HZ) {
             float zv[K];
-            load_blocked<T, K, VEC>(z + l0, nv, zv);
+            load_dir<T, K, VEC>(z, l0, L, rev, zv);
 #pragma unroll
             for (int i = 0; i < K; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
-            store_blocked<T, K, VEC>(out_z + l0, nv, y);
+            store_dir<T, K, VEC>(out_z, l0, L, rev, y);
         }
         // checkpoints every 1024 elements (and at the end of the sequence)
         const int pos = (c + 1) * CS;

@@ -29,7 +29,9 @@ constexpr int kFN = 16;    // dstate
 constexpr int kFK = VMS_FWD_K;  // elements per lane (4, 8 or 16)
 constexpr int kFRows = 4;  // waves (rows) per workgroup
 
-template <typename T, int K>
+// REV: the lane's K logical elements are stored right-to-left (see vms_hip.h `reverse`): element i of
+// the logical run is vector element K-1-i of the physical run
+template <typename T, int K, bool REV>
 struct RawVecF {
     static constexpr int EPV = (16 / sizeof(T)) < K ? (16 / sizeof(T)) : K;  // 16-byte vectors, or 8-byte when K is small
     vec_t<T, EPV> v[K / EPV];
@@ -41,10 +43,13 @@ struct RawVecF {
             if (!valid) v[i] = vec_t<T, EPV>{};
         }
     }
-    __device__ __forceinline__ float at(int i) const { return static_cast<float>(v[i / EPV][i % EPV]); }
+    __device__ __forceinline__ float at(int i) const {
+        const int e = REV ? K - 1 - i : i;
+        return static_cast<float>(v[e / EPV][e % EPV]);
+    }
 };
 
-template <typename T, int K>
+template <typename T, int K, bool REV>
 __device__ __forceinline__ void store_vec(T* __restrict__ ptr, const float (&in)[K]) {
     constexpr int EPV = (16 / sizeof(T)) < K ? (16 / sizeof(T)) : K;
     using V = vec_t<T, EPV>;
@@ -52,7 +57,7 @@ __device__ __forceinline__ void store_vec(T* __restrict__ ptr, const float (&in)
     for (int v = 0; v < K / EPV; ++v) {
         V t;
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[v * EPV + e]);
+        for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[REV ? K - 1 - (v * EPV + e) : v * EPV + e]);
         reinterpret_cast<V*>(ptr)[v] = t;
     }
 }
@@ -73,7 +78,7 @@ __device__ __forceinline__ void wave_scan_fused(float& a, float& x) {
 #ifndef VMS_FWD_MINWAVES
 #define VMS_FWD_MINWAVES 3  // <= 168 VGPRs: 3 waves per SIMD (measured best of 2 / 3 / 4)
 #endif
-template <typename T, bool HZ>
+template <typename T, bool HZ, bool REV>
 __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast_kernel(const vms_scan_fwd_params p) {
     constexpr int K = kFK, N = kFN, CS = kWave * K;
     const int lane = threadIdx.x & 63;
@@ -107,20 +112,21 @@ __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast
 
     const int n_kchunks = (L + CS - 1) / CS;
     for (int c = 0; c < n_kchunks; ++c) {
-        const int l0 = c * CS + lane * K;
+        const int l0 = c * CS + lane * K;        // logical start of this lane's K elements
         const bool ok = l0 < L;
-        const T* const Bc = Bv + c * CS;
-        const T* const Cc = Cv + c * CS;
-        const uint32_t jo = lane * K;
-        RawVecF<T, K> rB0, rC0, rB1, rC1;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;  // physical start (seqlen % K == 0)
+        const T* const Bc = Bv;
+        const T* const Cc = Cv;
+        const uint32_t jo = pl0;
+        RawVecF<T, K, REV> rB0, rC0, rB1, rC1;
         rB0.load(Bc, jo, ok);
         rC0.load(Cc, jo, ok);
         float dl[K], du[K], y[K];
         float sdl = 0.f;
         {
-            RawVecF<T, K> t0, t1;
-            t0.load(u_b, o_u + l0, ok);
-            t1.load(dt_b, o_dt + l0, ok);
+            RawVecF<T, K, REV> t0, t1;
+            t0.load(u_b, o_u + pl0, ok);
+            t1.load(dt_b, o_dt + pl0, ok);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 float t = t1.at(i) + bias;
@@ -132,8 +138,8 @@ __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast
                 sdl += dl[i];
             }
         }
-        auto do_state = [&](const int n, const RawVecF<T, K>& cB, const RawVecF<T, K>& cC, RawVecF<T, K>& nB,
-                            RawVecF<T, K>& nC) __attribute__((always_inline)) {
+        auto do_state = [&](const int n, const RawVecF<T, K, REV>& cB, const RawVecF<T, K, REV>& cC,
+                            RawVecF<T, K, REV>& nB, RawVecF<T, K, REV>& nC) __attribute__((always_inline)) {
             if (n + 1 < N) {
                 nB.load(Bc + (int64_t)(n + 1) * p.B_dstate_stride, jo, ok);
                 nC.load(Cc + (int64_t)(n + 1) * p.C_dstate_stride, jo, ok);
@@ -172,16 +178,16 @@ __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast
             do_state(n, rB0, rC0, rB1, rC1);
             do_state(n + 1, rB1, rC1, rB0, rC0);
         }
-        if (ok) store_vec<T, K>(out_b + (o_out + l0), y);
+        if (ok) store_vec<T, K, REV>(out_b + (o_out + pl0), y);
         if (HZ) {
-            RawVecF<T, K> tz;
-            tz.load(z_b, o_z + l0, ok);
+            RawVecF<T, K, REV> tz;
+            tz.load(z_b, o_z + pl0, ok);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float zv = tz.at(i);
                 y[i] *= zv * sigmoidf_(zv);
             }
-            if (ok) store_vec<T, K>(outz_b + (o_oz + l0), y);
+            if (ok) store_vec<T, K, REV>(outz_b + (o_oz + pl0), y);
         }
         // reference-shaped checkpoints every 1024 elements (vms_hip.h): even slot = state after the
         // first 1024 elements of a 2048-chunk, odd slot = state after the chunk (or the sequence)
@@ -213,8 +219,10 @@ template <typename T>
 static int launch_fast(const vms_scan_fwd_params& p, hipStream_t stream) {
     const int tiles = (p.dim + kFRows - 1) / kFRows;
     dim3 grid(p.batch * tiles), block(kFRows * kWave);
-    if (p.z) hipLaunchKernelGGL((scan_fwd_fast_kernel<T, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((scan_fwd_fast_kernel<T, false>), grid, block, 0, stream, p);
+#define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_fwd_fast_kernel<T, Z_, R_>), grid, block, 0, stream, p)
+    if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
+    else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
+#undef VMS_L
     VMS_LAUNCH_CHECK();
     return VMS_OK;
 }

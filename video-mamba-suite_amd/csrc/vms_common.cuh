@@ -89,6 +89,54 @@ __device__ __forceinline__ void store_blocked(T* __restrict__ ptr, int n_valid, 
     }
 }
 
+// Direction-aware variants: the K LOGICAL elements [l0, l0+K) of a row of length L, where logical
+// position t is physical position (rev ? L-1-t : t).  Used by the kernels' `reverse` mode, which
+// reads / writes the sequence right-to-left instead of running on flipped copies.
+template <typename T, int K, bool VEC>
+__device__ __forceinline__ void load_dir(const T* __restrict__ row, int l0, int L, bool rev, float (&out)[K],
+                                         float pad = 0.f) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int nv = L - l0;
+    if (!rev) {
+        load_blocked<T, K, VEC>(row + l0, nv, out, pad);
+    } else if (VEC && nv >= K && (L % EPV) == 0) {
+        using V = vec_t<T, EPV>;
+        const V* vp = reinterpret_cast<const V*>(row + (L - l0 - K));
+#pragma unroll
+        for (int v = 0; v < K / EPV; ++v) {
+            V t = vp[v];
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) out[K - 1 - (v * EPV + e)] = static_cast<float>(t[e]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i) out[i] = i < nv ? static_cast<float>(row[L - 1 - l0 - i]) : pad;
+    }
+}
+
+template <typename T, int K, bool VEC>
+__device__ __forceinline__ void store_dir(T* __restrict__ row, int l0, int L, bool rev, const float (&in)[K]) {
+    constexpr int EPV = 16 / sizeof(T);
+    const int nv = L - l0;
+    if (!rev) {
+        store_blocked<T, K, VEC>(row + l0, nv, in);
+    } else if (VEC && nv >= K && (L % EPV) == 0) {
+        using V = vec_t<T, EPV>;
+        V* vp = reinterpret_cast<V*>(row + (L - l0 - K));
+#pragma unroll
+        for (int v = 0; v < K / EPV; ++v) {
+            V t;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[K - 1 - (v * EPV + e)]);
+            vp[v] = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < K; ++i)
+            if (i < nv) row[L - 1 - l0 - i] = static_cast<T>(in[i]);
+    }
+}
+
 // ---- DPP cross-lane primitives (wave64 = 4 rows of 16 lanes) ---------------------------------
 // dpp_mov<CTRL,ROWMASK>(old, src): lane reads `src` of the lane selected by CTRL; lanes whose
 // source does not exist or whose row is masked off keep `old`.

@@ -71,8 +71,9 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, var_B, var_C
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
-    """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)"""
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
+    """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)
+    reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies."""
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
@@ -80,11 +81,11 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
     # the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor is a view of a wider buffer whose
     # tail carries 128-element sub-checkpoints for the backward kernel (include/vms_hip.h)
     x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=A.dtype)[..., :dstate * 2]
-    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus)
+    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
-def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z):
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False):
     """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)"""
     batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
@@ -123,7 +124,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     dD = torch.zeros_like(D_) if D_ is not None else None
     ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     _k.scan_bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
-                ddelta_bias, dz, delta_softplus)
+                ddelta_bias, dz, delta_softplus, reverse)
     result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
     if z_ is not None:
         result.append(dz)

@@ -30,7 +30,7 @@ class ScanFwdParams(ctypes.Structure):
             "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
-        + [("x_has_sub", _i32), ("reserved0", _i32)]
+        + [("x_has_sub", _i32), ("reverse", _i32)]
     )
 
 
@@ -49,7 +49,7 @@ class ScanBwdParams(ctypes.Structure):
 
 class ConvFwdParams(ctypes.Structure):
     _fields_ = (
-        [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "wdtype", "silu_activation")]
+        [(n, _i32) for n in ("batch", "dim", "seqlen", "width", "dtype", "wdtype", "silu_activation", "reverse")]
         + [(n, _vp) for n in ("x", "weight", "bias", "out")]
         + [(n, _i64) for n in ("x_batch_stride", "x_c_stride", "x_l_stride", "weight_c_stride",
                                "weight_width_stride", "out_batch_stride", "out_c_stride", "out_l_stride")]
@@ -146,7 +146,7 @@ def dtype_code(t):
         raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
 
 
-def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus):
+def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False):
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
     var_B, var_C = B.dim() >= 3, C.dim() >= 3
@@ -155,6 +155,7 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.n_chunks = (seqlen + 2047) // 2048
     P.dtype = dtype_code(u)
     P.is_variable_B, P.is_variable_C, P.delta_softplus = int(var_B), int(var_C), int(bool(delta_softplus))
+    P.reverse = int(bool(reverse))
     P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
     P.out, P.out_z, P.x = _ptr(out), _ptr(out_z), _ptr(x)
@@ -182,16 +183,16 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
         P.C_d_stride, P.C_dstate_stride = C.stride(0), C.stride(1)
 
 
-def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus):
+def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False):
     P = ScanFwdParams()
-    fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus)
+    fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     _call("vms_selective_scan_fwd", P, u)
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
-             ddelta_bias, dz, delta_softplus):
+             ddelta_bias, dz, delta_softplus, reverse=False):
     Q = ScanBwdParams()
-    fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus)
+    fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
     Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
     Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
@@ -211,11 +212,12 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
     _call("vms_selective_scan_bwd", Q, u)
 
 
-def fill_conv_fwd(P, x, weight, bias, out, silu):
+def fill_conv_fwd(P, x, weight, bias, out, silu, reverse=False):
     P.batch, P.dim, P.seqlen = x.shape
     P.width = weight.shape[-1]
     P.dtype, P.wdtype = dtype_code(x), dtype_code(weight)
     P.silu_activation = int(bool(silu))
+    P.reverse = int(bool(reverse))
     P.x, P.weight, P.bias, P.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(out)
     P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride()
     P.weight_c_stride, P.weight_width_stride = weight.stride()
@@ -223,15 +225,15 @@ def fill_conv_fwd(P, x, weight, bias, out, silu):
         P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride()
 
 
-def conv_fwd(x, weight, bias, out, silu):
+def conv_fwd(x, weight, bias, out, silu, reverse=False):
     P = ConvFwdParams()
-    fill_conv_fwd(P, x, weight, bias, out, silu)
+    fill_conv_fwd(P, x, weight, bias, out, silu, reverse)
     _call("vms_causal_conv1d_fwd", P, x)
 
 
-def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu):
+def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False):
     Q = ConvBwdParams()
-    fill_conv_fwd(Q.f, x, weight, bias, None, silu)
+    fill_conv_fwd(Q.f, x, weight, bias, None, silu, reverse)
     Q.dout, Q.dx, Q.dweight, Q.dbias = _ptr(dout), _ptr(dx), _ptr(dweight), _ptr(dbias)
     Q.dout_batch_stride, Q.dout_c_stride, Q.dout_l_stride = dout.stride()
     Q.dx_batch_stride, Q.dx_c_stride, Q.dx_l_stride = dx.stride()
