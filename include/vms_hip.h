@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 1
+#define VMS_ABI_VERSION 2
 
 typedef enum {
     VMS_OK = 0,
@@ -84,12 +84,21 @@ typedef struct {
      * backward kernel walk 128-element chunks; they live in the same allocation, behind the
      * reference-shaped (.., 2*dstate) view the Python layer hands out). */
     int64_t x_chunk_stride;
+    /* x_has_sub == 2: x is dense (pitch 2*dstate) and is FOLLOWED, in the same allocation, by the
+     * "rows" checkpoint region written by the row-major fast kernels: float hck[batch][dim/64][ceil(seqlen/128)]
+     * [dstate][64] = the state BEFORE 128-element chunk c of row (b, 64*rb + lane), in scan order
+     * (dstate == 16, (dim / n_groups) % 64 == 0 only).  vms_scan_x_elems() gives the total size. */
     int32_t x_has_sub;
     /* reverse != 0 (an extension; the reference has no such flag): the scan runs right-to-left,
      * i.e. the call equals flip(op(flip(every seqlen-indexed tensor))) without the copies the
      * reference's bidirectional blocks pay (mamba_simple.py:244,258, mamba_new.py:193,213).
      * x keeps scan order (chunk c = the c-th 2048 elements visited). */
     int32_t reverse;
+    /* optional scratch for the fast kernels (vms_scan_fwd_workspace_bytes / _bwd_; 16-byte aligned,
+     * contents undefined on entry and exit, private to this call until the stream reaches its end).
+     * NULL / too small -> the generic kernels run. */
+    void *workspace;
+    int64_t workspace_bytes;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).
@@ -115,6 +124,13 @@ typedef struct {
 
 int vms_selective_scan_fwd(const vms_scan_fwd_params *p, void *stream);
 int vms_selective_scan_bwd(const vms_scan_bwd_params *p, void *stream);
+/* scratch the fast kernels want for this problem (0: none / not eligible); only sizes, dtype and
+ * flags of *p are read */
+int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params *p);
+int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params *p);
+/* number of floats of an x allocation that carries the "rows" checkpoint region (x_has_sub == 2),
+ * or batch*dim*n_chunks*2*dstate when the shape is not eligible */
+int64_t vms_scan_x_elems(const vms_scan_fwd_params *p);
 
 /* ---- causal depthwise conv1d ---------------------------------------------------------
  * x, out, dout, dx : (batch, dim, seqlen); either unit seqlen stride (any batch/channel

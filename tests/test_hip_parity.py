@@ -141,6 +141,94 @@ def test_scan_bwd_fast_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
         check(got[k], want[k], tol * 5, k)
 
 
+ROWS_SHAPES = [(2, 64, 128, 1), (1, 128, 144, 2), (2, 64, 1024, 1), (1, 64, 2064, 1), (1, 192, 4096, 1),
+               (3, 64, 1168, 1), (1, 256, 16, 1)]
+
+
+def _rows_problem(shape, itype, has_z, seed=0):
+    batch, dim, L, groups = shape
+    N = 16
+    torch.manual_seed(seed)
+    g = dict(u=torch.randn(batch, dim, L), delta=0.5 * torch.rand(batch, dim, L), A=-0.5 * torch.rand(dim, N),
+             B=torch.randn(batch, groups, N, L), C=torch.randn(batch, groups, N, L), D=torch.randn(dim),
+             delta_bias=0.5 * torch.rand(dim), g=torch.randn(batch, dim, L), softplus=1)
+    if has_z:
+        g["z"] = torch.randn(batch, dim, L)
+    return {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in g.items()}
+
+
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", ROWS_SHAPES)
+@pytest.mark.parametrize("has_z", [True, False])
+def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
+    """The row-major kernels (lane = row, packed state pairs, 128-element chunks; dstate 16,
+    (dim / groups) % 64 == 0, seqlen % 8 == 0): parity with the oracle for outputs and all gradients, and
+    agreement with the generic kernels on the same inputs."""
+    import selective_scan_cuda
+    import vms_hip
+    monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
+    g = _rows_problem(shape, itype, has_z)
+    tol = TOL[itype]
+    # the raw extension really takes the rows layout for this problem
+    f = lambda k, dt=itype: G(g[k], dt)
+    res = selective_scan_cuda.fwd(f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                  f("z") if has_z else None, f("delta_bias", torch.float32), True)
+    assert res[1].storage_offset() == vms_hip.X_HEADER and res[1].is_contiguous()
+    got, want = run_scan(g, itype, oracle)
+    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    got_gen, _ = run_scan(g, itype, oracle)
+    for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
+        if want.get(k) is not None:
+            check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k} vs oracle")
+            check(got[k], got_gen[k].detach().float().cpu().numpy(), tol * 2, f"{k} rows vs generic kernel")
+    for k in ("dA", "dD", "ddelta_bias"):
+        check(got[k], want[k], tol * 5, k)
+
+
+@pytest.mark.parametrize("impl", ["rows", "fast", "generic"])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 64, 144, 1)])
+def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
+    """reverse=True == flip(fwd(flip(every seqlen-indexed tensor))) for every forward implementation."""
+    import selective_scan_cuda
+    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    g = _rows_problem(shape, itype, True, seed=3)
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                  f("z"), f("delta_bias", torch.float32))
+    out_r, x_r, oz_r = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, True)
+    fl = lambda t: t.flip(-1).contiguous()
+    out_f, x_f, oz_f = selective_scan_cuda.fwd(fl(u), fl(dl), A, fl(B), fl(C), D, fl(z), bias, True)
+    tol = 1e-6 if itype == torch.float32 else 1e-2
+    check(out_r, out_f.flip(-1).float().cpu().numpy(), tol, "out")
+    check(oz_r, oz_f.flip(-1).float().cpu().numpy(), tol, "out_z")
+    check(x_r[:, :, -1, 1::2], x_f[:, :, -1, 1::2].float().cpu().numpy(), 1e-5, "last_state")
+
+
+def test_scan_rows_checkpoint_region(oracle, monkeypatch):
+    """x returned by the rows forward: reference-shaped slots plus the chunk-start states that follow them
+    in the same allocation (include/vms_hip.h, x_has_sub == 2)."""
+    import selective_scan_cuda
+    import vms_hip
+    monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
+    g = _rows_problem((2, 128, 2448, 2), torch.float32, True, seed=5)
+    f = lambda k: G(g[k])
+    out, x, out_z = selective_scan_cuda.fwd(f("u"), f("delta"), f("A"), f("B"), f("C"), f("D"), f("z"), f("delta_bias"), True)
+    b, d, L, N = 2, 128, 2448, 16
+    nch = (L + 127) // 128
+    o = oracle.scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["z"], g["delta_bias"], True, prec="f64")
+    check(x, o["x"], 1e-3, "reference-shaped x (mid + end slots)")
+    ref = x.numel()
+    full = torch.empty(0, device=DEV).set_(x.untyped_storage(), vms_hip.X_HEADER + ref, (b, d // 64, nch, N, 64))
+    for c in (1, 7, 16, 19):
+        t = oracle.scan_fwd(*(g[k][..., :c * 128] for k in ("u", "delta")), g["A"], g["B"][..., :c * 128],
+                            g["C"][..., :c * 128], g["D"], g["z"][..., :c * 128], g["delta_bias"], True, prec="f64")
+        got = full[:, :, c].permute(0, 1, 3, 2).reshape(b, d, N)  # (b, rb, lane, n) -> (b, d, n)
+        check(got, t["last_state"], 1e-3, f"state before chunk {c}")
+    assert float(full[:, :, 0].abs().max()) == 0.0
+
+
+
 def test_scan_strided_views_and_checkpoints(oracle):
     """u/z are channel halves of one xz buffer, delta is d-slowest, out inherits delta's layout,
     dz is written into a slice of a pre-allocated dxz (SSI:175, 182, 244-248); raw extension ABI."""

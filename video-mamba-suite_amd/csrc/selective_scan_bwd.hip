@@ -22,6 +22,7 @@ namespace vms {
 
 int validate_scan_common(const vms_scan_fwd_params& p);
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
+int scan_impl_knob();
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
@@ -321,6 +322,8 @@ static int dispatch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t s) {
 
 using namespace vms;
 
+extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) { return 0; }
+
 extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* stream) {
     VMS_CHECK(qq != nullptr, "null params");
     const vms_scan_bwd_params& q = *qq;
@@ -340,8 +343,8 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
                mult16(q.du_d_stride, es) && mult16(q.ddelta_batch_stride, es) && mult16(q.ddelta_d_stride, es);
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool force_generic = getenv("VMS_FORCE_GENERIC") != nullptr;  // test / profiling knob (read per call)
-    if (!force_generic && !p.reverse && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
+    const int knob = scan_impl_knob();
+    if (knob >= 1 && !p.reverse && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);
         case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);

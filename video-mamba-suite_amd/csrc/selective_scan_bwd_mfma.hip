@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
 
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec) {
     const vms_scan_fwd_params& p = q.f;
-    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kMN || !p.x || !p.x_has_sub) return false;
+    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kMN || !p.x || p.x_has_sub != 1) return false;
     const int dpg = p.dim / p.n_groups;
     if (dpg % kMRows != 0) return false;     // a workgroup's rows must share one B/C group
     if (p.seqlen % kMK != 0) return false;   // a lane's K elements are all in range or all out

@@ -78,10 +78,9 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
     out_z = torch.empty_like(z_) if z_ is not None else None
-    # the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor is a view of a wider buffer whose
-    # tail carries 128-element sub-checkpoints for the backward kernel (include/vms_hip.h)
-    x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=A.dtype)[..., :dstate * 2]
-    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse)
+    # x: the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor, allocated by the binding as a view
+    # of a larger buffer that also carries the finer checkpoints the backward kernels start from
+    x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 

@@ -30,7 +30,7 @@ class ScanFwdParams(ctypes.Structure):
             "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
-        + [("x_has_sub", _i32), ("reverse", _i32)]
+        + [("x_has_sub", _i32), ("reverse", _i32), ("workspace", _vp), ("workspace_bytes", _i64)]
     )
 
 
@@ -71,6 +71,7 @@ EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
     "vms_sizeof_scan_bwd_params", "vms_sizeof_conv_fwd_params", "vms_sizeof_conv_bwd_params",
+    "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems",
 )
 
 _lib = None
@@ -114,6 +115,8 @@ def lib():
                                   f"{ctypes.sizeof(st)} in the binding")
         for fn in EXPORTS[:5]:
             getattr(L, fn).restype = ctypes.c_int
+        for fn in EXPORTS[11:14]:
+            getattr(L, fn).restype = ctypes.c_int64
         _lib = L
     return _lib
 
@@ -160,8 +163,9 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
     P.out, P.out_z, P.x = _ptr(out), _ptr(out_z), _ptr(x)
     if x is not None:
-        # x is either dense (.., 2N) or the (.., 2N) view of a (.., 18N) buffer carrying 128-element
-        # sub-checkpoints behind the reference-shaped slots (see include/vms_hip.h)
+        # x is dense (.., 2N), or the (.., 2N) view of a (.., 18N) buffer carrying 128-element
+        # sub-checkpoints behind the reference-shaped slots, or the dense tensor followed by the
+        # row-major kernels' checkpoint region (see include/vms_hip.h)
         P.x_chunk_stride = x.stride(2)
         P.x_has_sub = int(x.stride(2) >= 18 * dstate and x.stride(3) == 1)
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
@@ -183,16 +187,53 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
         P.C_d_stride, P.C_dstate_stride = C.stride(0), C.stride(1)
 
 
+X_HEADER = 64  # floats in front of a rows-layout x allocation: its storage offset is how bwd recognises it
+
+
+def rows_x_elems(P):
+    """floats of the x allocation the row-major kernels want for the problem in P (reference part +
+    checkpoint region), or 0 when they do not apply."""
+    ref = P.batch * P.dim * P.n_chunks * 2 * P.dstate
+    n = lib().vms_scan_x_elems(ctypes.byref(P))
+    return n if n > ref else 0
+
+
+def is_rows_x(x, n_elems):
+    return (n_elems > 0 and x is not None and x.is_contiguous() and x.storage_offset() == X_HEADER
+            and x.untyped_storage().nbytes() == (X_HEADER + n_elems) * 4)
+
+
 def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False):
+    """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
     P = ScanFwdParams()
     fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
+    ws = None
+    if x is None:
+        batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
+        ne = rows_x_elems(P)
+        if ne:
+            ref = batch * dim * n_chunks * 2 * dstate
+            x = torch.empty(X_HEADER + ne, device=u.device, dtype=torch.float32)[X_HEADER:X_HEADER + ref]
+            x = x.view(batch, dim, n_chunks, 2 * dstate)
+            ws = torch.empty(lib().vms_scan_fwd_workspace_bytes(ctypes.byref(P)), device=u.device, dtype=torch.uint8)
+            P.x, P.x_chunk_stride, P.x_has_sub = _ptr(x), 2 * dstate, 2
+            P.workspace, P.workspace_bytes = _ptr(ws), ws.numel()
+        else:
+            # the reference-shaped tensor is a view of a wider buffer whose tail carries 128-element
+            # sub-checkpoints for the backward kernel (include/vms_hip.h)
+            x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=torch.float32)[..., :dstate * 2]
+            P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
+            P.x_has_sub = 1
     _call("vms_selective_scan_fwd", P, u)
+    return x
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
              ddelta_bias, dz, delta_softplus, reverse=False):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
+    if is_rows_x(x, rows_x_elems(Q.f)):
+        Q.f.x_has_sub = 2
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
     Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
     Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
