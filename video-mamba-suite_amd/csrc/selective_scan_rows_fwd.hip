@@ -25,7 +25,13 @@ namespace vms {
 constexpr int kRN = 16;    // dstate
 constexpr int kRT = 128;   // chunk length == checkpoint distance
 constexpr int kRE = 8;     // elements per inner step
-constexpr int kRTE = 16;   // positions per activation tile
+#ifndef VMS_RTE
+#define VMS_RTE 16
+#endif
+constexpr int kRTE = VMS_RTE;   // positions per activation tile
+#ifndef VMS_DMA_AUX
+#define VMS_DMA_AUX 0
+#endif
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -72,22 +78,13 @@ int64_t scan_rows_fwd_ws_bytes(const vms_scan_fwd_params& p) {
     return rows_bc_bytes(p, g) + rows_agg_bytes(p, g);
 }
 
-// ---- packed fp32 helpers (one instruction each; plain `asm` so the scheduler may move them) ----
-// (s.x * v.x, s.x * v.y) / (s.y * v.x, s.y * v.y): broadcast one half of the first operand
-__device__ __forceinline__ f2 pk_mul_b0(f2 s, f2 v) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "v"(v)); return r; }
-__device__ __forceinline__ f2 pk_mul_b1(f2 s, f2 v) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(s), "v"(v)); return r; }
-// same with the second operand in an SGPR pair
-__device__ __forceinline__ f2 pk_mul_b0_s(f2 s, f2 sv) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(s), "s"(sv)); return r; }
-__device__ __forceinline__ f2 pk_mul_b1_s(f2 s, f2 sv) { f2 r; asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(s), "s"(sv)); return r; }
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// first operand produced by v_exp_f32: gfx950 needs one wait state between a transcendental and a
-// non-transcendental VALU op that reads its result, and the hazard recognizer does not see into asm
-__device__ __forceinline__ f2 pk_fma_after_trans(f2 a, f2 b, f2 c) { f2 r; asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ f2 pk_fma_s(f2 sa, f2 b, f2 c) { f2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(sa), "v"(b), "v"(c)); return r; }
-
 // scalar loads of one position's 16 B (or C) values; completion is awaited by SWAIT* below, which also
 // ties the registers to the instruction stream (the compiler does not track asm loads)
+#ifdef VMS_DBG_NOSMEM  // profiling experiment: always the same (cached) line
+#define VMS_SLOAD16(dst, base, imm) asm volatile("s_load_dwordx16 %0, %1, 0" : "=&s"(dst) : "s"(g.bc))
+#else
 #define VMS_SLOAD16(dst, base, imm) asm volatile("s_load_dwordx16 %0, %1, " #imm : "=&s"(dst) : "s"(base))
+#endif
 #define VMS_SWAIT1(a, dep) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+v"(dep))
 #define VMS_SWAIT2(a, b, dep) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+v"(dep))
 
@@ -139,7 +136,7 @@ struct Tile {
         const T* g = base + (int64_t)(lane / SEG) * d_stride + pt0 + (lane % SEG) * EPV;
 #pragma unroll
         for (int j = 0; j < SEG; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(g + (int64_t)(j * RPI) * d_stride), (lds_void_t*)(img + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(g + (int64_t)(j * RPI) * d_stride), (lds_void_t*)(img + j * 1024), 16, 0, VMS_DMA_AUX);
     }
     static __device__ __forceinline__ void flush_out(T* base, int64_t d_stride, int pt0, const char* img, int lane) {
         T* g = base + (int64_t)(lane / SEG) * d_stride + pt0 + (lane % SEG) * EPV;
@@ -206,19 +203,24 @@ __device__ __forceinline__ RowsWave rows_wave(const vms_scan_fwd_params& p, cons
 }
 
 // ---- pass 1: chunk-local end state (from a zero state) and sum of delta ------------------------------
-#define VMS_P1_Q(i, CUR, q)                                                                \
-    {                                                                                      \
-        f2 t = (i % 2) ? pk_mul_b1(d2[i / 2], A2[q]) : pk_mul_b0(d2[i / 2], A2[q]);        \
-        f2 a = f2{fast_exp2(t.x), fast_exp2(t.y)};                                         \
-        f2 bb = (i % 2) ? pk_mul_b1_s(v2[i / 2], VMS_PAIR(CUR, q)) : pk_mul_b0_s(v2[i / 2], VMS_PAIR(CUR, q)); \
-        x2[q] = pk_fma_after_trans(a, x2[q], bb);                                          \
+// One position, all 8 state pairs.  Plain vector code: the backend selects v_pk_mul_f32 / v_pk_fma_f32 (the
+// splat of delta becomes an op_sel modifier, the B / C pairs stay SGPR operands), schedules around the
+// result latencies and inserts only the wait states the hardware needs (hand-placed asm made the hazard
+// recognizer pad every dependent pair, and hid the transcendental -> VALU hazard from it).
+#define VMS_SPLAT(v, i) __builtin_shufflevector(v[(i) / 2], v[(i) / 2], (i) % 2, (i) % 2)
+#define VMS_FOR8(M, ...) M(0, __VA_ARGS__) M(1, __VA_ARGS__) M(2, __VA_ARGS__) M(3, __VA_ARGS__) M(4, __VA_ARGS__) M(5, __VA_ARGS__) M(6, __VA_ARGS__) M(7, __VA_ARGS__)
+#define VMS_P1_Q(q, CUR)                                                    \
+    {                                                                       \
+        const f2 t = ds * A2[q];                                            \
+        const f2 a = f2{fast_exp2(t.x), fast_exp2(t.y)};                    \
+        x2[q] = __builtin_elementwise_fma(a, x2[q], vs * VMS_PAIR(CUR, q)); \
     }
-#define VMS_P1_ELEM(i, CUR, NXT, IMM)                                                      \
-    {                                                                                      \
-        VMS_SWAIT1(CUR, x2[7]);                                                            \
-        VMS_SLOAD16(NXT, bcp, IMM);                                                        \
-        VMS_P1_Q(i, CUR, 0) VMS_P1_Q(i, CUR, 1) VMS_P1_Q(i, CUR, 2) VMS_P1_Q(i, CUR, 3)    \
-        VMS_P1_Q(i, CUR, 4) VMS_P1_Q(i, CUR, 5) VMS_P1_Q(i, CUR, 6) VMS_P1_Q(i, CUR, 7)    \
+#define VMS_P1_ELEM(i, CUR, NXT, IMM)                  \
+    {                                                  \
+        VMS_SWAIT1(CUR, x2[7]);                        \
+        VMS_SLOAD16(NXT, bcp, IMM);                    \
+        const f2 ds = VMS_SPLAT(d2, i), vs = VMS_SPLAT(v2, i); \
+        VMS_FOR8(VMS_P1_Q, CUR)                        \
     }
 
 template <typename T, bool SP, bool REV>
@@ -259,12 +261,14 @@ __global__ __launch_bounds__(256) void scan_rows_p1_kernel(const vms_scan_fwd_pa
         ru.read(img_u, lane);
         rd.read(img_d, lane);
         VMS_WAIT_LGKM();
+#ifndef VMS_DBG_NOVMEM
         if (tile + 1 < ntiles) {
             Tile<T>::dma_in(u0, p.u_d_stride, pt(tile + 1), img_u, lane);
             Tile<T>::dma_in(d0, p.delta_d_stride, pt(tile + 1), img_d, lane);
         }
+#endif
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kRTE / 8; ++h) {
             f2 d2[4], v2[4];
 #pragma unroll
             for (int i = 0; i < kRE; ++i) {
@@ -330,21 +334,20 @@ __global__ __launch_bounds__(256) void scan_rows_carry_kernel(const vms_scan_fwd
 }
 
 // ---- pass 2: the recurrence from the true chunk-start state, contraction with C, gate ------------------
-#define VMS_P2_Q(i, CB, CC, q)                                                             \
-    {                                                                                      \
-        f2 t = (i % 2) ? pk_mul_b1(d2[i / 2], A2[q]) : pk_mul_b0(d2[i / 2], A2[q]);        \
-        f2 a = f2{fast_exp2(t.x), fast_exp2(t.y)};                                         \
-        f2 bb = (i % 2) ? pk_mul_b1_s(v2[i / 2], VMS_PAIR(CB, q)) : pk_mul_b0_s(v2[i / 2], VMS_PAIR(CB, q)); \
-        x2[q] = pk_fma_after_trans(a, x2[q], bb);                                          \
-        y2[i] = pk_fma_s(VMS_PAIR(CC, q), x2[q], y2[i]);                                   \
+#define VMS_P2_Q(q, i, CB, CC)                                              \
+    {                                                                       \
+        const f2 t = ds * A2[q];                                            \
+        const f2 a = f2{fast_exp2(t.x), fast_exp2(t.y)};                    \
+        x2[q] = __builtin_elementwise_fma(a, x2[q], vs * VMS_PAIR(CB, q));  \
+        y2[i] = __builtin_elementwise_fma(VMS_PAIR(CC, q), x2[q], y2[i]);   \
     }
-#define VMS_P2_ELEM(i, CB, CC, NB, NC, IMMB, IMMC)                                         \
-    {                                                                                      \
-        VMS_SWAIT2(CB, CC, x2[7]);                                                         \
-        VMS_SLOAD16(NB, bcp, IMMB);                                                        \
-        VMS_SLOAD16(NC, bcp, IMMC);                                                        \
-        VMS_P2_Q(i, CB, CC, 0) VMS_P2_Q(i, CB, CC, 1) VMS_P2_Q(i, CB, CC, 2) VMS_P2_Q(i, CB, CC, 3) \
-        VMS_P2_Q(i, CB, CC, 4) VMS_P2_Q(i, CB, CC, 5) VMS_P2_Q(i, CB, CC, 6) VMS_P2_Q(i, CB, CC, 7) \
+#define VMS_P2_ELEM(i, CB, CC, NB, NC, IMMB, IMMC)     \
+    {                                                  \
+        VMS_SWAIT2(CB, CC, x2[7]);                     \
+        VMS_SLOAD16(NB, bcp, IMMB);                    \
+        VMS_SLOAD16(NC, bcp, IMMC);                    \
+        const f2 ds = VMS_SPLAT(d2, i), vs = VMS_SPLAT(v2, i); \
+        VMS_FOR8(VMS_P2_Q, i, CB, CC)                  \
     }
 
 template <typename T, bool HZ, bool SP, bool REV>
@@ -389,20 +392,22 @@ __global__ __launch_bounds__(256) void scan_rows_p2_kernel(const vms_scan_fwd_pa
     Tile<T>::dma_in(u0, p.u_d_stride, pt(0), img_u, lane);
     Tile<T>::dma_in(d0, p.delta_d_stride, pt(0), img_d, lane);
     if (HZ) Tile<T>::dma_in(z0, p.z_d_stride, pt(0), img_z, lane);
+    VMS_WAIT_VM();
     for (int tile = 0; tile < ntiles; ++tile) {
         Raw16<T, REV> ru, rd, rz;
-        VMS_WAIT_VM();
         ru.read(img_u, lane);
         rd.read(img_d, lane);
         if (HZ) rz.read(img_z, lane);
         VMS_WAIT_LGKM();
+#ifndef VMS_DBG_NOVMEM
         if (tile + 1 < ntiles) {
             Tile<T>::dma_in(u0, p.u_d_stride, pt(tile + 1), img_u, lane);
             Tile<T>::dma_in(d0, p.delta_d_stride, pt(tile + 1), img_d, lane);
             if (HZ) Tile<T>::dma_in(z0, p.z_d_stride, pt(tile + 1), img_z, lane);
         }
+#endif
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < kRTE / 8; ++h) {
             f2 d2[4], v2[4], y2[kRE];
 #pragma unroll
             for (int i = 0; i < kRE; ++i) {
@@ -436,9 +441,18 @@ __global__ __launch_bounds__(256) void scan_rows_p2_kernel(const vms_scan_fwd_pa
             }
         }
         VMS_LDS_ORDER();
+#ifdef VMS_DBG_NOVMEM
+        if (tile == ntiles - 1)
+#endif
+        {
         Tile<T>::flush_out(o0, p.out_d_stride, pt(tile), img_o, lane);
         if (HZ) Tile<T>::flush_out(oz0, p.out_z_d_stride, pt(tile), img_oz, lane);
-        VMS_LDS_ORDER();
+        }
+        // the next tile's DMA is older than these stores: wait for it, not for them
+        if (Tile<T>::SEG * (HZ ? 2 : 1) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (Tile<T>::SEG * (HZ ? 2 : 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (Tile<T>::SEG * (HZ ? 2 : 1) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     }
     VMS_SWAIT2(Bq0, Cq0, x2[7]);
 }
