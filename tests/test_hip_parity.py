@@ -185,7 +185,7 @@ def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
         check(got[k], want[k], tol * 5, k)
 
 
-@pytest.mark.parametrize("impl", ["rows", "fast", "generic"])
+@pytest.mark.parametrize("impl", ["rows", "pair", "fast", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 64, 144, 1)])
 def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):

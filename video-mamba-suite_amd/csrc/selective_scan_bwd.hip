@@ -23,6 +23,8 @@ namespace vms {
 int validate_scan_common(const vms_scan_fwd_params& p);
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
 int scan_impl_knob();
+bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec);
+int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream);
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
@@ -344,6 +346,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int knob = scan_impl_knob();
+    if (knob >= 2 && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
     if (knob >= 1 && !p.reverse && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);

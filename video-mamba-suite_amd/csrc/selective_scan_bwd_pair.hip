@@ -1,0 +1,433 @@
+// selective_scan_bwd_pair.hip -- backward selective scan for gfx950 (wave64), ELEMENT PAIRS in packed fp32.
+//
+// Replaces selective_scan_bwd_kernel (mamba/csrc/selective_scan/selective_scan_bwd_kernel.cuh:75-489) for
+// variable B/C, dstate 16, 16-byte aligned I/O, seqlen % 8 == 0, with the forward's 128-element
+// sub-checkpoints in x (vms_hip.h, x_has_sub == 1).  Same decomposition as selective_scan_bwd_mfma.hip:
+//   * a wave owns 4 rows: lane = 16*r + j, row r = one DPP row, lane j owns the 8 consecutive elements
+//     [8j, 8j+8) of the row's current 128-element chunk; chunks are walked from the end of the sequence;
+//     the forward re-scan and the adjoint suffix scan are 4-step DPP row scans;
+//   * dB / dC are summed over the 4 rows of a wave on the matrix pipe (v_mfma_f32_16x16x4_f32 with a 0/1
+//     selector as A operand: exact fp32), over the 8 waves of a workgroup through LDS once per 4 states,
+//     and reach memory as one fp32 atomic per 32 rows;
+//   * per-(row, state) carries live in one register (lane j <-> state j), handed out with ds_bpermute.
+// What is new here: everything that is independent across the 8 elements of a lane (exp arguments, b = delta u B,
+// c = C dy, g a x, the du / ddelta / dA / dB / dC contributions) is computed on PAIRS of consecutive elements
+// with v_pk_mul_f32 / v_pk_fma_f32; only the four recurrences along the elements stay scalar chains.  This
+// kernel has 2048 waves at (8, 8192, 1024, 16) = 2 per SIMD, and a wave issues one instruction every ~8.5
+// cycles whatever it is (tools/microbench.hip): instruction COUNT is what the run time follows, and the
+// pairing takes it from ~32 to ~20 per (element, state) without growing the register footprint (pairing
+// the STATES instead needs 64-bit versions of every per-element array: 350 VGPRs, measured slower).
+// du / ddelta are accumulated as S1_i = sum_n g B, S2_i = sum_n A g a x_{i-1} and combined once per chunk;
+// the lane aggregates' "a" components come from exp2(A * sum(delta)) instead of running products.
+// `reverse` (vms_hip.h) is supported: the lane's 8 logical elements are read / written right-to-left.
+#include "vms_common.cuh"
+
+namespace vms {
+
+constexpr int kBN = 16;   // dstate
+constexpr int kBK = 8;    // elements per lane
+constexpr int kBQ = 8;    // row quads (waves) per workgroup
+constexpr int kBRows = 4 * kBQ;
+constexpr int kBSG = 4;   // states between two cross-quad reductions (= 2 pairs)
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+
+template <typename T, bool REV>
+struct RawB {
+    static constexpr int EPV = 16 / sizeof(T);
+    vec_t<T, EPV> v[kBK / EPV];
+    // seqlen % K == 0: a lane's elements are all valid or all past the end; invalid lanes read the (always
+    // valid) start of the buffer and are neutralised by the caller (delta = 0 / masked stores)
+    __device__ __forceinline__ void load(const T* __restrict__ base, uint32_t off, bool valid) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
+#pragma unroll
+        for (int i = 0; i < kBK / EPV; ++i) v[i] = vp[i];
+    }
+    __device__ __forceinline__ float at(int i) const {
+        const int e = REV ? kBK - 1 - i : i;
+        return static_cast<float>(v[e / EPV][e % EPV]);
+    }
+};
+template <typename T, bool REV>
+__device__ __forceinline__ void store_b(T* __restrict__ ptr, const float (&in)[kBK]) {
+    constexpr int EPV = 16 / sizeof(T);
+    using V = vec_t<T, EPV>;
+#pragma unroll
+    for (int v = 0; v < kBK / EPV; ++v) {
+        V t;
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[REV ? kBK - 1 - (v * EPV + e) : v * EPV + e]);
+        reinterpret_cast<V*>(ptr)[v] = t;
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float bdpp(float old, float src) {
+    return dpp_mov<CTRL, 0xf>(old, src);
+}
+constexpr int DPP_B_ROW_BCAST0 = 0x150;  // row_newbcast:0
+constexpr int DPP_B_ROW_ROR = 0x120;
+
+// Forward inclusive scan of (pa, px) and suffix inclusive scan of (ra, rg) inside each 16-lane row,
+// interleaved: one DPP-fused VOP2 per monoid component and step (x += dpp(x) * a ; a *= dpp(a); lanes
+// whose DPP source falls outside the row are not written = identity).  The interleaving also provides the
+// 2 wait states a DPP read needs after a VALU write of its source.
+__device__ __forceinline__ void row_scan_pair_b(float& pa, float& px, float& ra, float& rg) {
+#define VMS_STEP(S)                                                                   \
+    "v_fmac_f32_dpp %0, %0, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_fmac_f32_dpp %2, %2, %3 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %1, %1, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_mul_f32_dpp %3, %3, %3 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" VMS_STEP(1) VMS_STEP(2) VMS_STEP(4) VMS_STEP(8) "s_nop 1"
+                 : "+v"(px), "+v"(pa), "+v"(rg), "+v"(ra));
+#undef VMS_STEP
+}
+
+// workgroup barrier that orders LDS traffic only (no vmcnt drain)
+__device__ __forceinline__ void lds_barrier_b() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// value of lane (row, n) for a run-time n: byte_index = ((lane & 48) | n) * 4
+__device__ __forceinline__ float row_bcast_b(float v, int byte_index) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ float row_allsum_b(float v) {
+    v += bdpp<DPP_B_ROW_ROR + 1>(0.f, v);
+    v += bdpp<DPP_B_ROW_ROR + 2>(0.f, v);
+    v += bdpp<DPP_B_ROW_ROR + 4>(0.f, v);
+    v += bdpp<DPP_B_ROW_ROR + 8>(0.f, v);
+    return v;
+}
+
+
+template <typename T, bool HZ, bool REV>
+__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_scan_bwd_params q) {
+    const vms_scan_fwd_params& p = q.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = kBK, N = kBN;
+    constexpr int CH = 16 * K;   // elements per row per iteration (128)
+    constexpr int SL = 4 * K;    // lanes of a wave holding reduced vectors (D rows 0..K-1)
+    lds_f32x4* slab = (lds_f32x4*)smem;  // [quad][state % 4][tensor][SL]
+    const int lane = threadIdx.x & 63;
+    const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, r = lane >> 4;
+    // consecutive workgroups share a row tile across batches -> batch = blockIdx % batch keeps the
+    // B/C of one batch on one XCD's L2 when batch == 8
+    const int b = blockIdx.x % p.batch;
+    const int d0 = (blockIdx.x / p.batch) * kBRows;
+    const int d = d0 + quad * 4 + r;
+    const bool row_ok = d < p.dim;
+    const int dc = row_ok ? d : p.dim - 1;
+    const int g = d0 / (p.dim / p.n_groups);  // host guarantees one group per workgroup
+    const int L = p.seqlen;
+
+    const T* const u_b = static_cast<const T*>(p.u);
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    const T* const dout_b = static_cast<const T*>(q.dout);
+    T* const du_b = static_cast<T*>(q.du);
+    T* const ddelta_b = static_cast<T*>(q.ddelta);
+    const T* const z_b = static_cast<const T*>(p.z);
+    const T* const outp_b = static_cast<const T*>(p.out);
+    T* const dz_b = static_cast<T*>(q.dz);
+    T* const out_z_b = static_cast<T*>(p.out_z);
+#define VMS_OFF(bs, ds) static_cast<uint32_t>((int64_t)b * (bs) + (int64_t)dc * (ds))
+    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    float* const dBg = q.dB + (int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride;
+    float* const dCg = q.dC + (int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride;
+    const float* const x_b = static_cast<const float*>(p.x);
+    const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
+    // A of the lane's row: lane j keeps A[d][j]; handed out per state by a row broadcast
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
+
+    float sel[K];  // MFMA row selectors
+#pragma unroll
+    for (int e = 0; e < K; ++e) sel[e] = j == e ? 1.f : 0.f;
+
+    float gcar = 0.f;   // adjoint entering this chunk from the right, state n = j
+    float anx = 1.f;    // a of the first element of the chunk to the right, state n = j
+    float dAacc = 0.f;  // dA[d][j]
+    float dD_acc = 0.f, dbias_acc = 0.f;
+
+    RawB<T, REV> rB0, rC0, rB1, rC1;  // two named sets: explicit double buffering
+    const int n_c = (L + CH - 1) / CH;
+    for (int c = n_c - 1; c >= 0; --c) {
+        const int l0 = c * CH + j * K;
+        const bool okb = l0 < L, ok = okb && row_ok;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;      // physical start of the lane's K elements
+        const bool okn = c > 0;                          // the same lane in the next (= previous-in-sequence) chunk
+        const uint32_t pl0n = REV ? L - (l0 - CH) - K : l0 - CH;
+        if (c == n_c - 1) {
+            rB0.load(Bv, pl0, okb);
+            rC0.load(Cv, pl0, okb);
+        }
+        float uv[K], dy[K];
+        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2];
+        float sdl = 0.f, dl_first = 0.f;
+        {
+            RawB<T, REV> t0, t1, t2;
+            t0.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl0, ok);
+            t1.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
+            t2.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                uv[i] = t0.at(i);
+                dy[i] = ok ? t2.at(i) : 0.f;  // past the end: c = 0, a = 1 (identity for the suffix scan)
+                float t = t1.at(i) + bias;
+                if (p.delta_softplus) t = softplusf_(t);
+                t = ok ? t : 0.f;
+                dl2[i / 2][i % 2] = t;
+                sdl += t;
+                if (i == 0) dl_first = t;
+            }
+        }
+        // state entering the chunk = 128-element sub-checkpoint c-1 (vms_hip.h); lane j loads state j
+        float hck = 0.f;
+        if (c > 0) {
+            const uint32_t o_x = static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride);
+            const int e128 = c * (CH / 128) - 1;  // index of the 128-element sub-checkpoint ending at c*CH
+            hck = x_b[o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j)];
+        }
+        if (HZ) {
+            float zv[K], ov[K], dzv[K];
+            {
+                RawB<T, REV> t0, t1;
+                t0.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
+                t1.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl0, ok);
+#pragma unroll
+                for (int i = 0; i < K; ++i) { zv[i] = t0.at(i); ov[i] = t1.at(i); }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float s = sigmoidf_(zv[i]);
+                const float silu = zv[i] * s;
+                dzv[i] = dy[i] * ov[i] * s * (1.f + zv[i] * (1.f - s));
+                dy[i] *= silu;
+                ov[i] *= silu;
+            }
+            if (ok) {
+                store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
+                if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
+            }
+        }
+        f2 S1[K / 2], S2[K / 2];  // per element: sum_n g B  /  sum_n A g a x_{i-1}
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            dy2[i / 2][i % 2] = dy[i];
+            dlu2[i / 2][i % 2] = dl2[i / 2][i % 2] * uv[i];
+            dD_acc = fmaf(dy[i], uv[i], dD_acc);
+        }
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            S1[k] = f2{0.f, 0.f};
+            S2[k] = f2{0.f, 0.f};
+        }
+        // row broadcasts for the first state (later states are prefetched inside the loop)
+        float bc_A, bc_h, bc_anx, bc_g;
+        {
+            const int b0 = (lane & 48) << 2;
+            bc_A = row_bcast_b(A_mine, b0);
+            bc_h = row_bcast_b(hck, b0);
+            bc_anx = row_bcast_b(anx, b0);
+            bc_g = row_bcast_b(gcar, b0);
+        }
+#define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
+        // One state.  Everything that is independent across the lane's 8 elements runs on ELEMENT PAIRS
+        // (v_pk_*): widening products, the gradient contributions; the four recurrences along the elements
+        // (forward / adjoint, lane aggregate / seeded) stay scalar chains.
+        auto do_state = [&](const int n, const RawB<T, REV>& cB, const RawB<T, REV>& cC, RawB<T, REV>& nB,
+                            RawB<T, REV>& nC) __attribute__((always_inline)) {
+            {   // B / C of the next state -- after the last one: state 0 of the next chunk to the left
+                const int nn = (n + 1) & (N - 1);
+                const bool wrap = n + 1 == N;
+                const uint32_t po = wrap ? pl0n : pl0;
+                const bool pok = wrap ? okn : okb;
+                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
+                nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
+            }
+            const float Araw = bc_A, hin = bc_h, anx_n = bc_anx, gin = bc_g;
+            {   // next state's broadcasts (lane n+1 is not touched by this state's carry updates)
+                const int bnext = ((lane & 48) | ((n + 1) & (N - 1))) << 2;
+                bc_A = row_bcast_b(A_mine, bnext);
+                bc_h = row_bcast_b(hck, bnext);
+                bc_anx = row_bcast_b(anx, bnext);
+                bc_g = row_bcast_b(gcar, bnext);
+            }
+            const float An = Araw * kLog2e;
+            const f2 An2 = f2{An, An}, Araw2 = f2{Araw, Araw};
+            f2 Bn2[K / 2], c2[K / 2], a2[K / 2], xs2[K / 2], ax2[K / 2];
+            // ---- local scans: forward (a, b) and adjoint (alpha = a_{i+1}, c = C dy) ----
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                Bn2[k] = f2{cB.at(2 * k), cB.at(2 * k + 1)};
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
+                c2[k] = f2{cC.at(2 * k), cC.at(2 * k + 1)} * dy2[k];
+            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
+            float pa = fast_exp2(sdl * An);
+            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);  // lane 15 of the row <- next chunk
+            float rg = 0.f;
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
+            float ra = fast_exp2((sdl - dl_first) * An) * a_right;
+            row_scan_pair_b(pa, px, ra, rg);
+            const float ea = bdpp<DPP_ROW_SHR1>(1.f, pa);
+            const float ex = bdpp<DPP_ROW_SHR1>(0.f, px);
+            const float xseed = fmaf(ea, hin, ex);  // state entering this lane's first element
+            const float esa = bdpp<DPP_ROW_SHL1>(1.f, ra);
+            const float esx = bdpp<DPP_ROW_SHL1>(0.f, rg);
+            float grun = fmaf(esa, gin, esx);
+            // new carries = values at the row's lane 0
+            const float gout = bdpp<DPP_B_ROW_BCAST0>(0.f, fmaf(ra, gin, rg));
+            const float afirst = bdpp<DPP_B_ROW_BCAST0>(0.f, a2[0].x);
+            if (j == n) { gcar = gout; anx = afirst; }
+            // forward pass B: a_i x_{i-1} and x_i (xs2 holds b_i on entry)
+            {
+                float xrun = xseed;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float ax = VMS_EL(a2, i) * xrun;
+                    xrun = ax + VMS_EL(xs2, i);
+                    VMS_EL(ax2, i) = ax;
+                    VMS_EL(xs2, i) = xrun;
+                }
+            }
+            // adjoint pass B: g_i (c2 is overwritten)
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                grun = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), grun, VMS_EL(c2, i));
+                VMS_EL(c2, i) = grun;
+            }
+            // per-element contributions, two elements per instruction
+            f32x4 accB = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+            f2 dA2 = f2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 g2 = c2[k];
+                const f2 gax = g2 * ax2[k];  // g * a_i x_{i-1}
+                S1[k] = __builtin_elementwise_fma(g2, Bn2[k], S1[k]);
+                S2[k] = __builtin_elementwise_fma(Araw2, gax, S2[k]);
+                dA2 = __builtin_elementwise_fma(dl2[k], gax, dA2);
+                const f2 dBv = g2 * dlu2[k];
+                const f2 dCv = dy2[k] * xs2[k];
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k], dBv.x, accB, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k], dCv.x, accC, 0, 0, 0);
+                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k + 1], dBv.y, accB, 0, 0, 0);
+                accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k + 1], dCv.y, accC, 0, 0, 0);
+            }
+            const float dA_tot = row_allsum_b(dA2.x + dA2.y);
+            if (j == n) dAacc += dA_tot;
+            // 4-row sums of this state -> LDS (only D rows 0..K-1, i.e. lanes < 4K, carry data)
+            if (lane < SL) {
+                slab[((quad * kBSG + (n % kBSG)) * 2 + 0) * SL + lane] = accB;
+                slab[((quad * kBSG + (n % kBSG)) * 2 + 1) * SL + lane] = accC;
+            }
+            if (n % kBSG == kBSG - 1) {
+                lds_barrier_b();
+                // (state, tensor, slab lane) -> sum over the 8 row quads, 4 atomics per thread
+                const int t = threadIdx.x;
+                if (t < kBSG * 2 * SL) {
+                    const int pl = t % SL, ten = (t / SL) & 1, st = t / (2 * SL);
+                    f32x4 s = slab[((0 * kBSG + st) * 2 + ten) * SL + pl];
+#pragma unroll
+                    for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * SL + pl];
+                    const int nn = n - (kBSG - 1) + st;
+                    const int lo = c * CH + (pl & 15) * K + 4 * (pl >> 4);  // first of 4 logical positions
+                    float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
+                    if (lo < L) {  // seqlen % 8 == 0: the 4 positions are all in or all out
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) atomicAdd(dst + (REV ? L - 1 - (lo + e) : lo + e), s[e]);
+                    }
+                }
+                lds_barrier_b();
+            }
+        };
+        // rolled (by 2) on purpose: a fully unrolled state loop does not fit the instruction cache
+#pragma unroll 1
+        for (int n = 0; n < N; n += 2) {
+            do_state(n, rB0, rC0, rB1, rC1);
+            do_state(n + 1, rB1, rC1, rB0, rC0);
+        }
+#undef VMS_EL
+        {
+            float duv[K], ddl[K];
+            RawB<T, REV> t0;
+            t0.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float s1 = S1[i / 2][i % 2], s2 = S2[i / 2][i % 2];
+                duv[i] = fmaf(dl2[i / 2][i % 2], s1, Dd * dy2[i / 2][i % 2]);
+                ddl[i] = fmaf(uv[i], s1, s2);
+                if (p.delta_softplus) {
+                    const float rr = t0.at(i) + bias;
+                    ddl[i] = rr <= 20.f ? ddl[i] * sigmoidf_(rr) : ddl[i];
+                }
+                dbias_acc += ok ? ddl[i] : 0.f;
+            }
+            if (ok) {
+                store_b<T, REV>(du_b + (VMS_OFF(q.du_batch_stride, q.du_d_stride) + pl0), duv);
+                store_b<T, REV>(ddelta_b + (VMS_OFF(q.ddelta_batch_stride, q.ddelta_d_stride) + pl0), ddl);
+            }
+        }
+    }
+#undef VMS_OFF
+    const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
+    if (row_ok) {
+        if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
+        if (q.ddelta_bias && j == 0) atomicAdd(q.ddelta_bias + d, db_tot);
+        atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)j * q.dA_dstate_stride, dAacc);
+    }
+}
+
+bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
+    const vms_scan_fwd_params& p = q.f;
+    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || p.x_has_sub != 1) return false;
+    const int dpg = p.dim / p.n_groups;
+    if (dpg % kBRows != 0) return false;     // a workgroup's rows must share one B/C group
+    if (p.seqlen % kBK != 0) return false;   // a lane's K elements are all in range or all out
+    // 32-bit element offsets inside the kernel
+    const int64_t lim = (int64_t)1 << 31;
+    auto span = [&](int64_t bs, int64_t ds) { return (p.batch - 1) * bs + (p.dim - 1) * ds + p.seqlen; };
+    if (span(p.u_batch_stride, p.u_d_stride) >= lim || span(p.delta_batch_stride, p.delta_d_stride) >= lim ||
+        span(q.dout_batch_stride, q.dout_d_stride) >= lim || span(q.du_batch_stride, q.du_d_stride) >= lim ||
+        span(q.ddelta_batch_stride, q.ddelta_d_stride) >= lim || span(p.z_batch_stride, p.z_d_stride) >= lim ||
+        span(p.out_batch_stride, p.out_d_stride) >= lim || span(q.dz_batch_stride, q.dz_d_stride) >= lim ||
+        span(p.out_z_batch_stride, p.out_z_d_stride) >= lim ||
+        (int64_t)p.batch * p.dim * p.n_chunks * p.x_chunk_stride >= lim ||
+        (int64_t)(p.dstate - 1) * p.B_dstate_stride + p.seqlen >= lim || (int64_t)(p.dstate - 1) * p.C_dstate_stride + p.seqlen >= lim)
+        return false;
+    return true;
+}
+
+template <typename T>
+static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
+    const vms_scan_fwd_params& p = q.f;
+    const int tiles = (p.dim + kBRows - 1) / kBRows;
+    dim3 grid(p.batch * tiles), block(kBQ * kWave);
+    const size_t smem = 16 * (kBQ * kBSG * 2 * (4 * kBK));  // 32 KB
+#define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_>), grid, block, smem, stream, q)
+    if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
+    else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
+#undef VMS_L
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+
+int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream) {
+    switch (q.f.dtype) {
+        case VMS_BF16: return launch_bpair<bf16_t>(q, stream);
+        case VMS_F16: return launch_bpair<f16_t>(q, stream);
+        default: return launch_bpair<float>(q, stream);
+    }
+}
+
+}  // namespace vms

@@ -189,14 +189,19 @@ int64_t scan_rows_hck_elems(const vms_scan_fwd_params& p);
 int64_t scan_rows_fwd_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_rows(const vms_scan_fwd_params& p, hipStream_t stream);
 
-// which implementation a call may use: VMS_SCAN_IMPL = generic | fast | rows (test / profiling knob,
-// read per call); unset = the best eligible one
+bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec);
+int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
+
+// which implementations a call may use: VMS_SCAN_IMPL = generic (0) | fast (1) | pair (2) | rows (3), a
+// test / profiling knob read per call; every level also allows the ones below it.  Unset = pair: the
+// row-major kernels are an experiment that is slower than the paired lane-per-position kernels.
 int scan_impl_knob() {
     const char* e = getenv("VMS_SCAN_IMPL");
     if (getenv("VMS_FORCE_GENERIC") != nullptr) return 0;
-    if (e == nullptr) return 1;  // TODO: 3 once the rows backward kernel exists
+    if (e == nullptr) return 2;
     if (e[0] == 'g') return 0;
     if (e[0] == 'f') return 1;
+    if (e[0] == 'p') return 2;
     return 3;
 }
 
@@ -232,12 +237,13 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     const int knob = scan_impl_knob();
     if (p.x_has_sub == 2) {
         // the caller laid x out for the row-major kernels: nothing else fills its checkpoint region
-        VMS_CHECK(knob >= 2 && vec && scan_rows_eligible(p), "x_has_sub == 2 needs a problem the rows kernels accept");
+        VMS_CHECK(knob >= 3 && vec && scan_rows_eligible(p), "x_has_sub == 2 needs a problem the rows kernels accept");
         VMS_CHECK(p.x_chunk_stride == 0 || p.x_chunk_stride == 2 * p.dstate, "x_has_sub == 2 needs a dense x");
         VMS_CHECK(p.workspace != nullptr && aligned16(p.workspace) && p.workspace_bytes >= scan_rows_fwd_ws_bytes(p),
                   "workspace of vms_scan_fwd_workspace_bytes() bytes is required with x_has_sub == 2");
         return launch_scan_fwd_rows(p, s);
     }
+    if (knob >= 2 && scan_fwd_pair_eligible(p, vec)) return launch_scan_fwd_pair(p, s);
     if (knob >= 1 && scan_fwd_fast_eligible(p, vec)) return launch_scan_fwd_fast(p, s);
     switch (p.dtype) {
         case VMS_F32: return dispatch_fwd<float, 16>(p, vec, s);
@@ -247,13 +253,13 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 }
 
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
-    if (p == nullptr || scan_impl_knob() < 2 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return 0;
+    if (p == nullptr || scan_impl_knob() < 3 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return 0;
     return scan_rows_fwd_ws_bytes(*p);
 }
 extern "C" int64_t vms_scan_x_elems(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
     const int64_t ref = (int64_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
-    if (scan_impl_knob() < 2 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return ref;
+    if (scan_impl_knob() < 3 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return ref;
     return ref + scan_rows_hck_elems(*p);
 }
 extern "C" const char* vms_last_error(void) { return vms::last_error(); }
