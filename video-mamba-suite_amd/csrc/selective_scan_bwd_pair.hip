@@ -6,9 +6,10 @@
 //   * a wave owns 4 rows: lane = 16*r + j, row r = one DPP row, lane j owns the 8 consecutive elements
 //     [8j, 8j+8) of the row's current 128-element chunk; chunks are walked from the end of the sequence;
 //     the forward re-scan and the adjoint suffix scan are 4-step DPP row scans;
-//   * dB / dC are summed over the 4 rows of a wave on the matrix pipe (v_mfma_f32_16x16x4_f32 with a 0/1
-//     selector as A operand: exact fp32), over the 8 waves of a workgroup through LDS once per 4 states,
-//     and reach memory as one fp32 atomic per 32 rows;
+//   * dB / dC are summed over the 4 rows of a wave with v_permlane16_swap / v_permlane32_swap (3 swaps + 3
+//     adds per 4 values; the MFMA route of selective_scan_bwd_mfma.hip makes the backend unpack every
+//     packed op in the MFMA shadow), over the 8 waves of a workgroup through LDS once per 4 states, and
+//     reach memory as one fp32 atomic per 32 rows;
 //   * per-(row, state) carries live in one register (lane j <-> state j), handed out with ds_bpermute.
 // What is new here: everything that is independent across the 8 elements of a lane (exp arguments, b = delta u B,
 // c = C dy, g a x, the du / ddelta / dA / dB / dC contributions) is computed on PAIRS of consecutive elements
@@ -32,7 +33,7 @@ constexpr int kBSG = 4;   // states between two cross-quad reductions (= 2 pairs
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) f2 lds_f2;
 
 template <typename T, bool REV>
 struct RawB {
@@ -85,6 +86,26 @@ __device__ __forceinline__ void row_scan_pair_b(float& pa, float& px, float& ra,
 #undef VMS_STEP
 }
 
+// Sum over the 4 DPP rows of four values at once: v01 = (v0, v1), v23 = (v2, v3) per lane; on return row r of
+// the result holds, in every column, the sum over the wave's 4 rows of value r.  v_permlane16_swap exchanges
+// the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of
+// the first with the lower half of the second (gfx950).  (The clang builtins for these two return the same
+// register twice on ROCm 7.2 -- hence asm.)
+__device__ __forceinline__ float rows_sum4(f2 v01, f2 v23) {
+    float a = v01.x, b = v01.y, c = v23.x, d = v23.y;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    float p = a + b, q = c + d;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+    return p + q;
+}
+
+// one v_pk_fma_f32 (the backend splits a <2 x float> fma whose operands were assembled from scalars)
+__device__ __forceinline__ f2 pk_fma_b(f2 a, f2 b, f2 c) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // workgroup barrier that orders LDS traffic only (no vmcnt drain)
 __device__ __forceinline__ void lds_barrier_b() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -110,8 +131,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN;
     constexpr int CH = 16 * K;   // elements per row per iteration (128)
-    constexpr int SL = 4 * K;    // lanes of a wave holding reduced vectors (D rows 0..K-1)
-    lds_f32x4* slab = (lds_f32x4*)smem;  // [quad][state % 4][tensor][SL]
+    lds_f2* slab = (lds_f2*)smem;  // [quad][state % 4][tensor][64 lanes]
     const int lane = threadIdx.x & 63;
     const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, r = lane >> 4;
@@ -144,10 +164,6 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
     // A of the lane's row: lane j keeps A[d][j]; handed out per state by a row broadcast
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
-
-    float sel[K];  // MFMA row selectors
-#pragma unroll
-    for (int e = 0; e < K; ++e) sel[e] = j == e ? 1.f : 0.f;
 
     float gcar = 0.f;   // adjoint entering this chunk from the right, state n = j
     float anx = 1.f;    // a of the first element of the chunk to the right, state n = j
@@ -308,45 +324,41 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 VMS_EL(c2, i) = grun;
             }
             // per-element contributions, two elements per instruction
-            f32x4 accB = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
             f2 dA2 = f2{0.f, 0.f};
+            f2 dBv[K / 2], dCv[K / 2];
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
                 const f2 g2 = c2[k];
                 const f2 gax = g2 * ax2[k];  // g * a_i x_{i-1}
-                S1[k] = __builtin_elementwise_fma(g2, Bn2[k], S1[k]);
-                S2[k] = __builtin_elementwise_fma(Araw2, gax, S2[k]);
-                dA2 = __builtin_elementwise_fma(dl2[k], gax, dA2);
-                const f2 dBv = g2 * dlu2[k];
-                const f2 dCv = dy2[k] * xs2[k];
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k], dBv.x, accB, 0, 0, 0);
-                accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k], dCv.x, accC, 0, 0, 0);
-                accB = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k + 1], dBv.y, accB, 0, 0, 0);
-                accC = __builtin_amdgcn_mfma_f32_16x16x4f32(sel[2 * k + 1], dCv.y, accC, 0, 0, 0);
+                S1[k] = pk_fma_b(g2, Bn2[k], S1[k]);
+                S2[k] = pk_fma_b(Araw2, gax, S2[k]);
+                dA2 = pk_fma_b(dl2[k], gax, dA2);
+                dBv[k] = g2 * dlu2[k];
+                dCv[k] = dy2[k] * xs2[k];
             }
+            // dB / dC: sum over the wave's 4 rows.  Element i of the lane ends up, summed, in DPP row i % 4 of
+            // register i / 4: lane (r, j) of {w0, w1} holds the 4-row sums of positions 8j + r and 8j + 4 + r.
+            const f2 wB = f2{rows_sum4(dBv[0], dBv[1]), rows_sum4(dBv[2], dBv[3])};
+            const f2 wC = f2{rows_sum4(dCv[0], dCv[1]), rows_sum4(dCv[2], dCv[3])};
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
-            // 4-row sums of this state -> LDS (only D rows 0..K-1, i.e. lanes < 4K, carry data)
-            if (lane < SL) {
-                slab[((quad * kBSG + (n % kBSG)) * 2 + 0) * SL + lane] = accB;
-                slab[((quad * kBSG + (n % kBSG)) * 2 + 1) * SL + lane] = accC;
-            }
+            // 4-row sums of this state -> LDS
+            slab[((quad * kBSG + (n % kBSG)) * 2 + 0) * kWave + lane] = wB;
+            slab[((quad * kBSG + (n % kBSG)) * 2 + 1) * kWave + lane] = wC;
             if (n % kBSG == kBSG - 1) {
                 lds_barrier_b();
-                // (state, tensor, slab lane) -> sum over the 8 row quads, 4 atomics per thread
+                // (state, tensor, lane) -> sum over the 8 row quads, 2 atomics per thread (512 threads)
                 const int t = threadIdx.x;
-                if (t < kBSG * 2 * SL) {
-                    const int pl = t % SL, ten = (t / SL) & 1, st = t / (2 * SL);
-                    f32x4 s = slab[((0 * kBSG + st) * 2 + ten) * SL + pl];
+                const int pl = t & 63, ten = (t >> 6) & 1, st = t >> 7;
+                f2 s = slab[((0 * kBSG + st) * 2 + ten) * kWave + pl];
 #pragma unroll
-                    for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * SL + pl];
-                    const int nn = n - (kBSG - 1) + st;
-                    const int lo = c * CH + (pl & 15) * K + 4 * (pl >> 4);  // first of 4 logical positions
-                    float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
-                    if (lo < L) {  // seqlen % 8 == 0: the 4 positions are all in or all out
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) atomicAdd(dst + (REV ? L - 1 - (lo + e) : lo + e), s[e]);
-                    }
+                for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * kWave + pl];
+                const int nn = n - (kBSG - 1) + st;
+                const int lo = c * CH + (pl & 15) * K + (pl >> 4);  // logical positions lo and lo + 4
+                float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
+                if (lo < L) {  // seqlen % 8 == 0: a lane's 8 positions are all in or all out
+                    atomicAdd(dst + (REV ? L - 1 - lo : lo), s.x);
+                    atomicAdd(dst + (REV ? L - 1 - (lo + 4) : lo + 4), s.y);
                 }
                 lds_barrier_b();
             }
@@ -413,7 +425,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const vms_scan_fwd_params& p = q.f;
     const int tiles = (p.dim + kBRows - 1) / kBRows;
     dim3 grid(p.batch * tiles), block(kBQ * kWave);
-    const size_t smem = 16 * (kBQ * kBSG * 2 * (4 * kBK));  // 32 KB
+    const size_t smem = sizeof(float) * 2 * (kBQ * kBSG * 2 * kWave);  // 32 KB
 #define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_>), grid, block, smem, stream, q)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
