@@ -1,25 +1,25 @@
-// selective_scan_fwd_pair.hip -- forward selective scan for gfx950 (wave64), state PAIRS in packed fp32.
+// selective_scan_fwd_pair.hip -- forward selective scan for gfx950 (wave64), ELEMENT PAIRS in packed fp32.
 //
 // Same contract and the same decomposition as selective_scan_fwd_fast.hip (one wave per (batch, dim) row,
 // a lane owns K consecutive elements, the lane aggregates are scanned across the wave with DPP, the 16
 // running states live in one register), replacing selective_scan_fwd_kernel
 // (mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:67-303) for variable B/C, dstate 16.
 //
-// What is new: the 16 states are processed as 8 pairs held in 64-bit register pairs, so that every fp32
-// multiply / fma of the recurrence is ONE v_pk_mul_f32 / v_pk_fma_f32 for two states.  Measured on gfx950
+// What is new: everything that is independent across the 16 elements of a lane (the exp arguments,
+// b = delta u B, the contraction y += C x) runs on PAIRS of consecutive elements with v_pk_mul_f32 /
+// v_pk_fma_f32; the two recurrences along the elements stay scalar fma chains.  Measured on gfx950
 // (tools/microbench5.hip, profiles/r01_microbench_issue.txt): next to v_exp_f32 a scalar fp32 VALU op costs
-// ~3.8 cycles of issue, a packed op 4.0 for twice the work; the transcendental itself 8.3.  Per (element,
-// state pair) the kernel issues 5 packed ops + 2 v_exp_f32 (+ 4 integer ops widening bf16 B/C) where the
-// unpaired kernel issued 10 scalar ops + 2 v_exp_f32 + 4.  The cross-lane scan stays per state (DPP does
-// not exist for packed ops): the two states of a pair are scanned by one interleaved DPP sequence, which
-// also provides the wait states a DPP read needs after a VALU write, without s_nop.
-// K = 8 elements per lane (512-element chunks) keeps the pair arrays in ~120 VGPRs = 4 waves per SIMD.
+// ~3.8 cycles of issue, a packed op 4.0 for twice the work.  (Pairing the STATES instead -- also tried --
+// packs the chains too but doubles every per-element array: it has to drop to 8 elements per lane, which
+// doubles the cross-lane scan cost per element, and came out slower.)  Loads carry no select (a lane past the
+// end reads the row start and is neutralised through delta = 0), so that the prefetch of the next state's
+// B / C -- after the last state: of the next chunk's first state -- really stays in flight.
 #include "vms_common.cuh"
 
 namespace vms {
 
 constexpr int kPN = 16;  // dstate
-constexpr int kPK = 8;   // elements per lane
+constexpr int kPK = 16;  // elements per lane
 constexpr int kPRows = 4;
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -54,22 +54,25 @@ __device__ __forceinline__ void store_p(T* __restrict__ ptr, const float (&in)[k
     }
 }
 
-// inclusive 64-lane scan of two independent (a, x) monoids, interleaved: x += dpp(x) * a ; a *= dpp(a).
-// Every DPP source was written at least 3 instructions earlier (the other monoid sits in between).
-__device__ __forceinline__ void wave_scan_fused2(float& a0, float& x0, float& a1, float& x1) {
+// inclusive scan of the monoid (a, x) over the 64 lanes: 4 in-row steps + 2 cross-row broadcasts.
+// x += dpp(x) * a ; a *= dpp(a); lanes without a DPP source (or masked rows) are not written.
+__device__ __forceinline__ void wave_scan_fused_p(float& a, float& x) {
 #define VMS_STEP(CTRL, RM)                                                         \
     "v_fmac_f32_dpp %0, %0, %1 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"         \
-    "v_fmac_f32_dpp %2, %2, %3 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"         \
     "v_mul_f32_dpp %1, %1, %1 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"          \
-    "v_mul_f32_dpp %3, %3, %3 " CTRL " row_mask:" RM " bank_mask:0xf\n\t"
+    "s_nop 1\n\t"
     asm volatile("s_nop 1\n\t" VMS_STEP("row_shr:1", "0xf") VMS_STEP("row_shr:2", "0xf") VMS_STEP("row_shr:4", "0xf")
-                     VMS_STEP("row_shr:8", "0xf") VMS_STEP("row_bcast:15", "0xa") VMS_STEP("row_bcast:31", "0xc") "s_nop 1"
-                 : "+v"(x0), "+v"(a0), "+v"(x1), "+v"(a1));
+                     VMS_STEP("row_shr:8", "0xf") VMS_STEP("row_bcast:15", "0xa") VMS_STEP("row_bcast:31", "0xc")
+                 : "+v"(x), "+v"(a));
 #undef VMS_STEP
 }
+__device__ __forceinline__ f2 pk_fma_p(f2 a, f2 b, f2 c) {
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define VMS_ELP(arr, i) arr[(i) / 2][(i) % 2]
 
-// element i of a float array kept as register pairs, in both halves (becomes an op_sel modifier)
-#define VMS_SPLAT2(arr, i) f2{arr[(i) / 2][(i) % 2], arr[(i) / 2][(i) % 2]}
 
 #ifndef VMS_PAIR_MINWAVES
 #define VMS_PAIR_MINWAVES 3
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)d * p.A_d_stride + (int64_t)(lane & 15) * p.A_dstate_stride] * kLog2e;
     float hreg = 0.f;
 
-    RawP<T, REV> rB0a, rB0b, rC0a, rC0b, rB1a, rB1b, rC1a, rC1b;  // two named sets: explicit double buffering
+    RawP<T, REV> rB0, rC0, rB1, rC1;  // two named sets: explicit double buffering
     const int n_kchunks = (L + CS - 1) / CS;
     for (int c = 0; c < n_kchunks; ++c) {
         const int l0 = c * CS + lane * K;            // logical start of this lane's K elements
@@ -115,12 +118,10 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
         const bool okn = l0 + CS < L;                // the same lane in the next chunk
         const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
         if (c == 0) {
-            rB0a.load(Bv, pl0, ok);
-            rB0b.load(Bv + p.B_dstate_stride, pl0, ok);
-            rC0a.load(Cv, pl0, ok);
-            rC0b.load(Cv + p.C_dstate_stride, pl0, ok);
+            rB0.load(Bv, pl0, ok);
+            rC0.load(Cv, pl0, ok);
         }
-        f2 dl2[K / 2], du2[K / 2], y2[K];
+        f2 dl2[K / 2], du2[K / 2], y2[K / 2];
         float sdl = 0.f;
         {
             RawP<T, REV> t0, t1;
@@ -134,72 +135,62 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
                 const float uv = t0.at(i);
                 dl2[i / 2][i % 2] = t;
                 du2[i / 2][i % 2] = t * uv;
-                y2[i] = f2{Dd * uv, 0.f};
+                y2[i / 2][i % 2] = Dd * uv;
                 sdl += t;
             }
         }
-        auto do_pair = [&](const int q, const RawP<T, REV>& cBa, const RawP<T, REV>& cBb, const RawP<T, REV>& cCa,
-                           const RawP<T, REV>& cCb, RawP<T, REV>& nBa, RawP<T, REV>& nBb, RawP<T, REV>& nCa,
-                           RawP<T, REV>& nCb) __attribute__((always_inline)) {
-            {   // B / C of the next pair -- after the last pair: pair 0 of the next chunk
-                const int qn = (q + 1) & (N / 2 - 1);
-                const bool wrap = q + 1 == N / 2;
-                const T* const Bn = Bv + (int64_t)(2 * qn) * p.B_dstate_stride;
-                const T* const Cn = Cv + (int64_t)(2 * qn) * p.C_dstate_stride;
+        auto do_state = [&](const int n, const RawP<T, REV>& cB, const RawP<T, REV>& cC, RawP<T, REV>& nB,
+                            RawP<T, REV>& nC) __attribute__((always_inline)) {
+            {   // B / C of the next state -- after the last state: state 0 of the next chunk
+                const int nn = (n + 1) & (N - 1);
+                const bool wrap = n + 1 == N;
                 const uint32_t po = wrap ? pl0n : pl0;
                 const bool pok = wrap ? okn : ok;
-                nBa.load(Bn, po, pok);
-                nBb.load(Bn + p.B_dstate_stride, po, pok);
-                nCa.load(Cn, po, pok);
-                nCb.load(Cn + p.C_dstate_stride, po, pok);
+                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
+                nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
             }
-            const f2 An2 = f2{readlane_f(A_mine, 2 * q), readlane_f(A_mine, 2 * q + 1)};
-            const f2 hin2 = f2{readlane_f(hreg, 2 * q), readlane_f(hreg, 2 * q + 1)};
-            f2 a2[K], bx2[K];
-            f2 px2 = f2{0.f, 0.f};
+            const float An = readlane_f(A_mine, n);
+            const float hin = readlane_f(hreg, n);
+            const f2 An2 = f2{An, An};
+            f2 a2[K / 2], bx2[K / 2];
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const f2 t = VMS_SPLAT2(dl2, i) * An2;
-                a2[i] = f2{fast_exp2(t.x), fast_exp2(t.y)};
-                bx2[i] = VMS_SPLAT2(du2, i) * f2{cBa.at(i), cBb.at(i)};
-                px2 = __builtin_elementwise_fma(a2[i], px2, bx2[i]);
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                bx2[k] = du2[k] * f2{cB.at(2 * k), cB.at(2 * k + 1)};
             }
-            const f2 ts = f2{sdl, sdl} * An2;
-            f2 pa2 = f2{fast_exp2(ts.x), fast_exp2(ts.y)};  // product of the lane's K a_i
-            {
-                float a0 = pa2.x, x0 = px2.x, a1 = pa2.y, x1 = px2.y;
-                wave_scan_fused2(a0, x0, a1, x1);
-                pa2 = f2{a0, a1};
-                px2 = f2{x0, x1};
-            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_ELP(a2, i), px, VMS_ELP(bx2, i));
+            float pa = fast_exp2(sdl * An);  // product of the lane's K a_i
+            wave_scan_fused_p(pa, px);
             // exclusive prefix of this lane, seeded with the state carried from earlier chunks
-            const f2 ea2 = f2{dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa2.x), dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa2.y)};
-            const f2 ex2 = f2{dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px2.x), dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px2.y)};
-            f2 xs2 = __builtin_elementwise_fma(ea2, hin2, ex2);
-            const f2 hend2 = __builtin_elementwise_fma(pa2, hin2, px2);  // state after this lane's last element
+            const float ea = dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa);
+            const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
+            float xs = fmaf(ea, hin, ex);
+            const float hend = fmaf(pa, hin, px);  // state after this lane's last element
             if (p.x_has_sub && ((lane + 1) * K) % 128 == 0) {  // 128-element sub-checkpoints for the backward kernel
                 const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
-                float* dst = xck + (int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + 2 * q;
-                dst[0] = hend2.x;
-                dst[1] = hend2.y;
+                xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
             }
-            const float hout0 = readlane_f(hend2.x, 63), hout1 = readlane_f(hend2.y, 63);
-            if (lane == 2 * q) hreg = hout0;
-            if (lane == 2 * q + 1) hreg = hout1;
+            const float hout = readlane_f(hend, 63);
+            if (lane == n) hreg = hout;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
-                xs2 = __builtin_elementwise_fma(a2[i], xs2, bx2[i]);
-                y2[i] = __builtin_elementwise_fma(f2{cCa.at(i), cCb.at(i)}, xs2, y2[i]);
+                xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
+                VMS_ELP(bx2, i) = xs;  // x_i
             }
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) y2[k] = pk_fma_p(f2{cC.at(2 * k), cC.at(2 * k + 1)}, bx2[k], y2[k]);
         };
 #pragma unroll 1
-        for (int q = 0; q < N / 2; q += 2) {
-            do_pair(q, rB0a, rB0b, rC0a, rC0b, rB1a, rB1b, rC1a, rC1b);
-            do_pair(q + 1, rB1a, rB1b, rC1a, rC1b, rB0a, rB0b, rC0a, rC0b);
+        for (int n = 0; n < N; n += 2) {
+            do_state(n, rB0, rC0, rB1, rC1);
+            do_state(n + 1, rB1, rC1, rB0, rC0);
         }
         float y[K];
 #pragma unroll
-        for (int i = 0; i < K; ++i) y[i] = y2[i].x + y2[i].y;
+        for (int i = 0; i < K; ++i) y[i] = VMS_ELP(y2, i);
         if (ok) store_p<T, REV>(out_b + (o_out + pl0), y);
         if (HZ) {
             RawP<T, REV> tz;
