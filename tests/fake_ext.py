@@ -1,0 +1,64 @@
+"""CPU stand-ins for the two extension modules (test infrastructure): same argument lists / returns as
+selective_scan_cuda / causal_conv1d_cuda, computed with the C oracle.  Used to test the host logic of the
+fused autograd nodes and the modules without a GPU (tests/test_cpu_surface.py, tests/ddp_worker.py)."""
+import types
+
+import numpy as np
+import torch
+
+
+def make_fakes(oracle):
+    def np_(t, rev=False):
+        """rev: the extension's right-to-left mode is, by definition, the causal op on flipped copies"""
+        if t is None:
+            return None
+        a = t.detach().float().cpu().numpy()
+        return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
+
+    def un(a, rev):
+        return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
+
+    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
+        rv = reverse
+        r = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
+                            np_(delta_bias_), delta_softplus, prec="f64")
+        out = torch.empty_like(delta).copy_(torch.from_numpy(un(r["out"], rv)))
+        res = [out, torch.from_numpy(r["x"])]
+        if z_ is not None:
+            res.append(torch.empty_like(z_).copy_(torch.from_numpy(un(r["out_z"], rv))))
+        return res
+
+    def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
+            reverse=False):
+        rv = reverse
+        r = oracle.scan_bwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
+                            np_(delta_bias_), np_(dout, rv), delta_softplus, prec="f64")
+        r = {k: (un(v, rv) if v is not None else None) for k, v in r.items()}
+        tt = lambda a, like: torch.from_numpy(a).to(like.dtype)
+        res = [tt(r["du"], u), torch.empty_like(delta).copy_(tt(r["ddelta"], delta)), tt(r["dA"], A),
+               tt(r["dB"], B), tt(r["dC"], C),
+               tt(r["dD"], D_) if D_ is not None else None,
+               tt(r["ddelta_bias"], delta_bias_) if delta_bias_ is not None else None]
+        if z_ is not None:
+            dz = dz_ if dz_ is not None else torch.empty_like(z_)
+            dz.copy_(tt(r["dz"], z_))
+            res.append(dz)
+        if recompute_out_z:
+            f = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
+                                np_(delta_bias_), delta_softplus, prec="f64")
+            res.append(torch.from_numpy(un(f["out_z"], rv)).to(u.dtype))
+        return res
+
+    def cfwd(x, w, b, silu, reverse=False):
+        return torch.from_numpy(un(oracle.conv_fwd(np_(x, reverse), np_(w), np_(b), silu, prec="f64"), reverse)).to(x.dtype)
+
+    def cbwd(x, w, b, dout, dx_, silu, reverse=False):
+        r = oracle.conv_bwd(np_(x, reverse), np_(w), np_(b), np_(dout, reverse), silu, prec="f64")
+        dx = dx_ if dx_ is not None else torch.empty_like(x)
+        dx.copy_(torch.from_numpy(un(r["dx"], reverse)))
+        return [dx, torch.from_numpy(r["dweight"]), torch.from_numpy(r["dbias"]) if b is not None else None]
+
+
+    fs = types.SimpleNamespace(fwd=fwd, bwd=bwd)
+    fc = types.SimpleNamespace(causal_conv1d_fwd=cfwd, causal_conv1d_bwd=cbwd)
+    return fs, fc

@@ -119,47 +119,8 @@ def test_conv_update_ref_matches_golden():
 def fake_extensions(monkeypatch, oracle):
     """Replace the two extension modules seen by the interface code by CPU fakes that follow the
     extension ABI (same argument lists / returns) and compute with the C oracle."""
-    def np_(t):
-        return None if t is None else t.detach().float().cpu().numpy()
-
-    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus):
-        r = oracle.scan_fwd(np_(u), np_(delta), np_(A), np_(B), np_(C), np_(D_), np_(z_), np_(delta_bias_),
-                            delta_softplus, prec="f64")
-        out = torch.empty_like(delta).copy_(torch.from_numpy(r["out"]))
-        res = [out, torch.from_numpy(r["x"])]
-        if z_ is not None:
-            res.append(torch.empty_like(z_).copy_(torch.from_numpy(r["out_z"])))
-        return res
-
-    def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z):
-        r = oracle.scan_bwd(np_(u), np_(delta), np_(A), np_(B), np_(C), np_(D_), np_(z_), np_(delta_bias_),
-                            np_(dout), delta_softplus, prec="f64")
-        tt = lambda a, like: torch.from_numpy(a).to(like.dtype)
-        res = [tt(r["du"], u), torch.empty_like(delta).copy_(tt(r["ddelta"], delta)), tt(r["dA"], A),
-               tt(r["dB"], B), tt(r["dC"], C),
-               tt(r["dD"], D_) if D_ is not None else None,
-               tt(r["ddelta_bias"], delta_bias_) if delta_bias_ is not None else None]
-        if z_ is not None:
-            dz = dz_ if dz_ is not None else torch.empty_like(z_)
-            dz.copy_(tt(r["dz"], z_))
-            res.append(dz)
-        if recompute_out_z:
-            f = oracle.scan_fwd(np_(u), np_(delta), np_(A), np_(B), np_(C), np_(D_), np_(z_), np_(delta_bias_),
-                                delta_softplus, prec="f64")
-            res.append(torch.from_numpy(f["out_z"]).to(u.dtype))
-        return res
-
-    def cfwd(x, w, b, silu):
-        return torch.from_numpy(oracle.conv_fwd(np_(x), np_(w), np_(b), silu, prec="f64")).to(x.dtype)
-
-    def cbwd(x, w, b, dout, dx_, silu):
-        r = oracle.conv_bwd(np_(x), np_(w), np_(b), np_(dout), silu, prec="f64")
-        dx = dx_ if dx_ is not None else torch.empty_like(x)
-        dx.copy_(torch.from_numpy(r["dx"]))
-        return [dx, torch.from_numpy(r["dweight"]), torch.from_numpy(r["dbias"]) if b is not None else None]
-
-    fs = types.SimpleNamespace(fwd=fwd, bwd=bwd)
-    fc = types.SimpleNamespace(causal_conv1d_fwd=cfwd, causal_conv1d_bwd=cbwd)
+    from fake_ext import make_fakes
+    fs, fc = make_fakes(oracle)
     monkeypatch.setattr(ssi, "selective_scan_cuda", fs)
     monkeypatch.setattr(ssi, "causal_conv1d_cuda", fc)
     import causal_conv1d.causal_conv1d_interface as cci

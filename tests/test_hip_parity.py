@@ -205,6 +205,53 @@ def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     check(x_r[:, :, -1, 1::2], x_f[:, :, -1, 1::2].float().cpu().numpy(), 1e-5, "last_state")
 
 
+@pytest.mark.parametrize("impl", ["pair", "generic"])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 6, 300, 1)])
+def test_scan_bwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
+    """bwd(reverse=True) == the causal backward on flipped copies, gradients flipped back."""
+    import selective_scan_cuda
+    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    g = _rows_problem(shape, itype, True, seed=7)
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
+                                        f("D", torch.float32), f("z"), f("delta_bias", torch.float32), f("g"))
+    fl = lambda t: t.flip(-1).contiguous()
+    out_r, x_r, _ = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, True)
+    res_r = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x_r, out_r, None, True, True, True)
+    out_f, x_f, _ = selective_scan_cuda.fwd(fl(u), fl(dl), A, fl(B), fl(C), D, fl(z), bias, True)
+    res_f = selective_scan_cuda.bwd(fl(u), fl(dl), A, fl(B), fl(C), D, fl(z), bias, fl(dout), x_f, out_f, None, True, True)
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z")
+    tol = 2e-5 if itype == torch.float32 else 2e-2
+    for name, a, b_ in zip(names, res_r, res_f):
+        ref = b_.flip(-1) if b_.dim() >= 3 else b_
+        wide = 20 if name in ("dA", "dD", "ddelta_bias") else 1  # atomics: summation order differs
+        check(a, ref.float().cpu().numpy(), tol * wide, name)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("seqlen", [8, 151, 512, 1134])
+def test_conv_reverse_equals_flipped(seqlen, width, itype):
+    """reverse=True (anti-causal) == flip(conv(flip(x))), forward and backward, vector and scalar paths."""
+    import causal_conv1d_cuda
+    torch.manual_seed(seqlen + width)
+    b, d = 2, 40
+    x = torch.randn(b, d, seqlen, device=DEV).to(itype)
+    w = torch.randn(d, width, device=DEV)
+    bias = torch.randn(d, device=DEV)
+    dout = torch.randn(b, d, seqlen, device=DEV).to(itype)
+    fl = lambda t: t.flip(-1).contiguous()
+    y_r = causal_conv1d_cuda.causal_conv1d_fwd(x, w, bias, True, True)
+    y_f = causal_conv1d_cuda.causal_conv1d_fwd(fl(x), w, bias, True).flip(-1)
+    assert torch.equal(y_r, y_f)
+    dx_r, dw_r, db_r = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, None, True, True)
+    dx_f, dw_f, db_f = causal_conv1d_cuda.causal_conv1d_bwd(fl(x), w, bias, fl(dout), None, True)
+    assert torch.equal(dx_r, dx_f.flip(-1))
+    check(dw_r, dw_f.cpu().numpy(), 1e-4, "dweight")
+    check(db_r, db_f.cpu().numpy(), 1e-4, "dbias")
+
+
 def test_scan_rows_checkpoint_region(oracle, monkeypatch):
     """x returned by the rows forward: reference-shaped slots plus the chunk-start states that follow them
     in the same allocation (include/vms_hip.h, x_has_sub == 2)."""

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.y, b = blockIdx.z;
     const int L = p.seqlen;
+    const bool rev = p.reverse != 0;  // logical position t <-> physical L-1-t (anti-causal filter)
     const int l0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
     const T* x = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride;
     T* out = static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)c * p.out_c_stride;
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
 
     float xv[E + 3];  // xv[3 + i] = x[l0 + i]; xv[0..2] = x[l0-3 .. l0-1]
     float cur[E];
-    load_blocked<T, E, VEC>(x + l0, L - l0, cur);
+    load_dir<T, E, VEC>(x, l0, L, rev, cur);
 #pragma unroll
     for (int i = 0; i < E; ++i) xv[3 + i] = cur[i];
     // halo from the previous lane; the first lane of each wave reads it from memory
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int l = l0 - 1 - j;
-            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[l]) : 0.f;
+            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
         }
     }
     float o[E];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
         for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], xv[i + k], acc);
         o[i] = SILU ? acc * sigmoidf_(acc) : acc;
     }
-    store_blocked<T, E, VEC>(out + l0, L - l0, o);
+    store_dir<T, E, VEC>(out, l0, L, rev, o);
 }
 
 // ============================ L-contiguous backward ==========================================
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.y, b = blockIdx.z;
     const int L = p.seqlen;
+    const bool rev = p.reverse != 0;  // logical position t <-> physical L-1-t (anti-causal filter)
     const int l0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
     const T* x = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride;
     const T* dout = static_cast<const T*>(q.dout) + (int64_t)b * q.dout_batch_stride + (int64_t)c * q.dout_c_stride;
@@ -98,8 +100,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
     load_taps(p, c, taps, bias);
 
     float xv[E + 3], cur[E], gc[E], g[E + 3];  // g[i] = dout'[l0 + i], i up to E+2 (right halo)
-    load_blocked<T, E, VEC>(x + l0, L - l0, cur);
-    load_blocked<T, E, VEC>(dout + l0, L - l0, gc);
+    load_dir<T, E, VEC>(x, l0, L, rev, cur);
+    load_dir<T, E, VEC>(dout, l0, L, rev, gc);
 #pragma unroll
     for (int i = 0; i < E; ++i) { xv[3 + i] = cur[i]; g[i] = gc[i]; }
 #pragma unroll
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int l = l0 - 1 - j;
-            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[l]) : 0.f;
+            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
         }
     }
     if (SILU) {
@@ -130,12 +132,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int l = l0 + E + j;
-            xn[3 + j] = l < L ? static_cast<float>(x[l]) : 0.f;
+            xn[3 + j] = l < L ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int l = l0 + E + j;
-            float go = l < L ? static_cast<float>(dout[l]) : 0.f;
+            float go = l < L ? static_cast<float>(dout[rev ? L - 1 - l : l]) : 0.f;
             if (SILU) {
                 float pre = bias;
 #pragma unroll
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
         for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], g[i + 3 - k], acc);
         o[i] = acc;
     }
-    store_blocked<T, E, VEC>(dx + l0, L - l0, o);
+    store_dir<T, E, VEC>(dx, l0, L, rev, o);
     // dweight[k] += x[l - 3 + k] * dout'[l] ; dbias += dout'[l]   (own elements only)
     float dw[kTaps] = {0.f, 0.f, 0.f, 0.f}, db = 0.f;
 #pragma unroll
@@ -330,7 +332,7 @@ static int validate_conv(const vms_conv_fwd_params& p) {
     VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0, "empty problem");
     VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
     VMS_CHECK(p.x && p.weight, "x and weight are required");
-    VMS_CHECK(!p.reverse, "reverse (anti-causal) conv1d is not implemented yet");
+    VMS_CHECK(!p.reverse || (p.x_l_stride == 1 && !p.conv_state), "reverse (anti-causal) conv1d needs the seqlen-contiguous layout");
     return VMS_OK;
 }
 

@@ -13,6 +13,7 @@ flagged _no_reinit; A_log = log(1..d_state) fp32 flagged _no_weight_decay; D = 1
 which parameters are created (so a seed gives the same initial weights), forward semantics.
 """
 import math
+import os
 from typing import Optional
 
 import torch
@@ -25,6 +26,10 @@ from mamba_ssm.ops.selective_scan_interface import (mamba_inner_fn, mamba_inner_
                                                     selective_scan_fn)
 from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from mamba_ssm.ops.triton.selective_state_update import selective_state_update
+
+
+# VMS_NO_REVERSE=1: run the backward direction the reference's way (flipped copies through the causal ops)
+_USE_REVERSE_KERNELS = os.environ.get("VMS_NO_REVERSE", "0") != "1"
 
 
 def _s4d_real_log(d_inner, d_state, device):
@@ -135,16 +140,19 @@ class MambaCore(nn.Module):
             ssm_state.copy_(last_state)
         return y
 
-    def _direction(self, xz, suffix):
-        """One fused direction of the ViM block with parameter set `suffix` ('' or '_b')."""
+    def _direction(self, xz, suffix, reverse=False):
+        """One fused direction of the ViM block with parameter set `suffix` ('' or '_b').
+        reverse: right-to-left over the sequence; the result is in the ORIGINAL order."""
         g = lambda name: getattr(self, name + suffix)
         A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
         return mamba_inner_fn_no_out_proj(
             xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A,
-            None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True)
+            None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True,
+            reverse=reverse)
 
     def _merge_and_project(self, out, out_b):
-        y = (out + out_b.flip([-1])).transpose(1, 2)  # (B, L, d_inner)
+        """out_b: the backward direction's output, already in the original sequence order."""
+        y = (out + out_b).transpose(1, 2)  # (B, L, d_inner)
         if self.if_devide_out:
             y = self.norm(y) if self.variant == "vim_norm" else y / 2
         return F.linear(y, self.out_proj.weight, self.out_proj.bias)
@@ -166,7 +174,13 @@ class MambaCore(nn.Module):
         if self.bimamba_type == "v2":
             if fast:
                 out = self._direction(xz, "")
-                out_b = self._direction(xz.flip([-1]), "_b")
+                # the reference flips xz, runs the same causal node and flips the result back
+                # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values
+                # without the four full-tensor copies (two here, two in autograd)
+                if _USE_REVERSE_KERNELS:
+                    out_b = self._direction(xz, "_b", reverse=True)
+                else:
+                    out_b = self._direction(xz.flip([-1]), "_b").flip([-1])
             else:
                 A = -torch.exp(self.A_log.float())
                 A_b = -torch.exp(self.A_b_log.float())
@@ -174,7 +188,7 @@ class MambaCore(nn.Module):
                                                              self.x_proj, self.dt_proj, self.D, use_pytorch_conv=True)
                 out_b = self.python_mamba_inner_fn_no_out_proj(xz.flip([-1]), A_b, conv_state, ssm_state, seqlen,
                                                                self.conv1d_b, self.x_proj_b, self.dt_proj_b,
-                                                               self.D_b, use_pytorch_conv=True)
+                                                               self.D_b, use_pytorch_conv=True).flip([-1])
             return self._merge_and_project(out, out_b)
         # unidirectional (not constructible today: __init__ asserts "v2", as the reference does)
         A = -torch.exp(self.A_log.float())
@@ -189,11 +203,18 @@ class MambaCore(nn.Module):
     def _forward_dbm(self, xz, inference_params):
         assert self.use_fast_path and inference_params is None, "Not implemented"  # reference mamba_new.py:216
         xz_f, xz_b = torch.chunk(xz, 2, dim=1)
-        # the reversed sequence rides along as extra batch entries: one fused call, shared weights
-        stacked = torch.cat([xz_f, xz_b.flip([-1])], dim=0)
-        out = self._direction(stacked, "")
-        out_f, out_b = out.chunk(2)
-        y = torch.cat([out_f, out_b.flip([-1])], dim=1).transpose(1, 2)  # (B, L, 2*d_inner)
+        if _USE_REVERSE_KERNELS:
+            # shared weights, the second half scanned right-to-left: no cat / flip copies
+            # (the reference stacks the flipped half on the batch axis, mamba_new.py:192-213)
+            out_f = self._direction(xz_f, "")
+            out_b = self._direction(xz_b, "", reverse=True)
+            y = torch.cat([out_f, out_b], dim=1).transpose(1, 2)  # (B, L, 2*d_inner)
+        else:
+            # the reversed sequence rides along as extra batch entries: one fused call, shared weights
+            stacked = torch.cat([xz_f, xz_b.flip([-1])], dim=0)
+            out = self._direction(stacked, "")
+            out_f, out_b = out.chunk(2)
+            y = torch.cat([out_f, out_b.flip([-1])], dim=1).transpose(1, 2)  # (B, L, 2*d_inner)
         return F.linear(y, self.out_proj.weight, self.out_proj.bias)
 
     # ---- autoregressive decode (not used by any video task; kept for API completeness) ----------

@@ -150,13 +150,14 @@ def _autocast_weights(*ws):
     return tuple(w.to(dtype=dt) if w is not None else None for w in ws)
 
 
-def _conv_and_projections(xz, conv_w, conv_b, x_proj_w, dt_proj_w):
+def _conv_and_projections(xz, conv_w, conv_b, x_proj_w, dt_proj_w, reverse=False):
     """conv1d+SiLU on the x half of xz, then the two small GEMMs.
-    Returns conv_out (b, d, l), x_dbl (b*l, R+2N), delta (b, d, l) with d as the slowest axis."""
+    Returns conv_out (b, d, l), x_dbl (b*l, R+2N), delta (b, d, l) with d as the slowest axis.
+    reverse: anti-causal conv (the kernels' right-to-left mode; the GEMMs are position-wise)."""
     batch, _, L = xz.shape
     d_inner = conv_w.shape[0]
     R = dt_proj_w.shape[1]
-    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True)
+    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse)
     x_dbl = F.linear(conv_out.transpose(1, 2).reshape(batch * L, d_inner), x_proj_w)
     delta = _delta_from(x_dbl, dt_proj_w, batch, L)
     return conv_out, x_dbl, delta
@@ -193,8 +194,9 @@ def _flip_l(t):
 
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                   checkpoint_lvl):
-    """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A."""
+                   checkpoint_lvl, reverse=False):
+    """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A.
+    reverse: the whole node runs right-to-left (== flip o node o flip, without the copies)."""
     assert checkpoint_lvl in (0, 1)
     batch, _, L = xz.shape
     R = delta_proj_weight.shape[1]
@@ -211,7 +213,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv_b = conv1d_bias.contiguous() if conv1d_bias is not None else None
     d_inner = conv_w.shape[0]
     z = xz[:, d_inner:]
-    conv_out, x_dbl, delta = _conv_and_projections(xz, conv_w, conv_b, x_proj_weight, delta_proj_weight)
+    conv_out, x_dbl, delta = _conv_and_projections(xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, reverse)
 
     ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
     ctx.has_B_proj_bias, ctx.has_C_proj_bias = B_proj_bias is not None, C_proj_bias is not None
@@ -226,14 +228,15 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     if D is not None:
         D = D.contiguous()
 
-    out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus)
+    out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse)
     saved_b = (None, None, None)
     if A_b is not None:
         assert not A_b.is_complex(), "A should not be complex!!"
-        flip = lambda t: _flip_l(t) if t.dim() >= 3 else t  # constant (dim, dstate) B/C have no L axis
+        # the second scan reads the same tensors in the opposite direction (the reference flips copies of
+        # all of them, SSI:499-507); its outputs come back in the original order
         out_b, ckpt_b, out_z_b = selective_scan_cuda.fwd(
-            _flip_l(conv_out), _flip_l(delta), A_b, flip(B), flip(C), D, _flip_l(z), delta_bias, delta_softplus)
-        out_z = out_z + _flip_l(out_z_b)
+            conv_out, delta, A_b, B, C, D, z, delta_bias, delta_softplus, not reverse)
+        out_z = out_z + out_z_b
         saved_b = (A_b, ckpt_b, out_b)
 
     ctx.delta_softplus = delta_softplus
@@ -242,6 +245,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     ctx.has_out_proj = out_proj is not None
     ctx.has_out_proj_bias = out_bias is not None
     ctx.bidirectional = A_b is not None
+    ctx.reverse = bool(reverse)
     if checkpoint_lvl >= 1:  # rebuilt in backward from xz and x_dbl
         conv_out, delta = None, None
     ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_w,
@@ -262,7 +266,7 @@ def _inner_backward(ctx, dout):
     x, z = xz[:, :d_inner], xz[:, d_inner:]
     dout = _last_dim_contiguous(dout)
     if ctx.checkpoint_lvl == 1:
-        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True)
+        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse)
         delta = _delta_from(x_dbl, delta_proj_weight, batch, L)
     dxz = torch.empty_like(xz)
     dx, dz = dxz[:, :d_inner], dxz[:, d_inner:]
@@ -274,23 +278,22 @@ def _inner_backward(ctx, dout):
     else:
         dy = dout
     dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_cuda.bwd(
-        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True)
+        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True, ctx.reverse)
     dA_b = None
     if ctx.bidirectional:
-        flip = lambda t: _flip_l(t) if t.dim() >= 3 else t
         dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, out_z_b = selective_scan_cuda.bwd(
-            _flip_l(conv_out), _flip_l(delta), A_b, flip(B), flip(C), D, _flip_l(z), delta_bias, _flip_l(dy),
-            ckpt_b, out_b, torch.empty_like(dz), ctx.delta_softplus, True)
-        dconv_out = dconv_out + _flip_l(dconv_b)
-        ddelta = ddelta + _flip_l(ddelta_b)
-        dB = dB + flip(dB_b)
-        dC = dC + flip(dC_b)
+            conv_out, delta, A_b, B, C, D, z, delta_bias, dy,
+            ckpt_b, out_b, torch.empty_like(dz), ctx.delta_softplus, True, not ctx.reverse)
+        dconv_out = dconv_out + dconv_b
+        ddelta = ddelta + ddelta_b
+        dB = dB + dB_b
+        dC = dC + dC_b
         if dD is not None:
             dD = dD + dD_b
         if ddelta_bias is not None:
             ddelta_bias = ddelta_bias + ddelta_bias_b
-        dz.add_(_flip_l(dz_b))
-        out_z = out_z + _flip_l(out_z_b)
+        dz.add_(dz_b)
+        out_z = out_z + out_z_b
 
     dout_proj_weight = dout_proj_bias = None
     if ctx.has_out_proj:
@@ -319,7 +322,7 @@ def _inner_backward(ctx, dout):
     dx_proj_weight = dx_dbl.t() @ conv_out.transpose(1, 2).reshape(batch * L, d_inner)  # (R+2N, d)
     dconv_2d = torch.addmm(dconv_2d, x_proj_weight.t(), dx_dbl.t())       # + x_proj^T dx_dbl^T
     dconv_out = dconv_2d.view(d_inner, batch, L).permute(1, 0, 2)
-    _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True)
+    _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse)
     return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
                 dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
                 dout_proj_weight=dout_proj_weight, dout_proj_bias=dout_proj_bias,
@@ -334,11 +337,11 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
     @custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                 A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1):
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False):
         """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)"""
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               None, A, None, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
-                              delta_softplus, checkpoint_lvl)
+                              delta_softplus, checkpoint_lvl, reverse)
 
     @staticmethod
     @custom_bwd
@@ -346,7 +349,7 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
         g = _inner_backward(ctx, dout)
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
                 g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
-                None, None)
+                None, None, None)
 
 
 class MambaInnerFn(torch.autograd.Function):
@@ -420,10 +423,12 @@ def bimamba_inner_fn(
 def mamba_inner_fn_no_out_proj(
     xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-    C_proj_bias=None, delta_softplus=True
+    C_proj_bias=None, delta_softplus=True, reverse=False
 ):
+    """reverse (extension, default off): the node runs right-to-left over xz -- the value of
+    flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for."""
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
-                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, 1, reverse)
 
 
 # ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------
