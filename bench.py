@@ -29,6 +29,17 @@ import torch.distributed as dist
 
 B, L, D_MODEL, D_STATE, EXPAND, D_CONV = 8, 8192, 1024, 16, 1, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
+# separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01d_traffic.json")
+
+
+def profiled_traffic(kernel):
+    try:
+        with open(TRAFFIC_PROFILE) as f:
+            return json.load(f)[kernel]["hbm_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, groups=1, w=D_CONV):
@@ -154,7 +165,7 @@ def main():
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
         dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
         roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": None,
+                    "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": profiled_traffic(dom),
                     "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
         res = {
             "metric": "Mamba-block fwd+bwd tokens/s at (B,L,D,d_state)=(8,8192,1024,16); % HBM roofline",

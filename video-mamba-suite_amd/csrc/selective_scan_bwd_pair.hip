@@ -29,7 +29,10 @@ constexpr int kBN = 16;   // dstate
 constexpr int kBK = 8;    // elements per lane
 constexpr int kBQ = 8;    // row quads (waves) per workgroup
 constexpr int kBRows = 4 * kBQ;
-constexpr int kBSG = 4;   // states between two cross-quad reductions (= 2 pairs)
+#ifndef VMS_BWD_SG
+#define VMS_BWD_SG 8
+#endif
+constexpr int kBSG = VMS_BWD_SG;   // states between two cross-quad reductions
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -347,18 +350,20 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             slab[((quad * kBSG + (n % kBSG)) * 2 + 1) * kWave + lane] = wC;
             if (n % kBSG == kBSG - 1) {
                 lds_barrier_b();
-                // (state, tensor, lane) -> sum over the 8 row quads, 2 atomics per thread (512 threads)
-                const int t = threadIdx.x;
-                const int pl = t & 63, ten = (t >> 6) & 1, st = t >> 7;
-                f2 s = slab[((0 * kBSG + st) * 2 + ten) * kWave + pl];
+                // (state, tensor, lane) -> sum over the 8 row quads, 2 atomics each
 #pragma unroll
-                for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * kWave + pl];
-                const int nn = n - (kBSG - 1) + st;
-                const int lo = c * CH + (pl & 15) * K + (pl >> 4);  // logical positions lo and lo + 4
-                float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
-                if (lo < L) {  // seqlen % 8 == 0: a lane's 8 positions are all in or all out
-                    atomicAdd(dst + (REV ? L - 1 - lo : lo), s.x);
-                    atomicAdd(dst + (REV ? L - 1 - (lo + 4) : lo + 4), s.y);
+                for (int t = threadIdx.x; t < kBSG * 2 * kWave; t += kBQ * kWave) {
+                    const int pl = t & 63, ten = (t >> 6) & 1, st = t >> 7;
+                    f2 s = slab[((0 * kBSG + st) * 2 + ten) * kWave + pl];
+#pragma unroll
+                    for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * kWave + pl];
+                    const int nn = n - (kBSG - 1) + st;
+                    const int lo = c * CH + (pl & 15) * K + (pl >> 4);  // logical positions lo and lo + 4
+                    float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
+                    if (lo < L) {  // seqlen % 8 == 0: a lane's 8 positions are all in or all out
+                        atomicAdd(dst + (REV ? L - 1 - lo : lo), s.x);
+                        atomicAdd(dst + (REV ? L - 1 - (lo + 4) : lo + 4), s.y);
+                    }
                 }
                 lds_barrier_b();
             }
