@@ -28,6 +28,7 @@ namespace vms {
 constexpr int kBN = 16;   // dstate
 constexpr int kBK = 8;    // elements per lane
 constexpr int kBQ = 8;    // row quads (waves) per workgroup
+constexpr int kPD = 3;    // B / C prefetch distance in states
 constexpr int kBRows = 4 * kBQ;
 #ifndef VMS_BWD_SG
 #define VMS_BWD_SG 8
@@ -173,54 +174,71 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     float dAacc = 0.f;  // dA[d][j]
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    RawB<T, REV> rB0, rC0, rB1, rC1;  // two named sets: explicit double buffering
+    // four named sets: B / C are requested kPD states ahead of their use (explicit software pipeline)
+    RawB<T, REV> rB0, rC0, rB1, rC1, rB2, rC2, rB3, rC3;
+    // the row's own data of the NEXT chunk is requested while the current one computes
+    RawB<T, REV> pu, pdt, pdo, pz, pout;
+    float hck_next = 0.f;
     const int n_c = (L + CH - 1) / CH;
+    const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
+    auto request_row = [&](int cc) __attribute__((always_inline)) {
+        const int ll = cc * CH + j * K;
+        const bool v = cc >= 0 && ll < L && row_ok;
+        const uint32_t pl = REV ? L - ll - K : ll;
+        pu.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl, v);
+        pdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl, v);
+        pdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
+        if (HZ) {
+            pz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
+            pout.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+        }
+        // state entering chunk cc = 128-element sub-checkpoint cc-1 (vms_hip.h); lane j loads state j
+        const int e128 = cc * (CH / 128) - 1;
+        const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
+        hck_next = x_b[xo];
+    };
+    request_row(n_c - 1);
     for (int c = n_c - 1; c >= 0; --c) {
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
         const uint32_t pl0 = REV ? L - l0 - K : l0;      // physical start of the lane's K elements
         const bool okn = c > 0;                          // the same lane in the next (= previous-in-sequence) chunk
         const uint32_t pl0n = REV ? L - (l0 - CH) - K : l0 - CH;
-        if (c == n_c - 1) {
+        if (c == n_c - 1) {  // states 0 .. kPD-1 of the first chunk; later ones arrive through the pipeline
             rB0.load(Bv, pl0, okb);
             rC0.load(Cv, pl0, okb);
+            rB1.load(Bv + p.B_dstate_stride, pl0, okb);
+            rC1.load(Cv + p.C_dstate_stride, pl0, okb);
+            rB2.load(Bv + 2 * p.B_dstate_stride, pl0, okb);
+            rC2.load(Cv + 2 * p.C_dstate_stride, pl0, okb);
         }
         float uv[K], dy[K];
-        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2];
+        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2], sg2[K / 2];  // sg = d softplus / d(delta + bias)
         float sdl = 0.f, dl_first = 0.f;
-        {
-            RawB<T, REV> t0, t1, t2;
-            t0.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl0, ok);
-            t1.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
-            t2.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                uv[i] = t0.at(i);
-                dy[i] = ok ? t2.at(i) : 0.f;  // past the end: c = 0, a = 1 (identity for the suffix scan)
-                float t = t1.at(i) + bias;
-                if (p.delta_softplus) t = softplusf_(t);
-                t = ok ? t : 0.f;
-                dl2[i / 2][i % 2] = t;
-                sdl += t;
-                if (i == 0) dl_first = t;
+        for (int i = 0; i < K; ++i) {
+            uv[i] = pu.at(i);
+            dy[i] = ok ? pdo.at(i) : 0.f;  // past the end: c = 0, a = 1 (identity for the suffix scan)
+            float t = pdt.at(i) + bias, sg = 1.f;
+            if (p.delta_softplus) {  // selective_scan_fwd_kernel.cuh:153-156 and bwd_kernel.cuh:439-452
+                const float e = fast_exp(t);
+                const float w = 1.f + e;
+                const float rw = fast_rcp(w);
+                const float sp = (w == 1.f) ? e : fast_log(w) * (e * fast_rcp(w - 1.f));
+                sg = t <= 20.f ? e * rw : 1.f;
+                t = t <= 20.f ? sp : t;
             }
+            t = ok ? t : 0.f;
+            dl2[i / 2][i % 2] = t;
+            sg2[i / 2][i % 2] = sg;
+            sdl += t;
+            if (i == 0) dl_first = t;
         }
-        // state entering the chunk = 128-element sub-checkpoint c-1 (vms_hip.h); lane j loads state j
-        float hck = 0.f;
-        if (c > 0) {
-            const uint32_t o_x = static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride);
-            const int e128 = c * (CH / 128) - 1;  // index of the 128-element sub-checkpoint ending at c*CH
-            hck = x_b[o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j)];
-        }
+        const float hck = c > 0 ? hck_next : 0.f;
         if (HZ) {
             float zv[K], ov[K], dzv[K];
-            {
-                RawB<T, REV> t0, t1;
-                t0.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
-                t1.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl0, ok);
 #pragma unroll
-                for (int i = 0; i < K; ++i) { zv[i] = t0.at(i); ov[i] = t1.at(i); }
-            }
+            for (int i = 0; i < K; ++i) { zv[i] = pz.at(i); ov[i] = pout.at(i); }
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float s = sigmoidf_(zv[i]);
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             S1[k] = f2{0.f, 0.f};
             S2[k] = f2{0.f, 0.f};
         }
+        request_row(c - 1);  // in flight during the 16 states of this chunk
         // row broadcasts for the first state (later states are prefetched inside the loop)
         float bc_A, bc_h, bc_anx, bc_g;
         {
@@ -261,9 +280,9 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         // (forward / adjoint, lane aggregate / seeded) stay scalar chains.
         auto do_state = [&](const int n, const RawB<T, REV>& cB, const RawB<T, REV>& cC, RawB<T, REV>& nB,
                             RawB<T, REV>& nC) __attribute__((always_inline)) {
-            {   // B / C of the next state -- after the last one: state 0 of the next chunk to the left
-                const int nn = (n + 1) & (N - 1);
-                const bool wrap = n + 1 == N;
+            {   // B / C of state n + kPD -- past the last one: the first states of the next chunk to the left
+                const int nn = (n + kPD) & (N - 1);
+                const bool wrap = n + kPD >= N;
                 const uint32_t po = wrap ? pl0n : pl0;
                 const bool pok = wrap ? okn : okb;
                 nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
@@ -368,26 +387,23 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 lds_barrier_b();
             }
         };
-        // rolled (by 2) on purpose: a fully unrolled state loop does not fit the instruction cache
+        // rolled (by 4) on purpose: a fully unrolled state loop does not fit the instruction cache
 #pragma unroll 1
-        for (int n = 0; n < N; n += 2) {
-            do_state(n, rB0, rC0, rB1, rC1);
+        for (int n = 0; n < N; n += 4) {
+            do_state(n, rB0, rC0, rB3, rC3);
             do_state(n + 1, rB1, rC1, rB0, rC0);
+            do_state(n + 2, rB2, rC2, rB1, rC1);
+            do_state(n + 3, rB3, rC3, rB2, rC2);
         }
 #undef VMS_EL
         {
             float duv[K], ddl[K];
-            RawB<T, REV> t0;
-            t0.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float s1 = S1[i / 2][i % 2], s2 = S2[i / 2][i % 2];
                 duv[i] = fmaf(dl2[i / 2][i % 2], s1, Dd * dy2[i / 2][i % 2]);
                 ddl[i] = fmaf(uv[i], s1, s2);
-                if (p.delta_softplus) {
-                    const float rr = t0.at(i) + bias;
-                    ddl[i] = rr <= 20.f ? ddl[i] * sigmoidf_(rr) : ddl[i];
-                }
+                ddl[i] *= sg2[i / 2][i % 2];
                 dbias_acc += ok ? ddl[i] : 0.f;
             }
             if (ok) {
