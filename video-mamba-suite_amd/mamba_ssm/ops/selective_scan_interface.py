@@ -192,6 +192,27 @@ def _flip_l(t):
     return t.flip([-1])
 
 
+# ---- projections in the sequence-major layout ---------------------------------------------------------
+# The reference runs x_proj / dt_proj on "(b l) d" matrices (SSI:175-182), which turns conv_out into a
+# transposed GEMM operand and leaves B / C needing "(b l) n -> b n l" copies.  The same products taken per
+# batch on the (d, l) matrices the kernels already hold are plain row-major GEMMs whose outputs ARE the
+# layouts the scan wants:  x_dblT = W_x @ conv_out -> (b, R+2N, l): rows R..R+N are B, the last N are C
+# (unit seqlen stride, no copy);  delta = W_dt @ x_dblT[:, :R] -> (b, d, l).  Same arithmetic, different
+# summation grouping inside the GEMMs only.
+def _proj_T(conv_out, x_proj_w, dt_proj_w):
+    R = dt_proj_w.shape[1]
+    x_dblT = torch.matmul(x_proj_w, conv_out)           # (b, R+2N, l)
+    delta = torch.matmul(dt_proj_w, x_dblT[:, :R])      # (b, d, l)
+    return x_dblT, delta
+
+
+def _bc_from_x_dblT(x_dblT, lo, hi, bias):
+    M = x_dblT[:, lo:hi]
+    if bias is not None:
+        M = M + bias.to(dtype=M.dtype)[None, :, None]
+    return M.unsqueeze(1)                                # (b, 1, n, l), unit seqlen stride
+
+
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
                    checkpoint_lvl, reverse=False):
@@ -213,16 +234,19 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv_b = conv1d_bias.contiguous() if conv1d_bias is not None else None
     d_inner = conv_w.shape[0]
     z = xz[:, d_inner:]
-    conv_out, x_dbl, delta = _conv_and_projections(xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, reverse)
+    if is_complex:
+        raise RuntimeError("selective_scan: complex A is not supported by the MI355X HIP path")
+    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse)
+    x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
 
     ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
     ctx.has_B_proj_bias, ctx.has_C_proj_bias = B_proj_bias is not None, C_proj_bias is not None
     if B is None:
-        B = _bc_from_x_dbl(x_dbl, R, R + d_state, B_proj_bias, batch, L, is_complex)
+        B = _bc_from_x_dblT(x_dbl, R, R + d_state, B_proj_bias)
     else:
         B = _last_dim_contiguous(B)
     if C is None:
-        C = _bc_from_x_dbl(x_dbl, x_dbl.shape[1] - d_state, x_dbl.shape[1], C_proj_bias, batch, L, is_complex)
+        C = _bc_from_x_dblT(x_dbl, x_dbl.shape[1] - d_state, x_dbl.shape[1], C_proj_bias)
     else:
         C = _last_dim_contiguous(C)
     if D is not None:
@@ -267,7 +291,7 @@ def _inner_backward(ctx, dout):
     dout = _last_dim_contiguous(dout)
     if ctx.checkpoint_lvl == 1:
         conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse)
-        delta = _delta_from(x_dbl, delta_proj_weight, batch, L)
+        delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
     dxz = torch.empty_like(xz)
     dx, dz = dxz[:, :d_inner], dxz[:, d_inner:]
 
@@ -301,27 +325,25 @@ def _inner_backward(ctx, dout):
         if ctx.has_out_proj_bias:
             dout_proj_bias = dout.sum(dim=(0, 1))
 
-    dx_dbl = torch.empty_like(x_dbl)
+    dx_dbl = torch.empty_like(x_dbl)                                       # (b, R+2N, l)
     dB_proj_bias = dC_proj_bias = None
+    nx = x_dbl.shape[1]
     if ctx.is_variable_B:
-        dB2 = _bc_grad_to_x_dbl(dB, batch, L, is_complex)
+        dB2 = dB.squeeze(1)                                                # (b, n, l)
         if ctx.has_B_proj_bias:
-            dB_proj_bias = dB2.sum(0)
+            dB_proj_bias = dB2.sum(dim=(0, 2))
         dx_dbl[:, R:R + d_state] = dB2
         dB = None
     if ctx.is_variable_C:
-        dC2 = _bc_grad_to_x_dbl(dC, batch, L, is_complex)
+        dC2 = dC.squeeze(1)
         if ctx.has_C_proj_bias:
-            dC_proj_bias = dC2.sum(0)
-        dx_dbl[:, x_dbl.shape[1] - d_state:] = dC2
+            dC_proj_bias = dC2.sum(dim=(0, 2))
+        dx_dbl[:, nx - d_state:] = dC2
         dC = None
-    ddelta_2d = ddelta.permute(1, 0, 2).reshape(d_inner, batch * L)       # view when d-slowest
-    ddelta_proj_weight = ddelta_2d @ x_dbl[:, :R]                          # (d, R)
-    dx_dbl[:, :R] = ddelta_2d.t() @ delta_proj_weight                      # (b*l, R)
-    dconv_2d = dconv_out.permute(1, 0, 2).reshape(d_inner, batch * L)     # (d, b*l) (copy if b-major)
-    dx_proj_weight = dx_dbl.t() @ conv_out.transpose(1, 2).reshape(batch * L, d_inner)  # (R+2N, d)
-    dconv_2d = torch.addmm(dconv_2d, x_proj_weight.t(), dx_dbl.t())       # + x_proj^T dx_dbl^T
-    dconv_out = dconv_2d.view(d_inner, batch, L).permute(1, 0, 2)
+    ddelta_proj_weight = torch.matmul(ddelta, x_dbl[:, :R].transpose(1, 2)).sum(0)      # (d, R)
+    dx_dbl[:, :R] = torch.matmul(delta_proj_weight.t(), ddelta)                          # (b, R, l)
+    dx_proj_weight = torch.matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0)              # (R+2N, d)
+    dconv_out = torch.baddbmm(dconv_out, x_proj_weight.t().expand(batch, -1, -1), dx_dbl)  # + W_x^T dx_dbl
     _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse)
     return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
                 dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
