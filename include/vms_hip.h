@@ -17,6 +17,8 @@
  *        causal-conv1d/csrc/causal_conv1d.cpp:191-268, causal_conv1d_bwd.cu
  *   vms_causal_conv1d_update <- causal_conv1d_cuda.causal_conv1d_update
  *        causal-conv1d/csrc/causal_conv1d.cpp:270-327, causal_conv1d_update.cu
+ *   vms_layer_norm_fwd / _bwd <- the Triton kernels of mamba_ssm.ops.triton.layernorm
+ *        mamba/mamba_ssm/ops/triton/layernorm.py:51-377
  *
  * Conventions
  *   - plain C: POD parameter blocks, raw device pointers, sizes; no torch types.
@@ -169,6 +171,42 @@ int vms_causal_conv1d_fwd(const vms_conv_fwd_params *p, void *stream);
 int vms_causal_conv1d_bwd(const vms_conv_bwd_params *p, void *stream);
 int vms_causal_conv1d_update(const vms_conv_fwd_params *p, void *stream);
 
+/* ---- fused residual-add + LayerNorm / RMSNorm -------------------------------------------
+ * replaces the Triton kernels behind layer_norm_fn / rms_norm_fn / RMSNorm
+ * (mamba/mamba_ssm/ops/triton/layernorm.py: _layer_norm_fwd :122-173, _layer_norm_bwd :291-377).
+ * x, y, residual, residual_out : (rows, cols), unit column stride; weight, bias : (cols) FP32
+ * s = x + residual (fp32) ; y = (s - mean) * rstd * weight + bias   (is_rms: mean = 0)
+ * residual_out (optional) receives s in res_dtype; mean (optional, unused for rms), rstd : (rows) fp32 */
+typedef struct {
+    int32_t rows, cols;
+    int32_t x_dtype;          /* vms_dtype of x, y (forward) / dy, dx (backward)                       */
+    int32_t res_dtype;        /* vms_dtype of residual, residual_out / s, dres_out, dres_in: x_dtype or VMS_F32 */
+    int32_t is_rms;
+    float eps;
+    const void *x, *residual, *weight, *bias;
+    void *y, *residual_out;
+    float *mean, *rstd;
+    int64_t x_row_stride, residual_row_stride, y_row_stride, residual_out_row_stride;
+} vms_norm_params;
+
+/* backward.  s = the forward's pre-norm sum (residual_out, or x when none was stored), dy = grad of y,
+ * dres_out = grad of the prenorm output (optional).  dx (x_dtype); dres_in (res_dtype, optional: wanted
+ * when the residual's dtype differs from x's, layernorm.py:331, 373-375).  dw_partial / db_partial:
+ * (n_partials, cols) fp32, every row written; the caller sums over rows (the reference sums one partial
+ * per SM, :339-343, 371-372).  n_partials = vms_layer_norm_bwd_partials(&f). */
+typedef struct {
+    vms_norm_params f;        /* rows, cols, dtypes, is_rms, weight, mean, rstd are read */
+    const void *s, *dy, *dres_out;
+    void *dx, *dres_in;
+    float *dw_partial, *db_partial;
+    int32_t n_partials, reserved;
+    int64_t s_row_stride, dy_row_stride, dres_out_row_stride, dx_row_stride, dres_in_row_stride;
+} vms_norm_bwd_params;
+
+int vms_layer_norm_fwd(const vms_norm_params *p, void *stream);
+int vms_layer_norm_bwd(const vms_norm_bwd_params *p, void *stream);
+int vms_layer_norm_bwd_partials(const vms_norm_params *p);
+
 /* ---- misc ---------------------------------------------------------------------------- */
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
@@ -177,6 +215,8 @@ int vms_sizeof_scan_fwd_params(void);
 int vms_sizeof_scan_bwd_params(void);
 int vms_sizeof_conv_fwd_params(void);
 int vms_sizeof_conv_bwd_params(void);
+int vms_sizeof_norm_params(void);
+int vms_sizeof_norm_bwd_params(void);
 
 #ifdef __cplusplus
 }

@@ -149,3 +149,30 @@ def conv_update(x, conv_state, weight, bias=None, silu=False, prec="f32"):
     fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(W), _p(x), _p(cs), _p(weight), _p(bias),
        ctypes.c_int(bool(silu)), _p(out))
     return out, cs
+
+
+def norm_fwd(x, weight, bias=None, residual=None, eps=1e-6, is_rms=False, prec="f32"):
+    """-> dict(y, res_out (= x + residual), mean (None for rms), rstd); x: (rows, cols)."""
+    x, weight, bias, residual = map(_c, (x, weight, bias, residual))
+    rows, cols = x.shape
+    y, res_out = np.empty_like(x), np.empty_like(x)
+    mean = None if is_rms else np.empty(rows, np.float32)
+    rstd = np.empty(rows, np.float32)
+    fn = getattr(lib(), "vms_oracle_norm_fwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(rows), ctypes.c_int(cols), _p(x), _p(residual), _p(weight), _p(bias), ctypes.c_float(eps),
+       ctypes.c_int(bool(is_rms)), _p(y), _p(res_out), _p(mean), _p(rstd))
+    return dict(y=y, res_out=res_out, mean=mean, rstd=rstd)
+
+
+def norm_bwd(s, weight, mean, rstd, dy, dres_out=None, is_rms=False, has_bias=True, prec="f32"):
+    """s: the pre-norm sum x + residual saved by the forward.  -> dict(ds, dw, db)."""
+    s, weight, mean, rstd, dy, dres_out = map(_c, (s, weight, mean, rstd, dy, dres_out))
+    rows, cols = s.shape
+    ds, dw = np.empty_like(s), np.empty(cols, np.float32)
+    db = np.empty(cols, np.float32) if has_bias else None
+    fn = getattr(lib(), "vms_oracle_norm_bwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(rows), ctypes.c_int(cols), _p(s), _p(weight), _p(mean), _p(rstd), _p(dy), _p(dres_out),
+       ctypes.c_int(bool(is_rms)), _p(ds), _p(dw), _p(db))
+    return dict(ds=ds, dw=dw, db=db)

@@ -333,3 +333,73 @@ void FN(vms_oracle_conv_update)(int batch, int dim, int W, const float *x, float
             out[(size_t)b * dim + d] = (float)(silu ? acc * sigmoid_ref(acc) : acc);
         }
 }
+
+/* ---- fused residual-add + LayerNorm / RMSNorm -------------------------------------------------------
+ * layer_norm_ref / rms_norm_ref (mamba/mamba_ssm/ops/triton/layernorm.py:19-48) with upcast=True, which is
+ * what the reference's fused kernels compute (fp32 statistics on x + residual, :85-120):
+ *   s = x + residual ; [mean = sum(s)/N] ; var = sum((s - mean)^2)/N  (rms: sum(s^2)/N) ;
+ *   rstd = 1/sqrt(var + eps) ; y = (s - mean) * rstd * w + b   (rms: s * rstd * w + b)
+ * x, residual, y, res_out: (rows, cols); weight, bias: (cols); mean, rstd: (rows).  residual, bias,
+ * res_out, mean may be NULL. */
+void FN(vms_oracle_norm_fwd)(int rows, int cols, const float *x, const float *residual, const float *weight,
+                             const float *bias, float eps, int is_rms, float *y, float *res_out, float *mean,
+                             float *rstd) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; ++r) {
+        const float *xr = x + (size_t)r * cols;
+        const float *rr = residual ? residual + (size_t)r * cols : NULL;
+        real m = 0, v = 0;
+        for (int c = 0; c < cols; ++c) m += (real)xr[c] + (rr ? (real)rr[c] : (real)0);
+        m = is_rms ? (real)0 : m / cols;
+        for (int c = 0; c < cols; ++c) {
+            const real s = (real)xr[c] + (rr ? (real)rr[c] : (real)0) - m;
+            v += s * s;
+        }
+        const real rs = (real)(1.0 / sqrt((double)(v / cols) + (double)eps));
+        for (int c = 0; c < cols; ++c) {
+            const real s = (real)xr[c] + (rr ? (real)rr[c] : (real)0);
+            if (res_out) res_out[(size_t)r * cols + c] = (float)s;
+            y[(size_t)r * cols + c] = (float)((s - m) * rs * (real)weight[c] + (bias ? (real)bias[c] : (real)0));
+        }
+        if (mean) mean[r] = (float)m;
+        rstd[r] = (float)rs;
+    }
+}
+
+/* gradient of the above w.r.t. the pre-norm sum s (= dx = dresidual when both share a dtype), weight and
+ * bias; formulas of _layer_norm_bwd_kernel (layernorm.py:240-288):
+ *   xhat = (s - mean) * rstd ; wdy = w * dy ; c1 = sum(xhat * wdy)/N ; c2 = sum(wdy)/N  (rms: c2 = 0, mean = 0)
+ *   ds = (wdy - (xhat * c1 + c2)) * rstd [+ dres_out] ; dw = sum_rows dy * xhat ; db = sum_rows dy
+ * s: (rows, cols) the saved pre-norm sum; dres_out (gradient of the prenorm output) may be NULL. */
+void FN(vms_oracle_norm_bwd)(int rows, int cols, const float *s, const float *weight, const float *mean,
+                             const float *rstd, const float *dy, const float *dres_out, int is_rms, float *ds,
+                             float *dw, float *db) {
+    real *dwa = (real *)calloc(cols, sizeof(real));
+    real *dba = (real *)calloc(cols, sizeof(real));
+    for (int r = 0; r < rows; ++r) {
+        const float *sr = s + (size_t)r * cols, *dyr = dy + (size_t)r * cols;
+        const real m = (is_rms || !mean) ? (real)0 : (real)mean[r], rs = (real)rstd[r];
+        real c1 = 0, c2 = 0;
+        for (int c = 0; c < cols; ++c) {
+            const real xhat = ((real)sr[c] - m) * rs, wdy = (real)weight[c] * (real)dyr[c];
+            c1 += xhat * wdy;
+            c2 += wdy;
+            dwa[c] += (real)dyr[c] * xhat;
+            dba[c] += (real)dyr[c];
+        }
+        c1 /= cols;
+        c2 = is_rms ? (real)0 : c2 / cols;
+        for (int c = 0; c < cols; ++c) {
+            const real xhat = ((real)sr[c] - m) * rs, wdy = (real)weight[c] * (real)dyr[c];
+            real g = (wdy - (xhat * c1 + c2)) * rs;
+            if (dres_out) g += (real)dres_out[(size_t)r * cols + c];
+            ds[(size_t)r * cols + c] = (float)g;
+        }
+    }
+    for (int c = 0; c < cols; ++c) {
+        dw[c] = (float)dwa[c];
+        if (db) db[c] = (float)dba[c];
+    }
+    free(dwa);
+    free(dba);
+}

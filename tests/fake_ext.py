@@ -62,3 +62,34 @@ def make_fakes(oracle):
     fs = types.SimpleNamespace(fwd=fwd, bwd=bwd)
     fc = types.SimpleNamespace(causal_conv1d_fwd=cfwd, causal_conv1d_bwd=cbwd)
     return fs, fc
+
+
+def make_norm_fake(oracle):
+    """layer_norm_cuda stand-in (same signatures as video-mamba-suite_amd/layer_norm_cuda.py)."""
+    def np_(t):
+        return None if t is None else t.detach().float().cpu().numpy()
+
+    def nfwd(x, weight, bias, eps, residual=None, out_dtype=None, residual_dtype=None, is_rms_norm=False):
+        if residual is not None:
+            residual_dtype = residual.dtype
+        r = oracle.norm_fwd(np_(x), np_(weight), np_(bias), np_(residual), eps, is_rms_norm, prec="f64")
+        y = torch.from_numpy(r["y"]).to(x.dtype)
+        res_out = None
+        if residual is not None or (residual_dtype is not None and residual_dtype != x.dtype):
+            res_out = torch.from_numpy(r["res_out"]).to(residual_dtype)
+        mean = torch.from_numpy(r["mean"]) if not is_rms_norm else None
+        return y, mean, torch.from_numpy(r["rstd"]), res_out
+
+    def nbwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_residual=False, is_rms_norm=False,
+             x_dtype=None):
+        r = oracle.norm_bwd(np_(x), np_(weight), np_(mean), np_(rstd), np_(dy), np_(dresidual), is_rms_norm,
+                            has_bias=bias is not None, prec="f64")
+        dx = torch.from_numpy(r["ds"]).to(x_dtype or x.dtype)
+        dw = torch.from_numpy(r["dw"]).to(weight.dtype)
+        db = torch.from_numpy(r["db"]).to(bias.dtype) if bias is not None else None
+        dres_in = None
+        if has_residual:
+            dres_in = dx if dx.dtype == x.dtype else torch.from_numpy(r["ds"]).to(x.dtype)
+        return dx, dw, db, dres_in
+
+    return types.SimpleNamespace(fwd=nfwd, bwd=nbwd)

@@ -231,8 +231,61 @@ def gen_block(mods, name, which, d_model=32, L=33, batch=2, expand=2, d_state=8,
     save(name, x=npf(x), y=npf(y), g=npf(g), dx=npf(x.grad), **arrs)
 
 
+def load_reference_norm_refs():
+    """layer_norm_ref / rms_norm_ref (mamba/mamba_ssm/ops/triton/layernorm.py:19-48) without importing the
+    module (its top imports triton, absent here): the two pure-PyTorch function definitions are taken out of
+    the reference file's syntax tree and executed as they stand."""
+    import ast
+    path = f"{REF}/mamba/mamba_ssm/ops/triton/layernorm.py"
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("layer_norm_ref", "rms_norm_ref")]
+    assert len(keep) == 2
+    ns = {"torch": torch, "F": F}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["layer_norm_ref"], ns["rms_norm_ref"]
+
+
+def gen_norm(refs, name, shape, is_rms, has_residual, has_bias, prenorm, itype=torch.float32, eps=1e-5, seed=0):
+    """Fused add + norm semantics = the ref with upcast=True (what the reference's kernels compute)."""
+    layer_norm_ref, rms_norm_ref = refs
+    torch.manual_seed(seed)
+    N = shape[-1]
+    x = torch.randn(*shape).to(itype).float().requires_grad_()
+    res = torch.randn(*shape).to(itype).float().requires_grad_() if has_residual else None
+    w = (1 + 0.5 * torch.randn(N)).requires_grad_()
+    b = (0.5 * torch.randn(N)).requires_grad_() if has_bias else None
+    fn = rms_norm_ref if is_rms else layer_norm_ref
+    out = fn(x, w, b, residual=res, eps=eps, prenorm=prenorm, upcast=True)
+    y, pre = (out if prenorm else (out, None))
+    g = torch.randn_like(y)
+    gpre = torch.randn_like(y) if prenorm else None
+    loss = (y * g).sum() + ((pre * gpre).sum() if prenorm else 0)
+    loss.backward()
+    arrs = dict(x=npf(x), weight=npf(w), y=npf(y), g=npf(g), dx=npf(x.grad), dweight=npf(w.grad),
+                is_rms=int(is_rms), prenorm=int(prenorm), eps=eps, itype=str(itype))
+    if has_residual:
+        arrs.update(residual=npf(res), dresidual=npf(res.grad))
+    if has_bias:
+        arrs.update(bias=npf(b), dbias=npf(b.grad))
+    if prenorm:
+        arrs.update(pre=npf(pre), gpre=npf(gpre))
+    save(name, **arrs)
+
+
 def main():
     torch.set_num_threads(8)
+    if os.environ.get("GOLDEN_ONLY") == "norm":  # add the norm fixtures without touching the others
+        refs = load_reference_norm_refs()
+        k = 0
+        for is_rms in (False, True):
+            for shape in ((3, 17, 64), (2, 9, 192), (4, 1000), (2, 5, 1024), (1, 3, 2304)):
+                for has_residual, has_bias, prenorm in ((True, True, True), (False, False, False), (True, False, False)):
+                    k += 1
+                    gen_norm(refs, f"norm_{'rms' if is_rms else 'ln'}_N{shape[-1]}_r{int(has_residual)}b{int(has_bias)}p{int(prenorm)}",
+                             shape, is_rms, has_residual, has_bias, prenorm, seed=k)
+        gen_norm(refs, "norm_rms_bf16_N384", (2, 33, 384), True, True, False, True, itype=torch.bfloat16, seed=99)
+        gen_norm(refs, "norm_ln_bf16_N768", (2, 7, 768), False, True, True, True, itype=torch.bfloat16, seed=98)
+        return
     cci, ssi = load_reference()
     print("scan:")
     gen_scan(ssi, "scan_L128_g1", 2, 4, 8, 128)
@@ -257,6 +310,17 @@ def main():
     for W in (2, 3, 4):
         gen_conv_update(cci, f"convupd_W{W}", 2, 24, W, True, True)
     gen_conv_update(cci, "convupd_W4_plain", 2, 24, 4, False, False)
+    print("norm:")
+    refs = load_reference_norm_refs()
+    k = 0
+    for is_rms in (False, True):
+        for shape in ((3, 17, 64), (2, 9, 192), (4, 1000), (2, 5, 1024), (1, 3, 2304)):
+            for has_residual, has_bias, prenorm in ((True, True, True), (False, False, False), (True, False, False)):
+                k += 1
+                gen_norm(refs, f"norm_{'rms' if is_rms else 'ln'}_N{shape[-1]}_r{int(has_residual)}b{int(has_bias)}p{int(prenorm)}",
+                         shape, is_rms, has_residual, has_bias, prenorm, seed=k)
+    gen_norm(refs, "norm_rms_bf16_N384", (2, 33, 384), True, True, False, True, itype=torch.bfloat16, seed=99)
+    gen_norm(refs, "norm_ln_bf16_N768", (2, 7, 768), False, True, True, True, itype=torch.bfloat16, seed=98)
     print("inner:")
     mods = load_reference_modules(ssi)
     gen_inner(ssi, "inner_out_proj", "out_proj")

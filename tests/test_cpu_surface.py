@@ -119,8 +119,10 @@ def test_conv_update_ref_matches_golden():
 def fake_extensions(monkeypatch, oracle):
     """Replace the two extension modules seen by the interface code by CPU fakes that follow the
     extension ABI (same argument lists / returns) and compute with the C oracle."""
-    from fake_ext import make_fakes
+    from fake_ext import make_fakes, make_norm_fake
     fs, fc = make_fakes(oracle)
+    import mamba_ssm.ops.triton.layernorm as lnm
+    monkeypatch.setattr(lnm, "layer_norm_cuda", make_norm_fake(oracle))
     monkeypatch.setattr(ssi, "selective_scan_cuda", fs)
     monkeypatch.setattr(ssi, "causal_conv1d_cuda", fc)
     import causal_conv1d.causal_conv1d_interface as cci
@@ -187,3 +189,30 @@ def test_block_host_logic(fake_extensions, name, which, kw, fast):
         rg = T(g["grad." + k])
         err = (p.grad - rg).abs().max().item()
         assert err <= 2e-3 * max(1.0, rg.abs().max().item()), (k, err, rg.abs().max().item())
+
+
+# ---- fused add + norm: host logic of LayerNormFn over a checker-backed fake extension ----------------------
+@pytest.mark.parametrize("name", ["norm_ln_N64_r1b1p1", "norm_rms_N192_r0b0p0", "norm_rms_N1000_r1b0p0",
+                                  "norm_ln_N1024_r1b1p1"])
+def test_norm_fn_host_logic(fake_extensions, name):
+    import mamba_ssm.ops.triton.layernorm as lnm
+    g = load_golden(name)
+    x, w = T(g["x"], grad=True), T(g["weight"], grad=True)
+    b = T(g["bias"], grad=True) if "bias" in g else None
+    res = T(g["residual"], grad=True) if "residual" in g else None
+    prenorm = bool(g["prenorm"])
+    fn = lnm.rms_norm_fn if g["is_rms"] else lnm.layer_norm_fn
+    out = fn(x, w, b, residual=res, eps=float(g["eps"]), prenorm=prenorm)
+    y, pre = out if prenorm else (out, None)
+    torch.testing.assert_close(y, T(g["y"]), rtol=2e-4, atol=2e-5)
+    loss = (y * T(g["g"])).sum()
+    if prenorm:
+        torch.testing.assert_close(pre, T(g["pre"]), rtol=2e-4, atol=2e-5)
+        loss = loss + (pre * T(g["gpre"])).sum()
+    loss.backward()
+    torch.testing.assert_close(x.grad, T(g["dx"]), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(w.grad, T(g["dweight"]), rtol=1e-3, atol=1e-3)
+    if b is not None:
+        torch.testing.assert_close(b.grad, T(g["dbias"]), rtol=1e-3, atol=1e-3)
+    if res is not None:
+        torch.testing.assert_close(res.grad, T(g["dresidual"]), rtol=1e-3, atol=1e-4)

@@ -565,3 +565,98 @@ def test_block_bf16_autocast_runs_and_matches_fp32():
     check(y16, y32.detach().float().cpu().numpy(), 3e-2, "autocast output")
     for k, p in m.named_parameters():
         check(p.grad, g32[k].float().cpu().numpy(), 8e-2, "autocast grad " + k)
+
+
+# =================================================================================================
+# fused residual-add + LayerNorm / RMSNorm
+# =================================================================================================
+def _norm_run(g, itype, res_fp32=False):
+    import mamba_ssm.ops.triton.layernorm as lnm
+    x, w = G(g["x"], itype, True), G(g["weight"], grad=True)
+    b = G(g["bias"], grad=True) if "bias" in g else None
+    res = G(g["residual"], torch.float32 if res_fp32 else itype, True) if "residual" in g else None
+    prenorm = bool(g["prenorm"])
+    fn = lnm.rms_norm_fn if g["is_rms"] else lnm.layer_norm_fn
+    out = fn(x, w, b, residual=res, eps=float(g["eps"]), prenorm=prenorm, residual_in_fp32=res_fp32)
+    y, pre = out if prenorm else (out, None)
+    loss = (y.float() * G(g["g"])).sum()
+    if prenorm:
+        loss = loss + (pre.float() * G(g["gpre"])).sum()
+    loss.backward()
+    return dict(y=y, pre=pre, dx=x.grad, dweight=w.grad, dbias=b.grad if b is not None else None,
+                dresidual=res.grad if res is not None else None), (x, w, b, res)
+
+
+@pytest.mark.parametrize("name", golden_names("norm_"))
+def test_norm_vs_oracle_and_golden(oracle, name):
+    """layer_norm_fn / rms_norm_fn through the HIP kernels vs the fixtures produced by the reference's
+    layer_norm_ref / rms_norm_ref (+ autograd) and vs the oracle on the values the kernel saw."""
+    g = load_golden(name)
+    itype = itype_of(g)
+    tol = TOL[itype]
+    got, (x, w, b, res) = _norm_run(g, itype)
+    N = g["x"].shape[-1]
+    rows = g["x"].size // N
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy().reshape(-1, t.shape[-1]) if t.dim() > 1 else t.detach().float().cpu().numpy()
+    o = oracle.norm_fwd(f(x), f(w), f(b), f(res), float(g["eps"]), bool(g["is_rms"]), prec="f64")
+    ob = oracle.norm_bwd(o["res_out"], f(w), o["mean"], o["rstd"], g["g"].reshape(-1, N),
+                         g["gpre"].reshape(-1, N) if "gpre" in g else None, bool(g["is_rms"]), has_bias="bias" in g,
+                         prec="f64")
+    check(got["y"], o["y"].reshape(g["y"].shape), tol, "y vs oracle")
+    check(got["y"], g["y"], tol * 2, "y vs golden")
+    if got["pre"] is not None:
+        check(got["pre"], g["pre"], tol * 2, "prenorm sum vs golden")
+    check(got["dx"], ob["ds"].reshape(g["dx"].shape), tol * 2, "dx vs oracle")
+    check(got["dx"], g["dx"], tol * 4, "dx vs golden")
+    if got["dresidual"] is not None:
+        check(got["dresidual"], g["dresidual"], tol * 4, "dresidual vs golden")
+    check(got["dweight"], ob["dw"], tol * 5, "dweight vs oracle")
+    check(got["dweight"], g["dweight"], tol * 10, "dweight vs golden")
+    if got["dbias"] is not None:
+        check(got["dbias"], ob["db"], tol * 5, "dbias vs oracle")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", [8, 64, 200, 384, 1000, 1024, 2048, 4096, 5000])
+@pytest.mark.parametrize("is_rms", [False, True])
+@pytest.mark.parametrize("mode", ["plain", "residual", "residual_fp32_prenorm", "fp32_prenorm_no_residual"])
+def test_norm_shapes_vs_oracle(oracle, N, itype, is_rms, mode):
+    """Every kernel variant (register-resident 1/2/4/8 pieces, element-wise rows, residual dtypes, prenorm)
+    against the oracle; many more rows than resident waves so the persistent row loop and the dw / db
+    partial rows are exercised."""
+    torch.manual_seed(N)
+    rows = 37 if N >= 2048 else 3000
+    res_fp32 = "fp32" in mode
+    g = dict(x=torch.randn(rows, N).numpy(), weight=(1 + 0.5 * torch.randn(N)).numpy(), bias=(0.5 * torch.randn(N)).numpy(),
+             g=torch.randn(rows, N).numpy(), is_rms=int(is_rms), eps=1e-5, prenorm=int("prenorm" in mode))
+    if "residual" in mode and "no_residual" not in mode:
+        g["residual"] = torch.randn(rows, N).numpy()
+    if g["prenorm"]:
+        g["gpre"] = torch.randn(rows, N).numpy()
+    tol = TOL[itype]
+    got, (x, w, b, res) = _norm_run(g, itype, res_fp32)
+    if res_fp32 and g["prenorm"]:
+        assert got["pre"].dtype == torch.float32
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy()
+    o = oracle.norm_fwd(f(x), f(w), f(b), f(res), 1e-5, is_rms, prec="f64")
+    ob = oracle.norm_bwd(o["res_out"], f(w), o["mean"], o["rstd"], g["g"], g.get("gpre"), is_rms, prec="f64")
+    check(got["y"], o["y"], tol, "y")
+    if got["pre"] is not None:
+        check(got["pre"], o["res_out"], tol, "prenorm sum")
+    check(got["dx"], ob["ds"], tol * 2, "dx")
+    if got["dresidual"] is not None:
+        check(got["dresidual"], ob["ds"], tol * 2, "dresidual")
+    check(got["dweight"], ob["dw"], tol * 5, "dweight")
+    check(got["dbias"], ob["db"], tol * 5, "dbias")
+
+
+def test_norm_extension_errors():
+    import layer_norm_cuda
+    x = torch.randn(4, 64, device=DEV)
+    w = torch.ones(64, device=DEV)
+    with pytest.raises(RuntimeError):  # CPU tensors: no CPU path
+        layer_norm_cuda.fwd(x.cpu(), w.cpu(), None, 1e-5)
+    with pytest.raises(RuntimeError):  # weight shape
+        layer_norm_cuda.fwd(x, torch.ones(32, device=DEV), None, 1e-5)
+    with pytest.raises(RuntimeError):  # feature dim >= 64 KB (layernorm.py:150-153)
+        layer_norm_cuda.fwd(torch.randn(2, 20000, device=DEV), torch.ones(20000, device=DEV), None, 1e-5)

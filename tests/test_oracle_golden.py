@@ -87,3 +87,29 @@ def test_conv_update_oracle_matches_reference(oracle, name):
     out, cs = oracle.conv_update(g["x"], g["conv_state_in"], g["weight"], g.get("bias"), bool(g["silu"]))
     assert np.array_equal(cs, g["conv_state_out"])  # state roll is exact (test_causal_conv1d.py:113)
     close(out, g["out"], 1e-5, 1e-6, "out")
+
+
+@pytest.mark.parametrize("name", golden_names("norm_"))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_norm_oracle_matches_reference(oracle, name, prec):
+    """fused add + LayerNorm / RMSNorm restatement vs layer_norm_ref / rms_norm_ref (layernorm.py:19-48, upcast)
+    and their autograd gradients."""
+    g = load_golden(name)
+    is_rms, N = bool(g["is_rms"]), g["x"].shape[-1]
+    x2 = g["x"].reshape(-1, N)
+    res2 = g["residual"].reshape(-1, N) if "residual" in g else None
+    r = oracle.norm_fwd(x2, g["weight"], g.get("bias"), res2, float(g["eps"]), is_rms, prec=prec)
+    rtol, atol = (2e-2, 2e-2) if "bfloat16" in str(g["itype"]) else (2e-4, 2e-5)
+    close(r["y"].reshape(g["y"].shape), g["y"], rtol, atol, "y")
+    if "pre" in g:
+        close(r["res_out"].reshape(g["pre"].shape), g["pre"], rtol, atol, "prenorm sum")
+    dres = g["gpre"].reshape(-1, N) if "gpre" in g else None
+    b = oracle.norm_bwd(r["res_out"], g["weight"], r["mean"], r["rstd"], g["g"].reshape(-1, N), dres, is_rms,
+                        has_bias="bias" in g, prec=prec)
+    close(b["ds"].reshape(g["dx"].shape), g["dx"], rtol * 5, atol * 20, "dx")
+    if "dresidual" in g:
+        close(b["ds"].reshape(g["dx"].shape), g["dresidual"], rtol * 5, atol * 20, "dresidual")
+    rows = x2.shape[0]
+    close(b["dw"], g["dweight"], rtol * 5, atol * 20 * rows, "dweight")
+    if "bias" in g:
+        close(b["db"], g["dbias"], rtol * 5, atol * 20 * rows, "dbias")

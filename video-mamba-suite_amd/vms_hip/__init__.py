@@ -67,11 +67,31 @@ class ConvBwdParams(ctypes.Structure):
     )
 
 
+class NormParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("rows", "cols", "x_dtype", "res_dtype", "is_rms")] + [("eps", ctypes.c_float)]
+        + [(n, _vp) for n in ("x", "residual", "weight", "bias", "y", "residual_out", "mean", "rstd")]
+        + [(n, _i64) for n in ("x_row_stride", "residual_row_stride", "y_row_stride", "residual_out_row_stride")]
+    )
+
+
+class NormBwdParams(ctypes.Structure):
+    _fields_ = (
+        [("f", NormParams)]
+        + [(n, _vp) for n in ("s", "dy", "dres_out", "dx", "dres_in", "dw_partial", "db_partial")]
+        + [("n_partials", _i32), ("reserved", _i32)]
+        + [(n, _i64) for n in ("s_row_stride", "dy_row_stride", "dres_out_row_stride", "dx_row_stride",
+                               "dres_in_row_stride")]
+    )
+
+
 EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
     "vms_sizeof_scan_bwd_params", "vms_sizeof_conv_fwd_params", "vms_sizeof_conv_bwd_params",
     "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems",
+    "vms_layer_norm_fwd", "vms_layer_norm_bwd", "vms_layer_norm_bwd_partials", "vms_sizeof_norm_params",
+    "vms_sizeof_norm_bwd_params",
 )
 
 _lib = None
@@ -108,7 +128,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
-                         ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams)):
+                         ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
+                         ("norm", NormParams), ("norm_bwd", NormBwdParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -295,3 +316,44 @@ def conv_update(x, conv_state, weight, bias, out, silu):
     P.conv_state = _ptr(conv_state)
     P.conv_state_batch_stride, P.conv_state_c_stride, P.conv_state_l_stride = conv_state.stride()
     _call("vms_causal_conv1d_update", P, x)
+
+
+# ---- fused add + LayerNorm / RMSNorm --------------------------------------------------------------------
+def norm_fwd(x, residual, weight, bias, y, residual_out, mean, rstd, eps, is_rms):
+    """x, y, residual, residual_out: 2-D, unit column stride; weight / bias: fp32 (cols)."""
+    P = NormParams()
+    P.rows, P.cols = x.shape
+    P.x_dtype = dtype_code(x)
+    ref = residual if residual is not None else residual_out
+    P.res_dtype = dtype_code(ref) if ref is not None else P.x_dtype
+    P.is_rms, P.eps = int(bool(is_rms)), float(eps)
+    P.x, P.residual, P.weight, P.bias = _ptr(x), _ptr(residual), _ptr(weight), _ptr(bias)
+    P.y, P.residual_out, P.mean, P.rstd = _ptr(y), _ptr(residual_out), _ptr(mean), _ptr(rstd)
+    P.x_row_stride, P.y_row_stride = x.stride(0), y.stride(0)
+    if residual is not None:
+        P.residual_row_stride = residual.stride(0)
+    if residual_out is not None:
+        P.residual_out_row_stride = residual_out.stride(0)
+    _call("vms_layer_norm_fwd", P, x)
+
+
+def norm_bwd_partials(rows, cols):
+    P = NormParams()
+    P.rows, P.cols = rows, cols
+    return lib().vms_layer_norm_bwd_partials(ctypes.byref(P))
+
+
+def norm_bwd(s, dy, weight, mean, rstd, dres_out, dx, dres_in, dw_partial, db_partial, is_rms):
+    Q = NormBwdParams()
+    Q.f.rows, Q.f.cols = s.shape
+    Q.f.x_dtype, Q.f.res_dtype = dtype_code(dy), dtype_code(s)
+    Q.f.is_rms = int(bool(is_rms))
+    Q.f.weight, Q.f.mean, Q.f.rstd = _ptr(weight), _ptr(mean), _ptr(rstd)
+    Q.s, Q.dy, Q.dres_out, Q.dx, Q.dres_in = _ptr(s), _ptr(dy), _ptr(dres_out), _ptr(dx), _ptr(dres_in)
+    Q.dw_partial, Q.db_partial, Q.n_partials = _ptr(dw_partial), _ptr(db_partial), dw_partial.shape[0]
+    Q.s_row_stride, Q.dy_row_stride, Q.dx_row_stride = s.stride(0), dy.stride(0), dx.stride(0)
+    if dres_out is not None:
+        Q.dres_out_row_stride = dres_out.stride(0)
+    if dres_in is not None:
+        Q.dres_in_row_stride = dres_in.stride(0)
+    _call("vms_layer_norm_bwd", Q, s)
