@@ -46,4 +46,25 @@ def main():
         t = timeit(lambda: causal_conv1d_cuda.causal_conv1d_bwd(u, w, cb, dout, dx, True))
         print(f"conv_bwd  {t*1e3:9.1f} us  {ab['vms_causal_conv1d_bwd']/t/1e6:8.1f} GB/s  {ab['vms_causal_conv1d_bwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
 
-main()
+def norm_bench():
+    import layer_norm_cuda
+    M, N = 8 * 8192, 1024
+    x = torch.randn(M, N, device="cuda", dtype=torch.bfloat16); res = torch.randn(M, N, device="cuda", dtype=torch.float32)
+    w = torch.ones(N, device="cuda"); dy = torch.randn_like(x); dres = torch.randn_like(res)
+    y, mean, rstd, ro = layer_norm_cuda.fwd(x, w, None, 1e-5, res, is_rms_norm=True)
+    t = timeit(lambda: layer_norm_cuda.fwd(x, w, None, 1e-5, res, is_rms_norm=True))
+    by = M * N * (2 + 4 + 2 + 4)
+    print(f"rmsnorm_fwd (bf16 x + fp32 residual -> bf16 y + fp32 sum) {t*1e3:7.1f} us  {by/t/1e6:8.1f} GB/s  {by/t/1e6/8000*100:5.1f}% of 8 TB/s")
+    t = timeit(lambda: layer_norm_cuda.bwd(dy, ro, w, None, 1e-5, mean, rstd, dres, True, True, x_dtype=torch.bfloat16))
+    by = M * N * (4 + 2 + 4 + 2 + 4)
+    print(f"rmsnorm_bwd (fp32 sum, bf16 dy, fp32 dres -> bf16 dx, fp32 dres_in) {t*1e3:7.1f} us  {by/t/1e6:8.1f} GB/s  {by/t/1e6/8000*100:5.1f}% of 8 TB/s")
+    x2 = torch.randn(M, N, device="cuda", dtype=torch.bfloat16)
+    t = timeit(lambda: layer_norm_cuda.fwd(x2, w, w, 1e-5, None, is_rms_norm=False))
+    by = M * N * 4
+    print(f"layernorm_fwd (bf16 -> bf16) {t*1e3:7.1f} us  {by/t/1e6:8.1f} GB/s  {by/t/1e6/8000*100:5.1f}% of 8 TB/s")
+
+
+if "norm" in sys.argv[1:]:
+    norm_bench()
+else:
+    main()
