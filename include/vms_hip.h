@@ -17,6 +17,8 @@
  *        causal-conv1d/csrc/causal_conv1d.cpp:191-268, causal_conv1d_bwd.cu
  *   vms_causal_conv1d_update <- causal_conv1d_cuda.causal_conv1d_update
  *        causal-conv1d/csrc/causal_conv1d.cpp:270-327, causal_conv1d_update.cu
+ *   vms_selective_state_update <- the Triton kernel of mamba_ssm.ops.triton.selective_state_update
+ *        mamba/mamba_ssm/ops/triton/selective_state_update.py:16-154
  *   vms_layer_norm_fwd / _bwd <- the Triton kernels of mamba_ssm.ops.triton.layernorm
  *        mamba/mamba_ssm/ops/triton/layernorm.py:51-377
  *
@@ -207,6 +209,26 @@ int vms_layer_norm_fwd(const vms_norm_params *p, void *stream);
 int vms_layer_norm_bwd(const vms_norm_bwd_params *p, void *stream);
 int vms_layer_norm_bwd_partials(const vms_norm_params *p);
 
+/* ---- single-token SSM step ------------------------------------------------------------------
+ * replaces the Triton kernel behind selective_state_update
+ * (mamba/mamba_ssm/ops/triton/selective_state_update.py:16-154).
+ * state (batch, dim, dstate) in/out; x, dt, z, out (batch, dim) in x_dtype; A (dim, dstate), D, dt_bias
+ * (dim) in w_dtype; B, C (batch, dstate) in bc_dtype; D, z, dt_bias may be NULL. */
+typedef struct {
+    int32_t batch, dim, dstate;
+    int32_t state_dtype, x_dtype, bc_dtype, w_dtype;
+    int32_t dt_softplus;
+    void *state;
+    const void *x, *dt, *A, *B, *C, *D, *z, *dt_bias;
+    void *out;
+    int64_t state_batch_stride, state_d_stride, state_n_stride;
+    int64_t x_batch_stride, x_d_stride, dt_batch_stride, dt_d_stride, z_batch_stride, z_d_stride;
+    int64_t out_batch_stride, out_d_stride;
+    int64_t A_d_stride, A_n_stride, B_batch_stride, B_n_stride, C_batch_stride, C_n_stride;
+} vms_state_update_params;
+
+int vms_selective_state_update(const vms_state_update_params *p, void *stream);
+
 /* ---- misc ---------------------------------------------------------------------------- */
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
@@ -217,6 +239,7 @@ int vms_sizeof_conv_fwd_params(void);
 int vms_sizeof_conv_bwd_params(void);
 int vms_sizeof_norm_params(void);
 int vms_sizeof_norm_bwd_params(void);
+int vms_sizeof_state_update_params(void);
 
 #ifdef __cplusplus
 }

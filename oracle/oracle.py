@@ -176,3 +176,16 @@ def norm_bwd(s, weight, mean, rstd, dy, dres_out=None, is_rms=False, has_bias=Tr
     fn(ctypes.c_int(rows), ctypes.c_int(cols), _p(s), _p(weight), _p(mean), _p(rstd), _p(dy), _p(dres_out),
        ctypes.c_int(bool(is_rms)), _p(ds), _p(dw), _p(db))
     return dict(ds=ds, dw=dw, db=db)
+
+
+def state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplus=False, prec="f32"):
+    """Returns (out, new_state); `state` is not modified in place."""
+    x, dt, A, B, C, D, z, dt_bias = map(_c, (x, dt, A, B, C, D, z, dt_bias))
+    st = np.array(state, dtype=np.float32, order="C", copy=True)
+    batch, dim, N = st.shape
+    out = np.empty_like(x)
+    fn = getattr(lib(), "vms_oracle_state_update_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(N), _p(st), _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D),
+       _p(z), _p(dt_bias), ctypes.c_int(bool(dt_softplus)), _p(out))
+    return out, st

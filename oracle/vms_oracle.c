@@ -403,3 +403,33 @@ void FN(vms_oracle_norm_bwd)(int rows, int cols, const float *s, const float *we
     free(dwa);
     free(dba);
 }
+
+/* ---- single-token SSM step -------------------------------------------------------------------------
+ * selective_state_update_ref (mamba/mamba_ssm/ops/triton/selective_state_update.py:157-192):
+ *   dt = softplus?(dt + dt_bias) ; state = state * exp(dt * A) + dt * B * x ; out = sum_n state * C + D * x ;
+ *   out *= silu(z).   state (batch, dim, N) is updated in place; x, dt, z, out (batch, dim); A (dim, N);
+ *   B, C (batch, N); D, dt_bias (dim).  D, z, dt_bias may be NULL. */
+void FN(vms_oracle_state_update)(int batch, int dim, int N, float *state, const float *x, const float *dt,
+                                 const float *A, const float *B, const float *C, const float *D, const float *z,
+                                 const float *dt_bias, int dt_softplus, float *out) {
+    for (int b = 0; b < batch; ++b)
+        for (int d = 0; d < dim; ++d) {
+            real t = (real)dt[(size_t)b * dim + d] + (dt_bias ? (real)dt_bias[d] : (real)0);
+            if (dt_softplus) t = softplus_ref(t);
+            const real xv = (real)x[(size_t)b * dim + d];
+            float *st = state + ((size_t)b * dim + d) * N;
+            real acc = 0;
+            for (int n = 0; n < N; ++n) {
+                const real s = (real)st[n] * (real)exp((double)(t * (real)A[(size_t)d * N + n])) +
+                               t * (real)B[(size_t)b * N + n] * xv;
+                st[n] = (float)s;
+                acc += (real)st[n] * (real)C[(size_t)b * N + n];
+            }
+            if (D) acc += xv * (real)D[d];
+            if (z) {
+                const real zv = (real)z[(size_t)b * dim + d];
+                acc *= zv * sigmoid_ref(zv);
+            }
+            out[(size_t)b * dim + d] = (float)acc;
+        }
+}

@@ -245,6 +245,35 @@ def load_reference_norm_refs():
     return ns["layer_norm_ref"], ns["rms_norm_ref"]
 
 
+def load_reference_state_update_ref():
+    """selective_state_update_ref (mamba/mamba_ssm/ops/triton/selective_state_update.py:157-192), taken out of
+    the file's syntax tree (the module imports triton at the top)."""
+    import ast
+    from einops import rearrange
+    path = f"{REF}/mamba/mamba_ssm/ops/triton/selective_state_update.py"
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "selective_state_update_ref"]
+    assert len(keep) == 1
+    ns = {"torch": torch, "F": F, "rearrange": rearrange}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns["selective_state_update_ref"]
+
+
+def gen_state_update(ref, name, batch, dim, dstate, has_D, has_z, has_bias, softplus, seed=0):
+    torch.manual_seed(seed)
+    state = torch.randn(batch, dim, dstate)
+    x, dt = torch.randn(batch, dim), 0.5 * torch.rand(batch, dim)
+    A = -0.5 * torch.rand(dim, dstate)
+    B, C = torch.randn(batch, dstate), torch.randn(batch, dstate)
+    D = torch.randn(dim) if has_D else None
+    z = torch.randn(batch, dim) if has_z else None
+    bias = 0.5 * torch.rand(dim) if has_bias else None
+    st = state.clone()
+    out = ref(st, x, dt, A, B, C, D=D, z=z, dt_bias=bias, dt_softplus=softplus)
+    save(name, state_in=npf(state), state_out=npf(st), x=npf(x), dt=npf(dt), A=npf(A), B=npf(B), C=npf(C),
+         D=npf(D), z=npf(z), dt_bias=npf(bias), out=npf(out), softplus=int(softplus))
+
+
 def gen_norm(refs, name, shape, is_rms, has_residual, has_bias, prenorm, itype=torch.float32, eps=1e-5, seed=0):
     """Fused add + norm semantics = the ref with upcast=True (what the reference's kernels compute)."""
     layer_norm_ref, rms_norm_ref = refs
@@ -274,6 +303,13 @@ def gen_norm(refs, name, shape, is_rms, has_residual, has_bias, prenorm, itype=t
 
 def main():
     torch.set_num_threads(8)
+    if os.environ.get("GOLDEN_ONLY") == "ssu":
+        ref = load_reference_state_update_ref()
+        gen_state_update(ref, "ssu_N16_full", 3, 70, 16, True, True, True, True, seed=1)
+        gen_state_update(ref, "ssu_N8_plain", 2, 33, 8, False, False, False, False, seed=2)
+        gen_state_update(ref, "ssu_N64_noz", 2, 40, 64, True, False, True, True, seed=3)
+        gen_state_update(ref, "ssu_N5_odd", 1, 9, 5, True, True, False, False, seed=4)
+        return
     if os.environ.get("GOLDEN_ONLY") == "norm":  # add the norm fixtures without touching the others
         refs = load_reference_norm_refs()
         k = 0
@@ -321,6 +357,12 @@ def main():
                          shape, is_rms, has_residual, has_bias, prenorm, seed=k)
     gen_norm(refs, "norm_rms_bf16_N384", (2, 33, 384), True, True, False, True, itype=torch.bfloat16, seed=99)
     gen_norm(refs, "norm_ln_bf16_N768", (2, 7, 768), False, True, True, True, itype=torch.bfloat16, seed=98)
+    print("state update:")
+    ref = load_reference_state_update_ref()
+    gen_state_update(ref, "ssu_N16_full", 3, 70, 16, True, True, True, True, seed=1)
+    gen_state_update(ref, "ssu_N8_plain", 2, 33, 8, False, False, False, False, seed=2)
+    gen_state_update(ref, "ssu_N64_noz", 2, 40, 64, True, False, True, True, seed=3)
+    gen_state_update(ref, "ssu_N5_odd", 1, 9, 5, True, True, False, False, seed=4)
     print("inner:")
     mods = load_reference_modules(ssi)
     gen_inner(ssi, "inner_out_proj", "out_proj")

@@ -113,3 +113,14 @@ def test_norm_oracle_matches_reference(oracle, name, prec):
     close(b["dw"], g["dweight"], rtol * 5, atol * 20 * rows, "dweight")
     if "bias" in g:
         close(b["db"], g["dbias"], rtol * 5, atol * 20 * rows, "dbias")
+
+
+@pytest.mark.parametrize("name", golden_names("ssu_"))
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_state_update_oracle_matches_reference(oracle, name, prec):
+    """single-token SSM step vs selective_state_update_ref (selective_state_update.py:157-192)."""
+    g = load_golden(name)
+    out, st = oracle.state_update(g["state_in"], g["x"], g["dt"], g["A"], g["B"], g["C"], g.get("D"), g.get("z"),
+                                  g.get("dt_bias"), bool(g["softplus"]), prec=prec)
+    close(out, g["out"], 2e-4, 2e-5, "out")
+    close(st, g["state_out"], 2e-4, 2e-5, "state")

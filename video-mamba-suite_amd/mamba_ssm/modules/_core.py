@@ -25,7 +25,7 @@ from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 from mamba_ssm.ops.selective_scan_interface import (mamba_inner_fn, mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
 from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
-from mamba_ssm.ops.triton.selective_state_update import selective_state_update
+from mamba_ssm.ops.triton.selective_state_update import selective_state_update, selective_state_update_ref
 
 
 # VMS_NO_REVERSE=1: run the backward direction the reference's way (flipped copies through the causal ops)
@@ -236,8 +236,10 @@ class MambaCore(nn.Module):
         dt, B, C = torch.split(x_db, [self.dt_rank, self.d_state, self.d_state], dim=-1)
         dt = F.linear(dt, self.dt_proj.weight)  # bias is added inside the state update
         A = -torch.exp(self.A_log.float())
-        y = selective_state_update(ssm_state, x, dt, A, B, C, self.D, z=z, dt_bias=self.dt_proj.bias,
-                                   dt_softplus=True)
+        # CPU tensors take the reference's pure-PyTorch step (the reference falls back the same way when its
+        # kernel is unavailable, mamba_simple.py:320-332); GPU tensors always run the HIP kernel
+        ssu = selective_state_update if x.is_cuda else selective_state_update_ref
+        y = ssu(ssm_state, x, dt, A, B, C, self.D, z=z, dt_bias=self.dt_proj.bias, dt_softplus=True)
         out = self.out_proj(y)
         return out.unsqueeze(1), conv_state, ssm_state
 

@@ -85,13 +85,24 @@ class NormBwdParams(ctypes.Structure):
     )
 
 
+class StateUpdateParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "dstate", "state_dtype", "x_dtype", "bc_dtype", "w_dtype", "dt_softplus")]
+        + [(n, _vp) for n in ("state", "x", "dt", "A", "B", "C", "D", "z", "dt_bias", "out")]
+        + [(n, _i64) for n in ("state_batch_stride", "state_d_stride", "state_n_stride", "x_batch_stride",
+                               "x_d_stride", "dt_batch_stride", "dt_d_stride", "z_batch_stride", "z_d_stride",
+                               "out_batch_stride", "out_d_stride", "A_d_stride", "A_n_stride", "B_batch_stride",
+                               "B_n_stride", "C_batch_stride", "C_n_stride")]
+    )
+
+
 EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
     "vms_sizeof_scan_bwd_params", "vms_sizeof_conv_fwd_params", "vms_sizeof_conv_bwd_params",
     "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems",
     "vms_layer_norm_fwd", "vms_layer_norm_bwd", "vms_layer_norm_bwd_partials", "vms_sizeof_norm_params",
-    "vms_sizeof_norm_bwd_params",
+    "vms_sizeof_norm_bwd_params", "vms_selective_state_update", "vms_sizeof_state_update_params",
 )
 
 _lib = None
@@ -129,7 +140,7 @@ def lib():
         L.vms_last_error.restype = ctypes.c_char_p
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
-                         ("norm", NormParams), ("norm_bwd", NormBwdParams)):
+                         ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -357,3 +368,23 @@ def norm_bwd(s, dy, weight, mean, rstd, dres_out, dx, dres_in, dw_partial, db_pa
     if dres_in is not None:
         Q.dres_in_row_stride = dres_in.stride(0)
     _call("vms_layer_norm_bwd", Q, s)
+
+
+# ---- single-token SSM step ---------------------------------------------------------------------------------
+def state_update(state, x, dt, A, B, C, D, z, dt_bias, out, dt_softplus):
+    P = StateUpdateParams()
+    P.batch, P.dim, P.dstate = state.shape
+    P.state_dtype, P.x_dtype, P.bc_dtype, P.w_dtype = dtype_code(state), dtype_code(x), dtype_code(B), dtype_code(A)
+    P.dt_softplus = int(bool(dt_softplus))
+    P.state, P.x, P.dt, P.A, P.B, P.C = _ptr(state), _ptr(x), _ptr(dt), _ptr(A), _ptr(B), _ptr(C)
+    P.D, P.z, P.dt_bias, P.out = _ptr(D), _ptr(z), _ptr(dt_bias), _ptr(out)
+    P.state_batch_stride, P.state_d_stride, P.state_n_stride = state.stride()
+    P.x_batch_stride, P.x_d_stride = x.stride()
+    P.dt_batch_stride, P.dt_d_stride = dt.stride()
+    if z is not None:
+        P.z_batch_stride, P.z_d_stride = z.stride()
+    P.out_batch_stride, P.out_d_stride = out.stride()
+    P.A_d_stride, P.A_n_stride = A.stride()
+    P.B_batch_stride, P.B_n_stride = B.stride()
+    P.C_batch_stride, P.C_n_stride = C.stride()
+    _call("vms_selective_state_update", P, x)
