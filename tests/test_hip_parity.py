@@ -340,15 +340,24 @@ def test_scan_extension_error_behaviour():
         selective_scan_cuda.bwd(u2, u2, A, B2, B2, None, None, None, u2, None, None, None, False, False)
 
 
+# BASELINE.json configs at full size: [1] block shape, [2] TimeMamba-B tokens, [3] DBM feature sequence,
+# [4] long-video regime (per-GPU shard)
+FULL_SIZES = {"cfg2_8x1024x8192": (8, 1024, 8192), "cfg3_8x768x3136": (8, 768, 3136),
+              "cfg4_2x512x2304": (2, 512, 2304), "cfg5_1x768x65536": (1, 768, 65536)}
+
+
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
-def test_scan_full_size_rows_vs_oracle(oracle, itype):
-    """BASELINE.json config 2 size (8, 8192, 1024, 16): the oracle cannot run all 8192 rows in
+@pytest.mark.parametrize("cfg", list(FULL_SIZES))
+def test_scan_full_size_rows_vs_oracle(oracle, itype, cfg):
+    """BASELINE.json sizes ((8, 8192, 1024, 16) etc.): the oracle cannot run all rows in
     seconds, but rows are independent given (B, C) -- check a spread of rows fwd and bwd, plus a
     checksum-style property: dB/dC are sums over rows, so they must equal the sum of the
     per-row-block results computed by separate launches on row subsets."""
     from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
     torch.manual_seed(0)
-    b, d, N, L = 8, 1024, 16, 8192
+    (b, d, L), N = FULL_SIZES[cfg], 16
+    if cfg != "cfg2_8x1024x8192" and itype == torch.float32:
+        pytest.skip("fp32 I/O at full size is covered by cfg2")
     u = torch.randn(b, d, L, device=DEV, dtype=itype)
     delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
     z = torch.randn(b, d, L, device=DEV, dtype=itype)
@@ -362,8 +371,8 @@ def test_scan_full_size_rows_vs_oracle(oracle, itype):
     out = selective_scan_fn(u, delta, A, B, C, D, z=z, delta_bias=bias, delta_softplus=True)
     gout = torch.randn_like(out)
     out.backward(gout)
-    rows = [0, 1, 511, 1023]
-    batches = [0, 7]
+    rows = [0, 1, d // 2 - 1, d - 1]
+    batches = sorted({0, b - 1})
     f = lambda t: t.detach().float().cpu().numpy()
     tol = TOL[itype]
     for bi in batches:
