@@ -20,41 +20,36 @@ def _act_flag(activation):
     return activation is not None
 
 
+def _seq_or_channel_major(t):
+    """The kernels take (B, D, L) with a unit stride along L or along D; anything else is compacted."""
+    return t if (t.stride(2) == 1 or t.stride(1) == 1) else t.contiguous()
+
+
 class CausalConv1dFn(torch.autograd.Function):
     """out = act(conv1d_causal_depthwise(x, weight) + bias); x may be (B, D, L) with unit L stride
     or channel-last (unit D stride)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias=None, activation=None):
-        silu = _act_flag(activation)
-        if x.stride(2) != 1 and x.stride(1) != 1:
-            x = x.contiguous()
-        if bias is not None:
-            bias = bias.contiguous()
+        ctx.silu = _act_flag(activation)
+        x = _seq_or_channel_major(x)
+        bias = None if bias is None else bias.contiguous()
         ctx.save_for_backward(x, weight, bias)
-        ctx.activation = silu
-        return causal_conv1d_cuda.causal_conv1d_fwd(x, weight, bias, silu)
+        return causal_conv1d_cuda.causal_conv1d_fwd(x, weight, bias, ctx.silu)
 
     @staticmethod
     def backward(ctx, dout):
         x, weight, bias = ctx.saved_tensors
-        if dout.stride(2) != 1 and dout.stride(1) != 1:
-            dout = dout.contiguous()
-        # dx_ = None: the extension allocates dx (a caller may pre-allocate it to write into a
-        # slice of a larger gradient, as the fused Mamba node does)
-        dx, dweight, dbias = causal_conv1d_cuda.causal_conv1d_bwd(x, weight, bias, dout, None, ctx.activation)
-        return dx, dweight, (dbias if bias is not None else None), None
+        # no pre-allocated dx here (the fused Mamba node passes one to write into a slice of dxz)
+        dx, dweight, dbias = causal_conv1d_cuda.causal_conv1d_bwd(x, weight, bias, _seq_or_channel_major(dout), None,
+                                                                  ctx.silu)
+        return dx, dweight, dbias, None
 
 
 def causal_conv1d_fn(x, weight, bias=None, activation=None):
-    """
-    x: (batch, dim, seqlen)
-    weight: (dim, width)
-    bias: (dim,)
-    activation: either None or "silu" or "swish"
-
-    out: (batch, dim, seqlen)
-    """
+    """Depthwise causal conv1d (+ bias, + SiLU) with autograd.
+    x (batch, dim, seqlen), weight (dim, width), bias (dim,) or None, activation None | "silu" | "swish"
+    -> (batch, dim, seqlen)"""
     return CausalConv1dFn.apply(x, weight, bias, activation)
 
 
@@ -71,29 +66,18 @@ def causal_conv1d_ref(x, weight, bias=None, activation=None):
 
 
 def causal_conv1d_update(x, conv_state, weight, bias=None, activation=None):
-    """
-    x: (batch, dim)
-    conv_state: (batch, dim, width), updated in place
-    weight: (dim, width)
-    bias: (dim,)
-
-    out: (batch, dim)
-    """
+    """Decode step: x (batch, dim), conv_state (batch, dim, width) rolled in place, weight (dim, width),
+    bias (dim,) or None -> (batch, dim)"""
     return causal_conv1d_cuda.causal_conv1d_update(x, conv_state, weight, bias, _act_flag(activation))
 
 
 def causal_conv1d_update_ref(x, conv_state, weight, bias=None, activation=None):
     """Pure-PyTorch decode step: shift the window left by one, append x, dot with the taps."""
     silu = _act_flag(activation)
-    in_dtype = x.dtype
-    batch, dim = x.shape
-    width = weight.shape[1]
-    assert conv_state.shape == (batch, dim, width)
-    assert weight.shape == (dim, width)
-    conv_state.copy_(torch.cat([conv_state[:, :, 1:], x[:, :, None].to(conv_state.dtype)], dim=-1))
-    y = (conv_state * weight).sum(dim=-1)
-    if bias is not None:
-        y = y + bias
-    if silu:
-        y = F.silu(y)
-    return y.to(dtype=in_dtype)
+    if conv_state.shape != (*x.shape, weight.shape[1]) or weight.shape[0] != x.shape[1]:
+        raise ValueError("conv_state must be (batch, dim, width) and weight (dim, width)")
+    window = torch.cat([conv_state[:, :, 1:], x[:, :, None].to(conv_state.dtype)], dim=-1)
+    conv_state.copy_(window)
+    y = (window * weight).sum(dim=-1)
+    y = y if bias is None else y + bias
+    return (F.silu(y) if silu else y).to(dtype=x.dtype)

@@ -42,56 +42,44 @@ def rms_norm_ref(x, weight, bias, residual=None, eps=1e-6, prenorm=False, upcast
     return out if not prenorm else (out, x)
 
 
+def _rows(t):
+    """(..., N) -> (M, N) with a unit column stride (a copy only when the last dim is strided)."""
+    t2 = t.reshape(-1, t.shape[-1])
+    return t2 if t2.stride(-1) == 1 else t2.contiguous()
+
+
 class LayerNormFn(torch.autograd.Function):
-    """Host logic of the reference's LayerNormFn (layernorm.py:380-461) over the HIP kernels."""
+    """Autograd node of the fused add + norm: same inputs, outputs and gradient slots as the reference's
+    LayerNormFn (layernorm.py:380-461); the kernels live in csrc/layer_norm.hip."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False,
                 is_rms_norm=False):
-        x_shape_og = x.shape
-        x = x.reshape(-1, x.shape[-1])
-        if x.stride(-1) != 1:
-            x = x.contiguous()
-        if residual is not None:
-            assert residual.shape == x_shape_og
-            residual = residual.reshape(-1, residual.shape[-1])
-            if residual.stride(-1) != 1:
-                residual = residual.contiguous()
-        weight = weight.contiguous()
-        if bias is not None:
-            bias = bias.contiguous()
-        residual_dtype = residual.dtype if residual is not None else (torch.float32 if residual_in_fp32 else None)
-        y, mean, rstd, residual_out = layer_norm_cuda.fwd(x, weight, bias, eps, residual,
-                                                          residual_dtype=residual_dtype, is_rms_norm=is_rms_norm)
-        if residual_out is None:
-            residual_out = x  # nothing was added and no dtype change: the pre-norm sum is x itself
-        ctx.save_for_backward(residual_out, weight, bias, mean, rstd)
-        ctx.x_shape_og = x_shape_og
-        ctx.eps = eps
-        ctx.is_rms_norm = is_rms_norm
-        ctx.has_residual = residual is not None
-        ctx.prenorm = prenorm
-        ctx.x_dtype = x.dtype
-        y = y.reshape(x_shape_og)
-        return y if not prenorm else (y, residual_out.reshape(x_shape_og))
+        shape = x.shape
+        if residual is not None and residual.shape != shape:
+            raise ValueError("residual must have the shape of x")
+        x2 = _rows(x)
+        res2 = _rows(residual) if residual is not None else None
+        # the pre-norm sum is stored in the residual's dtype, or in fp32 on request when there is no residual
+        sum_dtype = res2.dtype if res2 is not None else (torch.float32 if residual_in_fp32 else None)
+        y2, mean, rstd, presum = layer_norm_cuda.fwd(x2, weight.contiguous(), bias.contiguous() if bias is not None else None,
+                                                     eps, res2, residual_dtype=sum_dtype, is_rms_norm=is_rms_norm)
+        if presum is None:  # nothing added, no dtype change: the sum is x itself
+            presum = x2
+        ctx.save_for_backward(presum, weight, bias, mean, rstd)
+        ctx.meta = (shape, eps, is_rms_norm, residual is not None, prenorm, x2.dtype)
+        y = y2.reshape(shape)
+        return (y, presum.reshape(shape)) if prenorm else y
 
     @staticmethod
-    def backward(ctx, dy, *args):
-        x, weight, bias, mean, rstd = ctx.saved_tensors
-        dy = dy.reshape(-1, dy.shape[-1])
-        if dy.stride(-1) != 1:
-            dy = dy.contiguous()
-        assert dy.shape == x.shape
-        dresidual = None
-        if ctx.prenorm:
-            dresidual = args[0].reshape(-1, args[0].shape[-1])
-            if dresidual.stride(-1) != 1:
-                dresidual = dresidual.contiguous()
-            assert dresidual.shape == x.shape
-        dx, dw, db, dresidual_in = layer_norm_cuda.bwd(dy, x, weight, bias, ctx.eps, mean, rstd, dresidual,
-                                                       ctx.has_residual, ctx.is_rms_norm, x_dtype=ctx.x_dtype)
-        return (dx.reshape(ctx.x_shape_og), dw, db,
-                dresidual_in.reshape(ctx.x_shape_og) if ctx.has_residual else None, None, None, None, None)
+    def backward(ctx, dy, *more):
+        presum, weight, bias, mean, rstd = ctx.saved_tensors
+        shape, eps, is_rms, had_residual, prenorm, x_dtype = ctx.meta
+        dy2 = _rows(dy)
+        dsum = _rows(more[0]) if prenorm else None  # gradient that arrived through the prenorm output
+        dx, dw, db, dres = layer_norm_cuda.bwd(dy2, presum, weight, bias, eps, mean, rstd, dsum, had_residual, is_rms,
+                                               x_dtype=x_dtype)
+        return (dx.reshape(shape), dw, db, dres.reshape(shape) if had_residual else None, None, None, None, None)
 
 
 def layer_norm_fn(x, weight, bias, residual=None, eps=1e-6, prenorm=False, residual_in_fp32=False,
