@@ -43,137 +43,250 @@ __device__ __forceinline__ float silu_grad(float pre) {
     return s * (1.f + pre * (1.f - s));
 }
 
-// ============================ L-contiguous forward ===========================================
-template <typename T, bool SILU, bool VEC>
+// ============================ L-contiguous kernels ===========================================
+// A wave owns NV consecutive strips of 64 * E elements of one (batch, channel) row; a lane owns one
+// 16-byte vector in each.  All NV (forward) / 2 NV (backward) loads of a lane are in flight together --
+// with a single vector per lane a CU holds 32 KB of requests, half of what 8 TB/s x ~2 us needs -- and the
+// strip boundaries inside the wave are crossed with v_readlane instead of memory.
+// DIR selects the addressing: 0 = generic (run-time direction, element-wise tails, any alignment);
+// 1 / 2 = left-to-right / right-to-left over 16-byte aligned rows with seqlen % E == 0, through a buffer
+// resource per row: out-of-range lanes read zeros and their stores are dropped by the bounds check, so
+// the hot path has no predication at all.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBufFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+
+__device__ __forceinline__ float lane_value(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+template <typename T, int DIR>
+struct RowIO {
+    static constexpr int E = 16 / sizeof(T);
+    __amdgpu_buffer_rsrc_t rsrc;
+    int L;
+    __device__ __forceinline__ RowIO(const T* row, int seqlen) : L(seqlen) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(row), 0, seqlen * (int)sizeof(T), kBufFlags);
+    }
+    // byte offset of the vector holding logical elements [l0, l0 + E); negative = out of range
+    __device__ __forceinline__ int voff(int l0) const { return (DIR == 2 ? L - l0 - E : l0) * (int)sizeof(T); }
+    __device__ __forceinline__ void load(int l0, float (&out)[E]) const {
+        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(l0), 0, 0);
+        const vec_t<T, E> t = __builtin_bit_cast(vec_t<T, E>, raw);
+#pragma unroll
+        for (int e = 0; e < E; ++e) out[DIR == 2 ? E - 1 - e : e] = static_cast<float>(t[e]);
+    }
+    __device__ __forceinline__ void store(int l0, const float (&in)[E]) const {
+        vec_t<T, E> t;
+#pragma unroll
+        for (int e = 0; e < E; ++e) t[e] = static_cast<T>(in[DIR == 2 ? E - 1 - e : e]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rsrc, voff(l0), 0, 0);
+    }
+    // one logical element, 0 outside [0, L); lanes with `active` false do not touch memory
+    __device__ __forceinline__ float elem(int l, bool active) const {
+        const int phys = DIR == 2 ? L - 1 - l : l;
+        const int off = active ? phys * (int)sizeof(T) : -1;
+        if constexpr (sizeof(T) == 2) {
+            const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rsrc, off, 0, 0);
+            return static_cast<float>(__builtin_bit_cast(T, h));
+        } else {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, 0, 0));
+        }
+    }
+};
+
+template <typename T, bool VEC>
+struct RowIOGeneric {
+    static constexpr int E = 16 / sizeof(T);
+    T* row;
+    int L;
+    bool rev;
+    __device__ __forceinline__ RowIOGeneric(const T* r, int seqlen, bool reverse) : row(const_cast<T*>(r)), L(seqlen), rev(reverse) {}
+    __device__ __forceinline__ void load(int l0, float (&out)[E]) const { load_dir<T, E, VEC>(row, l0, L, rev, out); }
+    __device__ __forceinline__ void store(int l0, const float (&in)[E]) const { store_dir<T, E, VEC>(row, l0, L, rev, in); }
+    __device__ __forceinline__ float elem(int l, bool active) const {
+        return (active && l >= 0 && l < L) ? static_cast<float>(row[rev ? L - 1 - l : l]) : 0.f;
+    }
+};
+
+template <typename T, bool VEC, int DIR>
+struct RowIOSel { using type = RowIO<T, DIR>; };
+template <typename T, bool VEC>
+struct RowIOSel<T, VEC, 0> { using type = RowIOGeneric<T, VEC>; };
+
+template <typename T, bool VEC, int DIR>
+__device__ __forceinline__ typename RowIOSel<T, VEC, DIR>::type make_row(const T* row, int L, bool rev) {
+    if constexpr (DIR == 0) return RowIOGeneric<T, VEC>(row, L, rev);
+    else return RowIO<T, DIR>(row, L);
+}
+
+template <typename T, bool SILU, bool VEC, int NV, int DIR>
 __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_fwd_params p) {
     constexpr int E = 16 / sizeof(T);
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int c = blockIdx.y, b = blockIdx.z;
     const int L = p.seqlen;
     const bool rev = p.reverse != 0;  // logical position t <-> physical L-1-t (anti-causal filter)
-    const int l0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
-    const T* x = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride;
-    T* out = static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)c * p.out_c_stride;
+    const int base = (blockIdx.x * (kConvThreads / 64) + wave) * (64 * E * NV) + lane * E;
+    const auto x = make_row<T, VEC, DIR>(static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride, L, rev);
+    const auto out = make_row<T, VEC, DIR>(static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)c * p.out_c_stride, L, rev);
     float taps[kTaps], bias;
     load_taps(p, c, taps, bias);
 
-    float xv[E + 3];  // xv[3 + i] = x[l0 + i]; xv[0..2] = x[l0-3 .. l0-1]
-    float cur[E];
-    load_dir<T, E, VEC>(x, l0, L, rev, cur);
+    float xv[NV][E + 3];  // xv[s][3 + i] = x[l0_s + i]; xv[s][0..2] = x[l0_s-3 .. l0_s-1]
 #pragma unroll
-    for (int i = 0; i < E; ++i) xv[3 + i] = cur[i];
-    // halo from the previous lane; the first lane of each wave reads it from memory
+    for (int s = 0; s < NV; ++s) {
+        float cur[E];
+        x.load(base + s * 64 * E, cur);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) xv[2 - j] = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, cur[E - 1 - j]);
-    if (lane == 0) {
+        for (int i = 0; i < E; ++i) xv[s][3 + i] = cur[i];
+    }
+    // halo from the previous lane; lane 0 takes it from lane 63 of the previous strip, or from memory
+    float edge[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) edge[j] = x.elem(base - 1 - j, lane == 0);
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int l = l0 - 1 - j;
-            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
+            const float own = xv[s][3 + E - 1 - j];
+            const float prev = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, own);
+            const float left = s == 0 ? edge[j] : lane_value(xv[s - 1][3 + E - 1 - j], 63);
+            xv[s][2 - j] = lane == 0 ? left : prev;
         }
     }
-    float o[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        float acc = bias;
+    for (int s = 0; s < NV; ++s) {
+        float o[E];
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], xv[i + k], acc);
-        o[i] = SILU ? acc * sigmoidf_(acc) : acc;
+        for (int i = 0; i < E; ++i) {
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], xv[s][i + k], acc);
+            o[i] = SILU ? acc * sigmoidf_(acc) : acc;
+        }
+        out.store(base + s * 64 * E, o);
     }
-    store_dir<T, E, VEC>(out, l0, L, rev, o);
 }
 
-// ============================ L-contiguous backward ==========================================
-template <typename T, bool SILU, bool VEC>
+template <typename T, bool SILU, bool VEC, int NV, int DIR>
 __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_bwd_params q) {
     const vms_conv_fwd_params& p = q.f;
     constexpr int E = 16 / sizeof(T);
+    constexpr int NW = kConvThreads / 64;
+    __shared__ float red[NW][kTaps + 1];
     const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const int c = blockIdx.y, b = blockIdx.z;
     const int L = p.seqlen;
     const bool rev = p.reverse != 0;  // logical position t <-> physical L-1-t (anti-causal filter)
-    const int l0 = (blockIdx.x * kConvThreads + threadIdx.x) * E;
-    const T* x = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride;
-    const T* dout = static_cast<const T*>(q.dout) + (int64_t)b * q.dout_batch_stride + (int64_t)c * q.dout_c_stride;
-    T* dx = static_cast<T*>(q.dx) + (int64_t)b * q.dx_batch_stride + (int64_t)c * q.dx_c_stride;
+    const int base = (blockIdx.x * NW + wave) * (64 * E * NV) + lane * E;
+    const auto x = make_row<T, VEC, DIR>(static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride, L, rev);
+    const auto dout = make_row<T, VEC, DIR>(static_cast<const T*>(q.dout) + (int64_t)b * q.dout_batch_stride + (int64_t)c * q.dout_c_stride, L, rev);
+    const auto dx = make_row<T, VEC, DIR>(static_cast<T*>(q.dx) + (int64_t)b * q.dx_batch_stride + (int64_t)c * q.dx_c_stride, L, rev);
     float taps[kTaps], bias;
     load_taps(p, c, taps, bias);
 
-    float xv[E + 3], cur[E], gc[E], g[E + 3];  // g[i] = dout'[l0 + i], i up to E+2 (right halo)
-    load_dir<T, E, VEC>(x, l0, L, rev, cur);
-    load_dir<T, E, VEC>(dout, l0, L, rev, gc);
+    float xv[NV][E + 3], g[NV][E + 3];  // g[s][i] = dout'[l0_s + i], i up to E+2 (right halo)
 #pragma unroll
-    for (int i = 0; i < E; ++i) { xv[3 + i] = cur[i]; g[i] = gc[i]; }
+    for (int s = 0; s < NV; ++s) {
+        float cur[E], gc[E];
+        x.load(base + s * 64 * E, cur);
+        dout.load(base + s * 64 * E, gc);
 #pragma unroll
-    for (int j = 0; j < 3; ++j) xv[2 - j] = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, cur[E - 1 - j]);
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int l = l0 - 1 - j;
-            xv[2 - j] = (l >= 0 && l < L) ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
-        }
+        for (int i = 0; i < E; ++i) { xv[s][3 + i] = cur[i]; g[s][i] = gc[i]; }
     }
-    if (SILU) {
+    // what precedes the wave's first element (lane 0) and what follows its last (lane 63)
+    const int lend = base + (NV - 1) * 64 * E + E;
+    float edge[3], xr[3], gr[3];
 #pragma unroll
-        for (int i = 0; i < E; ++i) {
-            float pre = bias;
-#pragma unroll
-            for (int k = 0; k < kTaps; ++k) pre = fmaf(taps[k], xv[i + k], pre);
-            g[i] *= silu_grad(pre);
-        }
+    for (int j = 0; j < 3; ++j) {
+        edge[j] = x.elem(base - 1 - j, lane == 0);
+        xr[j] = x.elem(lend + j, lane == 63);
+        gr[j] = dout.elem(lend + j, lane == 63);
     }
-    // right halo dout'[l0+E .. l0+E+2] from the next lane; the last lane recomputes it
 #pragma unroll
-    for (int j = 0; j < 3; ++j) g[E + j] = dpp_mov<DPP_WAVE_SHL1, 0xf>(0.f, g[j]);
-    if (lane == 63) {
-        float xn[6];  // x[l0+E-3 .. l0+E+2]
-#pragma unroll
-        for (int j = 0; j < 3; ++j) xn[j] = cur[E - 3 + j];
+    for (int s = 0; s < NV; ++s) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int l = l0 + E + j;
-            xn[3 + j] = l < L ? static_cast<float>(x[rev ? L - 1 - l : l]) : 0.f;
+            const float own = xv[s][3 + E - 1 - j];
+            const float prev = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, own);
+            const float left = s == 0 ? edge[j] : lane_value(xv[s - 1][3 + E - 1 - j], 63);
+            xv[s][2 - j] = lane == 0 ? left : prev;
         }
+        if (SILU) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int l = l0 + E + j;
-            float go = l < L ? static_cast<float>(dout[rev ? L - 1 - l : l]) : 0.f;
-            if (SILU) {
+            for (int i = 0; i < E; ++i) {
                 float pre = bias;
 #pragma unroll
-                for (int k = 0; k < kTaps; ++k) pre = fmaf(taps[k], xn[j + k], pre);
-                go *= silu_grad(pre);
+                for (int k = 0; k < kTaps; ++k) pre = fmaf(taps[k], xv[s][i + k], pre);
+                g[s][i] *= silu_grad(pre);
             }
-            g[E + j] = go;
         }
     }
-    // dx[l] = sum_k taps[k] * dout'[l + 3 - k]
-    float o[E];
+    if (SILU) {  // dout' of the three positions after the wave (gr = 0 in the other lanes)
+        float xn[6];
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        float acc = 0.f;
+        for (int j = 0; j < 3; ++j) { xn[j] = xv[NV - 1][E + j]; xn[3 + j] = xr[j]; }
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], g[i + 3 - k], acc);
-        o[i] = acc;
+        for (int j = 0; j < 3; ++j) {
+            float pre = bias;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) pre = fmaf(taps[k], xn[j + k], pre);
+            gr[j] *= silu_grad(pre);
+        }
     }
-    store_dir<T, E, VEC>(dx, l0, L, rev, o);
-    // dweight[k] += x[l - 3 + k] * dout'[l] ; dbias += dout'[l]   (own elements only)
+    // right halo dout'[l0_s+E .. l0_s+E+2]: next lane; lane 63 <- lane 0 of the next strip / the values above
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float next = dpp_mov<DPP_WAVE_SHL1, 0xf>(0.f, g[s][j]);
+            const float right = s == NV - 1 ? gr[j] : lane_value(g[s + 1][j], 0);
+            g[s][E + j] = lane == 63 ? right : next;
+        }
+    }
+    // dx[l] = sum_k taps[k] * dout'[l + 3 - k];  dweight[k] += x[l - 3 + k] * dout'[l];  dbias += dout'[l]
     float dw[kTaps] = {0.f, 0.f, 0.f, 0.f}, db = 0.f;
 #pragma unroll
-    for (int i = 0; i < E; ++i) {
-        db += g[i];
+    for (int s = 0; s < NV; ++s) {
+        float o[E];
 #pragma unroll
-        for (int k = 0; k < kTaps; ++k) dw[k] = fmaf(xv[i + k], g[i], dw[k]);
+        for (int i = 0; i < E; ++i) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], g[s][i + 3 - k], acc);
+            o[i] = acc;
+        }
+        dx.store(base + s * 64 * E, o);
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            db += g[s][i];
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) dw[k] = fmaf(xv[s][i + k], g[s][i], dw[k]);
+        }
     }
+    // one wave reduction per tap, the workgroup's waves through LDS, one atomic per (row segment, tap)
 #pragma unroll
     for (int k = 0; k < kTaps; ++k) {
-        const int w = k - (kTaps - p.width);
         const float t = wave_sum(dw[k]);
-        if (lane == 0 && w >= 0) atomicAdd(q.dweight + (int64_t)c * q.dweight_c_stride + (int64_t)w * q.dweight_width_stride, t);
+        if (lane == 0) red[wave][k] = t;
     }
-    if (q.dbias) {
+    {
         const float t = wave_sum(db);
-        if (lane == 0) atomicAdd(q.dbias + c, t);
+        if (lane == 0) red[wave][kTaps] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x <= kTaps) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[w][threadIdx.x];
+        const int wi = (int)threadIdx.x - (kTaps - p.width);
+        if (threadIdx.x == kTaps) {
+            if (q.dbias) atomicAdd(q.dbias + c, t);
+        } else if (wi >= 0) {
+            atomicAdd(q.dweight + (int64_t)c * q.dweight_c_stride + (int64_t)wi * q.dweight_width_stride, t);
+        }
     }
 }
 
@@ -345,11 +458,21 @@ static int conv_fwd_dispatch(const vms_conv_fwd_params& p, hipStream_t s) {
         VMS_CHECK(p.x_l_stride == 1 && p.out_l_stride == 1, "x and out need a unit seqlen stride");
         const bool vec = aligned16(p.x) && aligned16(p.out) && mult16(p.x_batch_stride, es) && mult16(p.x_c_stride, es) &&
                          mult16(p.out_batch_stride, es) && mult16(p.out_c_stride, es);
-        dim3 grid((p.seqlen + kConvThreads * E - 1) / (kConvThreads * E), p.dim, p.batch), block(kConvThreads);
-#define VMS_L(S_, V_) hipLaunchKernelGGL((conv_fwd_kernel<T, S_, V_>), grid, block, 0, s, p)
-        if (p.silu_activation) { if (vec) VMS_L(true, true); else VMS_L(true, false); }
-        else { if (vec) VMS_L(false, true); else VMS_L(false, false); }
+        // 16-byte rows with whole vectors: buffer-addressed kernels, 4 strips per wave when the row is long
+        const bool full = vec && p.seqlen % E == 0 && (int64_t)p.seqlen * es < ((int64_t)1 << 31);
+        const int nv = full && p.seqlen > 64 * E ? 4 : 1;
+        const int per_wg = kConvThreads * E * nv;
+        dim3 grid((p.seqlen + per_wg - 1) / per_wg, p.dim, p.batch), block(kConvThreads);
+#define VMS_K(S_, V_, N_, D_) hipLaunchKernelGGL((conv_fwd_kernel<T, S_, V_, N_, D_>), grid, block, 0, s, p)
+#define VMS_L(S_)                                                                       \
+    do {                                                                                \
+        if (!full) { if (vec) VMS_K(S_, true, 1, 0); else VMS_K(S_, false, 1, 0); }      \
+        else if (nv == 4) { if (p.reverse) VMS_K(S_, true, 4, 2); else VMS_K(S_, true, 4, 1); } \
+        else { if (p.reverse) VMS_K(S_, true, 1, 2); else VMS_K(S_, true, 1, 1); }       \
+    } while (0)
+        if (p.silu_activation) VMS_L(true); else VMS_L(false);
 #undef VMS_L
+#undef VMS_K
     } else {
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
         VMS_CHECK(p.out_c_stride == 1, "channel-last x needs a channel-last out");
@@ -375,11 +498,20 @@ static int conv_bwd_dispatch(const vms_conv_bwd_params& q, hipStream_t s) {
         const bool vec = aligned16(p.x) && aligned16(q.dout) && aligned16(q.dx) && mult16(p.x_batch_stride, es) &&
                          mult16(p.x_c_stride, es) && mult16(q.dout_batch_stride, es) && mult16(q.dout_c_stride, es) &&
                          mult16(q.dx_batch_stride, es) && mult16(q.dx_c_stride, es);
-        dim3 grid((p.seqlen + kConvThreads * E - 1) / (kConvThreads * E), p.dim, p.batch), block(kConvThreads);
-#define VMS_L(S_, V_) hipLaunchKernelGGL((conv_bwd_kernel<T, S_, V_>), grid, block, 0, s, q)
-        if (p.silu_activation) { if (vec) VMS_L(true, true); else VMS_L(true, false); }
-        else { if (vec) VMS_L(false, true); else VMS_L(false, false); }
+        const bool full = vec && p.seqlen % E == 0 && (int64_t)p.seqlen * es < ((int64_t)1 << 31);
+        const int nv = full && p.seqlen > 64 * E ? 4 : 1;
+        const int per_wg = kConvThreads * E * nv;
+        dim3 grid((p.seqlen + per_wg - 1) / per_wg, p.dim, p.batch), block(kConvThreads);
+#define VMS_K(S_, V_, N_, D_) hipLaunchKernelGGL((conv_bwd_kernel<T, S_, V_, N_, D_>), grid, block, 0, s, q)
+#define VMS_L(S_)                                                                       \
+    do {                                                                                \
+        if (!full) { if (vec) VMS_K(S_, true, 1, 0); else VMS_K(S_, false, 1, 0); }      \
+        else if (nv == 4) { if (p.reverse) VMS_K(S_, true, 4, 2); else VMS_K(S_, true, 4, 1); } \
+        else { if (p.reverse) VMS_K(S_, true, 1, 2); else VMS_K(S_, true, 1, 1); }       \
+    } while (0)
+        if (p.silu_activation) VMS_L(true); else VMS_L(false);
 #undef VMS_L
+#undef VMS_K
     } else {
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
         VMS_CHECK(q.dout_c_stride == 1 && q.dx_c_stride == 1, "channel-last x needs channel-last dout and dx");

@@ -343,7 +343,8 @@ def _inner_backward(ctx, dout):
     ddelta_proj_weight = torch.matmul(ddelta, x_dbl[:, :R].transpose(1, 2)).sum(0)      # (d, R)
     dx_dbl[:, :R] = torch.matmul(delta_proj_weight.t(), ddelta)                          # (b, R, l)
     dx_proj_weight = torch.matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0)              # (R+2N, d)
-    dconv_out = torch.baddbmm(dconv_out, x_proj_weight.t().expand(batch, -1, -1), dx_dbl)  # + W_x^T dx_dbl
+    # in place: dconv_out is this node's own buffer (the scan's du); out-of-place baddbmm copies it first
+    dconv_out.baddbmm_(x_proj_weight.t().expand(batch, -1, -1), dx_dbl)                 # + W_x^T dx_dbl
     _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse)
     return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
                 dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
