@@ -6,10 +6,13 @@
 //   * a wave owns 4 rows: lane = 16*r + j, row r = one DPP row, lane j owns the 8 consecutive elements
 //     [8j, 8j+8) of the row's current 128-element chunk; chunks are walked from the end of the sequence;
 //     the forward re-scan and the adjoint suffix scan are 4-step DPP row scans;
-//   * dB / dC are summed over the 4 rows of a wave with v_permlane16_swap / v_permlane32_swap (3 swaps + 3
-//     adds per 4 values; the MFMA route of selective_scan_bwd_mfma.hip makes the backend unpack every
-//     packed op in the MFMA shadow), over the 8 waves of a workgroup through LDS once per 4 states, and
-//     reach memory as one fp32 atomic per 32 rows;
+//   * B / C of a chunk are shared by the 32 rows of a workgroup: they are fetched once per workgroup (one
+//     16-byte vector per thread), widened to fp32 and parked in LDS (double-buffered across chunks); every
+//     lane then reads its 8 + 8 values per state with four ds_read_b128 -- no per-wave widening;
+//   * dB / dC: every lane writes its 8 + 8 products to an LDS slab [state % 2][tensor][row][position];
+//     every second state the workgroup sums the 32 rows (16 ds_read_b64 + 15 v_pk_add per thread, the two
+//     row halves joined by one v_permlane32_swap) and issues ONE fp32 atomic per (state, tensor, position);
+//     this takes the row reduction off the VALU critical path (in-wave permlane trees cost 24 ops per state);
 //   * per-(row, state) carries live in one register (lane j <-> state j), handed out with ds_bpermute.
 // What is new here: everything that is independent across the 8 elements of a lane (exp arguments, b = delta u B,
 // c = C dy, g a x, the du / ddelta / dA / dB / dC contributions) is computed on PAIRS of consecutive elements
@@ -28,16 +31,16 @@ namespace vms {
 constexpr int kBN = 16;   // dstate
 constexpr int kBK = 8;    // elements per lane
 constexpr int kBQ = 8;    // row quads (waves) per workgroup
-constexpr int kPD = 3;    // B / C prefetch distance in states
 constexpr int kBRows = 4 * kBQ;
-#ifndef VMS_BWD_SG
-#define VMS_BWD_SG 8
-#endif
-constexpr int kBSG = VMS_BWD_SG;   // states between two cross-quad reductions
+constexpr int kBSG = 2;            // states between two row reductions
+constexpr int kCH = 16 * kBK;      // elements per row per iteration (128)
+constexpr int kBcFloats = 2 * kBN * kCH;              // [tensor][state][position]
+constexpr int kSlabFloats = kBSG * 2 * kBRows * kCH;  // one pair of states: [state % 2][tensor][row][position]
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f2 lds_f2;
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
 
 template <typename T, bool REV>
 struct RawB {
@@ -90,19 +93,6 @@ __device__ __forceinline__ void row_scan_pair_b(float& pa, float& px, float& ra,
 #undef VMS_STEP
 }
 
-// Sum over the 4 DPP rows of four values at once: v01 = (v0, v1), v23 = (v2, v3) per lane; on return row r of
-// the result holds, in every column, the sum over the wave's 4 rows of value r.  v_permlane16_swap exchanges
-// the odd rows of its first operand with the even rows of its second, v_permlane32_swap the upper half of
-// the first with the lower half of the second (gfx950).  (The clang builtins for these two return the same
-// register twice on ROCm 7.2 -- hence asm.)
-__device__ __forceinline__ float rows_sum4(f2 v01, f2 v23) {
-    float a = v01.x, b = v01.y, c = v23.x, d = v23.y;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-    float p = a + b, q = c + d;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
-    return p + q;
-}
-
 // one v_pk_fma_f32 (the backend splits a <2 x float> fma whose operands were assembled from scalars)
 __device__ __forceinline__ f2 pk_fma_b(f2 a, f2 b, f2 c) {
     f2 r;
@@ -134,8 +124,13 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN;
-    constexpr int CH = 16 * K;   // elements per row per iteration (128)
-    lds_f2* slab = (lds_f2*)smem;  // [quad][state % 4][tensor][64 lanes]
+    constexpr int CH = kCH;      // elements per row per iteration (128)
+    // LDS: fp32 B / C of two chunks, then the dB / dC slab.  A row's 128 positions are stored as
+    // [half][lane j][4]: element i of lane j sits at float (i / 4) * 64 + 4 j + i % 4, so that the 16-byte
+    // accesses of consecutive lanes are consecutive (no bank conflicts).
+    lds_f4* const bc4 = (lds_f4*)smem;
+    lds_f4* const slab4 = (lds_f4*)(smem + kBcFloats);
+    lds_f2* const slab2 = (lds_f2*)(smem + kBcFloats);
     const int lane = threadIdx.x & 63;
     const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, r = lane >> 4;
@@ -174,8 +169,53 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     float dAacc = 0.f;  // dA[d][j]
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    // four named sets: B / C are requested kPD states ahead of their use (explicit software pipeline)
-    RawB<T, REV> rB0, rC0, rB1, rC1, rB2, rC2, rB3, rC3;
+    // B / C staging: thread (tensor, state, j) = (wave >> 2, 4 (wave & 3) + DPP row, lane & 15) fetches the 8
+    // values [8j, 8j+8) of one state of the NEXT chunk while the current one computes
+    RawB<T, REV> stg;
+    const int st_ten = quad >> 2, st_n = (quad & 3) * 4 + r;
+    const T* const st_src = (st_ten ? Cv + (int64_t)st_n * p.C_dstate_stride : Bv + (int64_t)st_n * p.B_dstate_stride);
+    bool st_ok = false;
+    auto stage_issue = [&](int cc) __attribute__((always_inline)) {
+        const int ll = cc * CH + j * K;
+        st_ok = cc >= 0 && ll < L;
+        stg.load(st_src, REV ? L - ll - K : ll, st_ok);
+    };
+    auto stage_commit = [&]() __attribute__((always_inline)) {
+        f32x4 lo, hi;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo[i] = st_ok ? stg.at(i) : 0.f;
+            hi[i] = st_ok ? stg.at(4 + i) : 0.f;
+        }
+        lds_f4* dst = bc4 + ((st_ten * N + st_n) * CH) / 4 + j;
+        dst[0] = lo;
+        dst[16] = hi;
+    };
+    // per-state fp32 B / C of the lane: two register sets (current state, next state)
+    struct BCReg { f32x4 b0, b1, c0, c1; };
+    auto bc_fetch = [&](BCReg& t, int n) __attribute__((always_inline)) {
+        const lds_f4* src = bc4 + (n * CH) / 4 + j;
+        t.b0 = src[0];
+        t.b1 = src[16];
+        t.c0 = src[N * CH / 4];
+        t.c1 = src[N * CH / 4 + 16];
+    };
+    BCReg bcA, bcB;
+    // row reduction of the slab: wave -> (state % 2, tensor, half of the position pairs), lanes 0..31 / 32..63
+    // sum rows 0..15 / 16..31 of one position pair; after the swap lane l < 32 owns float 2m, lane l + 32
+    // float 2m + 1 of the swizzled row
+    const int rd_st = quad >> 2, rd_ten = (quad >> 1) & 1;
+    const int rd_m = (quad & 1) * 32 + (lane & 31);
+    const lds_f2* const rd_src = slab2 + (((rd_st * 2 + rd_ten) * kBRows + (lane >> 5) * 16) * CH) / 2 + rd_m;
+    // the sums of a pair are taken while the NEXT pair computes (slab double-buffered): half of the 16 reads
+    // are issued at the start of each of its two states and consumed at the end of that state
+    f2 rdv[8], racc = f2{0.f, 0.f};
+    float* rd_ptr = nullptr;  // where the pair being summed goes
+    bool rd_okp = false;
+    const int rd_idx = 2 * rd_m + (lane >> 5);
+    const int rd_pos = 8 * ((rd_idx & 63) >> 2) + 4 * (rd_idx >> 6) + (rd_idx & 3);   // position inside the chunk
+    float* const rd_dst = rd_ten ? dCg : dBg;
+    const int64_t rd_stride = rd_ten ? q.dC_dstate_stride : q.dB_dstate_stride;
     // the row's own data of the NEXT chunk is requested while the current one computes
     RawB<T, REV> pu, pdt, pdo, pz, pout;
     float hck_next = 0.f;
@@ -198,20 +238,16 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         hck_next = x_b[xo];
     };
     request_row(n_c - 1);
+    stage_issue(n_c - 1);
+    stage_commit();
+    lds_barrier_b();
+    bc_fetch(bcA, 0);
     for (int c = n_c - 1; c >= 0; --c) {
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
         const uint32_t pl0 = REV ? L - l0 - K : l0;      // physical start of the lane's K elements
-        const bool okn = c > 0;                          // the same lane in the next (= previous-in-sequence) chunk
-        const uint32_t pl0n = REV ? L - (l0 - CH) - K : l0 - CH;
-        if (c == n_c - 1) {  // states 0 .. kPD-1 of the first chunk; later ones arrive through the pipeline
-            rB0.load(Bv, pl0, okb);
-            rC0.load(Cv, pl0, okb);
-            rB1.load(Bv + p.B_dstate_stride, pl0, okb);
-            rC1.load(Cv + p.C_dstate_stride, pl0, okb);
-            rB2.load(Bv + 2 * p.B_dstate_stride, pl0, okb);
-            rC2.load(Cv + 2 * p.C_dstate_stride, pl0, okb);
-        }
+        const int rd_lo = c * CH + rd_pos;
+        float* const rd_dst_c = rd_dst + (REV ? L - 1 - rd_lo : rd_lo);
         float uv[K], dy[K];
         f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2], sg2[K / 2];  // sg = d softplus / d(delta + bias)
         float sdl = 0.f, dl_first = 0.f;
@@ -265,6 +301,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             S2[k] = f2{0.f, 0.f};
         }
         request_row(c - 1);  // in flight during the 16 states of this chunk
+        stage_issue(c - 1);
         // row broadcasts for the first state (later states are prefetched inside the loop)
         float bc_A, bc_h, bc_anx, bc_g;
         {
@@ -278,23 +315,23 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         // One state.  Everything that is independent across the lane's 8 elements runs on ELEMENT PAIRS
         // (v_pk_*): widening products, the gradient contributions; the four recurrences along the elements
         // (forward / adjoint, lane aggregate / seeded) stay scalar chains.
-        auto do_state = [&](const int n, const RawB<T, REV>& cB, const RawB<T, REV>& cC, RawB<T, REV>& nB,
-                            RawB<T, REV>& nC) __attribute__((always_inline)) {
-            {   // B / C of state n + kPD -- past the last one: the first states of the next chunk to the left
-                const int nn = (n + kPD) & (N - 1);
-                const bool wrap = n + kPD >= N;
-                const uint32_t po = wrap ? pl0n : pl0;
-                const bool pok = wrap ? okn : okb;
-                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
-                nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
+        auto do_state = [&](const int n, const int i4, const BCReg& cur, BCReg& nxt) __attribute__((always_inline)) {
+            const int par = i4 & 1, buf = (i4 >> 1) & 1;   // state of the pair, slab buffer of the pair
+            if (n + 1 < N) bc_fetch(nxt, n + 1);          // B / C of the next state
+            {   // rows [8 par, 8 par + 8) of this thread's half of the previous pair
+                const lds_f2* src = rd_src + ((buf ^ 1) * kSlabFloats) / 2 + par * 8 * (CH / 2);
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) rdv[rr] = src[rr * (CH / 2)];
             }
             const float Araw = bc_A, hin = bc_h, anx_n = bc_anx, gin = bc_g;
-            {   // next state's broadcasts (lane n+1 is not touched by this state's carry updates)
+            {   // next state's broadcasts (lane n+1 is not touched by this state's carry updates); issued here,
+                // waited for at the end of the state (asm: the compiler would start the next state early
+                // and wait for them in the middle of this one)
                 const int bnext = ((lane & 48) | ((n + 1) & (N - 1))) << 2;
-                bc_A = row_bcast_b(A_mine, bnext);
-                bc_h = row_bcast_b(hck, bnext);
-                bc_anx = row_bcast_b(anx, bnext);
-                bc_g = row_bcast_b(gcar, bnext);
+                asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\t"
+                             "ds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8"
+                             : "=&v"(bc_A), "=&v"(bc_h), "=&v"(bc_anx), "=&v"(bc_g)
+                             : "v"(bnext), "v"(A_mine), "v"(hck), "v"(anx), "v"(gcar));
             }
             const float An = Araw * kLog2e;
             const f2 An2 = f2{An, An}, Araw2 = f2{Araw, Araw};
@@ -302,11 +339,11 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             // ---- local scans: forward (a, b) and adjoint (alpha = a_{i+1}, c = C dy) ----
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
-                Bn2[k] = f2{cB.at(2 * k), cB.at(2 * k + 1)};
+                Bn2[k] = k == 0 ? f2{cur.b0.x, cur.b0.y} : k == 1 ? f2{cur.b0.z, cur.b0.w} : k == 2 ? f2{cur.b1.x, cur.b1.y} : f2{cur.b1.z, cur.b1.w};
                 const f2 t = dl2[k] * An2;
                 a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
                 xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
-                c2[k] = f2{cC.at(2 * k), cC.at(2 * k + 1)} * dy2[k];
+                c2[k] = (k == 0 ? f2{cur.c0.x, cur.c0.y} : k == 1 ? f2{cur.c0.z, cur.c0.w} : k == 2 ? f2{cur.c1.x, cur.c1.y} : f2{cur.c1.z, cur.c1.w}) * dy2[k];
             }
             float px = 0.f;
 #pragma unroll
@@ -358,43 +395,46 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 dBv[k] = g2 * dlu2[k];
                 dCv[k] = dy2[k] * xs2[k];
             }
-            // dB / dC: sum over the wave's 4 rows.  Element i of the lane ends up, summed, in DPP row i % 4 of
-            // register i / 4: lane (r, j) of {w0, w1} holds the 4-row sums of positions 8j + r and 8j + 4 + r.
-            const f2 wB = f2{rows_sum4(dBv[0], dBv[1]), rows_sum4(dBv[2], dBv[3])};
-            const f2 wC = f2{rows_sum4(dCv[0], dCv[1]), rows_sum4(dCv[2], dCv[3])};
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
-            // 4-row sums of this state -> LDS
-            slab[((quad * kBSG + (n % kBSG)) * 2 + 0) * kWave + lane] = wB;
-            slab[((quad * kBSG + (n % kBSG)) * 2 + 1) * kWave + lane] = wC;
-            if (n % kBSG == kBSG - 1) {
-                lds_barrier_b();
-                // (state, tensor, lane) -> sum over the 8 row quads, 2 atomics each
-#pragma unroll
-                for (int t = threadIdx.x; t < kBSG * 2 * kWave; t += kBQ * kWave) {
-                    const int pl = t & 63, ten = (t >> 6) & 1, st = t >> 7;
-                    f2 s = slab[((0 * kBSG + st) * 2 + ten) * kWave + pl];
-#pragma unroll
-                    for (int qd = 1; qd < kBQ; ++qd) s += slab[((qd * kBSG + st) * 2 + ten) * kWave + pl];
-                    const int nn = n - (kBSG - 1) + st;
-                    const int lo = c * CH + (pl & 15) * K + (pl >> 4);  // logical positions lo and lo + 4
-                    float* dst = ten == 0 ? dBg + (int64_t)nn * q.dB_dstate_stride : dCg + (int64_t)nn * q.dC_dstate_stride;
-                    if (lo < L) {  // seqlen % 8 == 0: a lane's 8 positions are all in or all out
-                        atomicAdd(dst + (REV ? L - 1 - lo : lo), s.x);
-                        atomicAdd(dst + (REV ? L - 1 - (lo + 4) : lo + 4), s.y);
-                    }
-                }
-                lds_barrier_b();
+            // everything requested at the start of the state has arrived by now
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(bc_A), "+v"(bc_h), "+v"(bc_anx), "+v"(bc_g), "+v"(rdv[0]), "+v"(rdv[1]), "+v"(rdv[2]),
+                           "+v"(rdv[3]), "+v"(rdv[4]), "+v"(rdv[5]), "+v"(rdv[6]), "+v"(rdv[7]));
+            {
+                const f2 t = ((rdv[0] + rdv[1]) + (rdv[2] + rdv[3])) + ((rdv[4] + rdv[5]) + (rdv[6] + rdv[7]));
+                racc = par == 0 ? t : racc + t;
+            }
+            // this row's products -> slab[buf][par][tensor][row]
+            {
+                lds_f4* dst = slab4 + (buf * kSlabFloats + ((par * 2 + 0) * kBRows + quad * 4 + r) * CH) / 4 + j;
+                dst[0] = __builtin_shufflevector(dBv[0], dBv[1], 0, 1, 2, 3);
+                dst[16] = __builtin_shufflevector(dBv[2], dBv[3], 0, 1, 2, 3);
+                dst[kBRows * CH / 4] = __builtin_shufflevector(dCv[0], dCv[1], 0, 1, 2, 3);
+                dst[kBRows * CH / 4 + 16] = __builtin_shufflevector(dCv[2], dCv[3], 0, 1, 2, 3);
+            }
+            if (par == 1) {
+                float sx = racc.x, sy = racc.y;
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(sx), "+v"(sy));
+                if (rd_okp) atomicAdd(rd_ptr, sx + sy);
+                // the pair just written is summed during the next one
+                rd_ptr = rd_dst_c + (int64_t)(n - 1 + rd_st) * rd_stride;
+                rd_okp = rd_lo < L;
+                lds_barrier_b();  // pair written by all rows; previous pair's buffer free again
             }
         };
         // rolled (by 4) on purpose: a fully unrolled state loop does not fit the instruction cache
 #pragma unroll 1
         for (int n = 0; n < N; n += 4) {
-            do_state(n, rB0, rC0, rB3, rC3);
-            do_state(n + 1, rB1, rC1, rB0, rC0);
-            do_state(n + 2, rB2, rC2, rB1, rC1);
-            do_state(n + 3, rB3, rC3, rB2, rC2);
+            do_state(n, 0, bcA, bcB);
+            do_state(n + 1, 1, bcB, bcA);
+            do_state(n + 2, 2, bcA, bcB);
+            do_state(n + 3, 3, bcB, bcA);
         }
+        // every wave is past its last B / C read of this chunk (barrier of the last pair): swap in the next chunk's
+        stage_commit();
+        lds_barrier_b();
+        bc_fetch(bcA, 0);
 #undef VMS_EL
         {
             float duv[K], ddl[K];
@@ -413,6 +453,15 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         }
     }
 #undef VMS_OFF
+    {   // the last pair (buffer 1) is still in the slab
+        const lds_f2* src = rd_src + kSlabFloats / 2;
+        f2 t = src[0];
+#pragma unroll
+        for (int rr = 1; rr < 16; ++rr) t += src[rr * (CH / 2)];
+        float sx = t.x, sy = t.y;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(sx), "+v"(sy));
+        if (rd_okp) atomicAdd(rd_ptr, sx + sy);
+    }
     const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
     if (row_ok) {
         if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
@@ -446,7 +495,15 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const vms_scan_fwd_params& p = q.f;
     const int tiles = (p.dim + kBRows - 1) / kBRows;
     dim3 grid(p.batch * tiles), block(kBQ * kWave);
-    const size_t smem = sizeof(float) * 2 * (kBQ * kBSG * 2 * kWave);  // 32 KB
+    const size_t smem = sizeof(float) * (kBcFloats + 2 * kSlabFloats);  // 16 KB + 2 x 64 KB
+    static bool once = false;  // more than the default 64 KB of LDS per workgroup
+    if (!once) {
+        once = true;
+#define VMS_A(Z_, R_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair_kernel<T, Z_, R_>), \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+        VMS_A(true, true); VMS_A(true, false); VMS_A(false, true); VMS_A(false, false);
+#undef VMS_A
+    }
 #define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_>), grid, block, smem, stream, q)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
