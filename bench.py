@@ -121,12 +121,14 @@ def main():
     if distributed:
         model = torch.nn.parallel.DistributedDataParallel(block, device_ids=[local_rank], bucket_cap_mb=32,
                                                           gradient_as_bucket_view=True)
-    hidden = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16)
+    # the block sits inside a network: its input gradient is part of the backward
+    hidden = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16, requires_grad=True)
     # fixed upstream gradient: the step is exactly the block's forward + backward (no loss kernels)
     gout = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16)
 
     def step():
         model.zero_grad(set_to_none=True)
+        hidden.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = model(hidden)
         out.backward(gout)

@@ -216,3 +216,43 @@ def test_norm_fn_host_logic(fake_extensions, name):
         torch.testing.assert_close(b.grad, T(g["dbias"]), rtol=1e-3, atol=1e-3)
     if res is not None:
         torch.testing.assert_close(res.grad, T(g["dresidual"]), rtol=1e-3, atol=1e-4)
+
+
+def test_projection_nodes_match_plain_autograd():
+    """in_proj_fn / out_proj_fn (mamba_ssm/ops/projections.py): same values and gradients as the reference's
+    rearrange(W @ rearrange(x)) (mamba_simple.py:144-149) and out_proj(y^T) left to autograd."""
+    import torch
+    from mamba_ssm.ops.projections import _k_splits, in_proj_fn, out_proj_fn
+    torch.manual_seed(0)
+    B, L, dm, C = 3, 40, 16, 24
+    x = torch.randn(B, L, dm, requires_grad=True)
+    w = torch.randn(C, dm, requires_grad=True)
+    b = torch.randn(C, requires_grad=True)
+    xz = in_proj_fn(x, w, b)
+    ref = (w @ x.reshape(B * L, dm).t()).view(C, B, L).permute(1, 0, 2) + b[:, None]
+    assert xz.shape == (B, C, L) and xz.stride(2) == 1
+    torch.testing.assert_close(xz, ref)
+    g = torch.randn(B, C, L)
+    got = torch.autograd.grad(xz, (x, w, b), g)
+    want = torch.autograd.grad(ref, (x, w, b), g)
+    for a, e in zip(got, want):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+    # a gradient that does not have xz's memory layout takes the copy path
+    got2 = torch.autograd.grad(in_proj_fn(x, w, None), (x, w), g.contiguous())
+    want2 = torch.autograd.grad((w @ x.reshape(B * L, dm).t()).view(C, B, L).permute(1, 0, 2), (x, w), g)
+    for a, e in zip(got2, want2):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+
+    y = torch.randn(B, C, L, requires_grad=True)
+    wo = torch.randn(dm, C, requires_grad=True)
+    bo = torch.randn(dm, requires_grad=True)
+    out = out_proj_fn(y, wo, bo)
+    ref = torch.nn.functional.linear(y.transpose(1, 2), wo, bo)
+    torch.testing.assert_close(out, ref)
+    go = torch.randn(B, L, dm)
+    got = torch.autograd.grad(out, (y, wo, bo), go)
+    want = torch.autograd.grad(ref, (y, wo, bo), go)
+    for a, e in zip(got, want):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+    assert got[0].stride(2) == 1   # (B, C, L) with a unit seqlen stride: what the scan backward reads
+    assert _k_splits(8 * 8192) == 8 and _k_splits(197) == 1 and _k_splits(3 * 8192 + 8192 * 13) == 16

@@ -75,7 +75,6 @@ template <int CTRL>
 __device__ __forceinline__ float bdpp(float old, float src) {
     return dpp_mov<CTRL, 0xf>(old, src);
 }
-constexpr int DPP_B_ROW_BCAST0 = 0x150;  // row_newbcast:0
 constexpr int DPP_B_ROW_ROR = 0x120;
 
 // Forward inclusive scan of (pa, px) and suffix inclusive scan of (ra, rg) inside each 16-lane row,
@@ -106,10 +105,6 @@ __device__ __forceinline__ void lds_barrier_b() {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
-// value of lane (row, n) for a run-time n: byte_index = ((lane & 48) | n) * 4
-__device__ __forceinline__ float row_bcast_b(float v, int byte_index) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_index, __builtin_bit_cast(int, v)));
-}
 __device__ __forceinline__ float row_allsum_b(float v) {
     v += bdpp<DPP_B_ROW_ROR + 1>(0.f, v);
     v += bdpp<DPP_B_ROW_ROR + 2>(0.f, v);
@@ -134,6 +129,11 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     const int lane = threadIdx.x & 63;
     const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, r = lane >> 4;
+    // per (row, state) record {A, state entering the chunk, a of the first element to the right, adjoint
+    // entering from the right}: wave-private, read one state ahead with a single ds_read_b128 (all 16 lanes of
+    // a row read the same address), the two carries rewritten by the row's lane 0 at the end of each state
+    lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kSlabFloats) + (quad * 4 + (lane >> 4)) * kBN;
+    __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
     // consecutive workgroups share a row tile across batches -> batch = blockIdx % batch keeps the
     // B/C of one batch on one XCD's L2 when batch == 8
     const int b = blockIdx.x % p.batch;
@@ -164,8 +164,6 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     // A of the lane's row: lane j keeps A[d][j]; handed out per state by a row broadcast
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
 
-    float gcar = 0.f;   // adjoint entering this chunk from the right, state n = j
-    float anx = 1.f;    // a of the first element of the chunk to the right, state n = j
     float dAacc = 0.f;  // dA[d][j]
     float dD_acc = 0.f, dbias_acc = 0.f;
 
@@ -240,8 +238,11 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     request_row(n_c - 1);
     stage_issue(n_c - 1);
     stage_commit();
+    rec4[j] = f32x4{A_mine, n_c > 1 ? hck_next : 0.f, 1.f, 0.f};   // lane j <-> state j
     lds_barrier_b();
     bc_fetch(bcA, 0);
+    f32x4 bc = rec4[0];   // record of the state about to run
+    const bool is_first = j == 0, is_last = j == 15;
     for (int c = n_c - 1; c >= 0; --c) {
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
@@ -270,7 +271,6 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             sdl += t;
             if (i == 0) dl_first = t;
         }
-        const float hck = c > 0 ? hck_next : 0.f;
         if (HZ) {
             float zv[K], ov[K], dzv[K];
 #pragma unroll
@@ -302,15 +302,6 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         }
         request_row(c - 1);  // in flight during the 16 states of this chunk
         stage_issue(c - 1);
-        // row broadcasts for the first state (later states are prefetched inside the loop)
-        float bc_A, bc_h, bc_anx, bc_g;
-        {
-            const int b0 = (lane & 48) << 2;
-            bc_A = row_bcast_b(A_mine, b0);
-            bc_h = row_bcast_b(hck, b0);
-            bc_anx = row_bcast_b(anx, b0);
-            bc_g = row_bcast_b(gcar, b0);
-        }
 #define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
         // One state.  Everything that is independent across the lane's 8 elements runs on ELEMENT PAIRS
         // (v_pk_*): widening products, the gradient contributions; the four recurrences along the elements
@@ -323,16 +314,11 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 #pragma unroll
                 for (int rr = 0; rr < 8; ++rr) rdv[rr] = src[rr * (CH / 2)];
             }
-            const float Araw = bc_A, hin = bc_h, anx_n = bc_anx, gin = bc_g;
-            {   // next state's broadcasts (lane n+1 is not touched by this state's carry updates); issued here,
-                // waited for at the end of the state (asm: the compiler would start the next state early
-                // and wait for them in the middle of this one)
-                const int bnext = ((lane & 48) | ((n + 1) & (N - 1))) << 2;
-                asm volatile("ds_bpermute_b32 %0, %4, %5\n\tds_bpermute_b32 %1, %4, %6\n\t"
-                             "ds_bpermute_b32 %2, %4, %7\n\tds_bpermute_b32 %3, %4, %8"
-                             : "=&v"(bc_A), "=&v"(bc_h), "=&v"(bc_anx), "=&v"(bc_g)
-                             : "v"(bnext), "v"(A_mine), "v"(hck), "v"(anx), "v"(gcar));
-            }
+            const float Araw = bc.x, hin = bc.y, anx_n = bc.z, gin = bc.w;
+            // the next state's record (waited for at the end of this state, see the anchor below); before the
+            // last state's read, lane j stores the state entering the NEXT chunk for state j
+            if (i4 == 3 && n == N - 1) rec1[4 * j + 1] = c > 1 ? hck_next : 0.f;
+            bc = rec4[(n + 1) & (N - 1)];
             const float An = Araw * kLog2e;
             const f2 An2 = f2{An, An}, Araw2 = f2{Araw, Araw};
             f2 Bn2[K / 2], c2[K / 2], a2[K / 2], xs2[K / 2], ax2[K / 2];
@@ -354,17 +340,14 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 #pragma unroll
             for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
             float ra = fast_exp2((sdl - dl_first) * An) * a_right;
+            // the carries enter at the end lanes, so that the inclusive scans deliver the true states / adjoints
+            px = fmaf(pa, is_first ? hin : 0.f, px);
+            rg = fmaf(ra, is_last ? gin : 0.f, rg);
             row_scan_pair_b(pa, px, ra, rg);
-            const float ea = bdpp<DPP_ROW_SHR1>(1.f, pa);
-            const float ex = bdpp<DPP_ROW_SHR1>(0.f, px);
-            const float xseed = fmaf(ea, hin, ex);  // state entering this lane's first element
-            const float esa = bdpp<DPP_ROW_SHL1>(1.f, ra);
-            const float esx = bdpp<DPP_ROW_SHL1>(0.f, rg);
-            float grun = fmaf(esa, gin, esx);
-            // new carries = values at the row's lane 0
-            const float gout = bdpp<DPP_B_ROW_BCAST0>(0.f, fmaf(ra, gin, rg));
-            const float afirst = bdpp<DPP_B_ROW_BCAST0>(0.f, a2[0].x);
-            if (j == n) { gcar = gout; anx = afirst; }
+            const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);  // state entering this lane's first element
+            float grun = bdpp<DPP_ROW_SHL1>(gin, rg);         // adjoint entering this lane's last element
+            // new carries = lane 0's a of its first element and the adjoint leaving it
+            if (is_first) *(lds_f2*)(rec1 + 4 * n + 2) = f2{a2[0].x, rg};
             // forward pass B: a_i x_{i-1} and x_i (xs2 holds b_i on entry)
             {
                 float xrun = xseed;
@@ -398,8 +381,8 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
             // everything requested at the start of the state has arrived by now
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(bc_A), "+v"(bc_h), "+v"(bc_anx), "+v"(bc_g), "+v"(rdv[0]), "+v"(rdv[1]), "+v"(rdv[2]),
+            asm volatile(""
+                         : "+v"(bc), "+v"(rdv[0]), "+v"(rdv[1]), "+v"(rdv[2]),
                            "+v"(rdv[3]), "+v"(rdv[4]), "+v"(rdv[5]), "+v"(rdv[6]), "+v"(rdv[7]));
             {
                 const f2 t = ((rdv[0] + rdv[1]) + (rdv[2] + rdv[3])) + ((rdv[4] + rdv[5]) + (rdv[6] + rdv[7]));
@@ -495,7 +478,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const vms_scan_fwd_params& p = q.f;
     const int tiles = (p.dim + kBRows - 1) / kBRows;
     dim3 grid(p.batch * tiles), block(kBQ * kWave);
-    const size_t smem = sizeof(float) * (kBcFloats + 2 * kSlabFloats);  // 16 KB + 2 x 64 KB
+    const size_t smem = sizeof(float) * (kBcFloats + 2 * kSlabFloats + kBRows * kBN * 4);  // 16 KB + 2 x 64 KB + 8 KB
     static bool once = false;  // more than the default 64 KB of LDS per workgroup
     if (!once) {
         once = true;

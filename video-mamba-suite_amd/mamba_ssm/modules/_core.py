@@ -24,6 +24,7 @@ from torch import Tensor
 from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
 from mamba_ssm.ops.selective_scan_interface import (mamba_inner_fn, mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
+from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
 from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from mamba_ssm.ops.triton.selective_state_update import selective_state_update, selective_state_update_ref
 
@@ -109,12 +110,7 @@ class MambaCore(nn.Module):
     # ---- pieces ---------------------------------------------------------------------------------
     def _in_projection(self, hidden_states):
         """(B, L, d_model) -> xz (B, C, L): GEMM and BLH->HBL transpose in one step."""
-        batch, seqlen, _ = hidden_states.shape
-        w = self.in_proj.weight
-        xz = (w @ hidden_states.reshape(batch * seqlen, -1).t()).view(w.shape[0], batch, seqlen).permute(1, 0, 2)
-        if self.in_proj.bias is not None:
-            xz = xz + self.in_proj.bias.to(dtype=xz.dtype)[:, None]
-        return xz
+        return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
 
     def python_mamba_inner_fn_no_out_proj(self, xz, A, conv_state, ssm_state, seqlen, conv1d, x_proj, dt_proj, D,
                                           use_pytorch_conv=False):
@@ -152,10 +148,12 @@ class MambaCore(nn.Module):
 
     def _merge_and_project(self, out, out_b):
         """out_b: the backward direction's output, already in the original sequence order."""
-        y = (out + out_b).transpose(1, 2)  # (B, L, d_inner)
+        y = out + out_b  # (B, d_inner, L)
         if self.if_devide_out:
-            y = self.norm(y) if self.variant == "vim_norm" else y / 2
-        return F.linear(y, self.out_proj.weight, self.out_proj.bias)
+            if self.variant == "vim_norm":
+                return F.linear(self.norm(y.transpose(1, 2)), self.out_proj.weight, self.out_proj.bias)
+            y = y / 2
+        return out_proj_fn(y, self.out_proj.weight, self.out_proj.bias)
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, hidden_states, inference_params=None):
@@ -208,7 +206,7 @@ class MambaCore(nn.Module):
             # (the reference stacks the flipped half on the batch axis, mamba_new.py:192-213)
             out_f = self._direction(xz_f, "")
             out_b = self._direction(xz_b, "", reverse=True)
-            y = torch.cat([out_f, out_b], dim=1).transpose(1, 2)  # (B, L, 2*d_inner)
+            return out_proj_fn(torch.cat([out_f, out_b], dim=1), self.out_proj.weight, self.out_proj.bias)
         else:
             # the reversed sequence rides along as extra batch entries: one fused call, shared weights
             stacked = torch.cat([xz_f, xz_b.flip([-1])], dim=0)
