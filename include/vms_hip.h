@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 2
+#define VMS_ABI_VERSION 3
 
 typedef enum {
     VMS_OK = 0,
@@ -124,6 +124,10 @@ typedef struct {
     int64_t dA_d_stride, dA_dstate_stride;
     int64_t dB_batch_stride, dB_group_stride, dB_d_stride, dB_dstate_stride;
     int64_t dC_batch_stride, dC_group_stride, dC_d_stride, dC_dstate_stride;
+    /* dz_accumulate != 0 (an extension): dz += instead of dz = ; the caller's dz already holds the gradient
+     * that reached z by another path (the other direction of a bidirectional block).  32-bit pad follows. */
+    int32_t dz_accumulate;
+    int32_t reserved0;
 } vms_scan_bwd_params;
 
 int vms_selective_scan_fwd(const vms_scan_fwd_params *p, void *stream);
@@ -167,6 +171,9 @@ typedef struct {
     int64_t dout_batch_stride, dout_c_stride, dout_l_stride;
     int64_t dx_batch_stride, dx_c_stride, dx_l_stride;
     int64_t dweight_c_stride, dweight_width_stride;
+    /* dx_accumulate != 0 (an extension): dx += instead of dx = (see dz_accumulate) */
+    int32_t dx_accumulate;
+    int32_t reserved0;
 } vms_conv_bwd_params;
 
 int vms_causal_conv1d_fwd(const vms_conv_fwd_params *p, void *stream);

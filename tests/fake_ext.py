@@ -29,7 +29,7 @@ def make_fakes(oracle):
         return res
 
     def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
-            reverse=False):
+            reverse=False, zeroed=None, keep_fp32=False, accumulate_dz=False):  # the scratch is the real shim's business
         rv = reverse
         r = oracle.scan_bwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
                             np_(delta_bias_), np_(dout, rv), delta_softplus, prec="f64")
@@ -41,7 +41,10 @@ def make_fakes(oracle):
                tt(r["ddelta_bias"], delta_bias_) if delta_bias_ is not None else None]
         if z_ is not None:
             dz = dz_ if dz_ is not None else torch.empty_like(z_)
-            dz.copy_(tt(r["dz"], z_))
+            if accumulate_dz:
+                dz.add_(tt(r["dz"], z_))
+            else:
+                dz.copy_(tt(r["dz"], z_))
             res.append(dz)
         if recompute_out_z:
             f = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
@@ -52,14 +55,21 @@ def make_fakes(oracle):
     def cfwd(x, w, b, silu, reverse=False):
         return torch.from_numpy(un(oracle.conv_fwd(np_(x, reverse), np_(w), np_(b), silu, prec="f64"), reverse)).to(x.dtype)
 
-    def cbwd(x, w, b, dout, dx_, silu, reverse=False):
+    def cbwd(x, w, b, dout, dx_, silu, reverse=False, zeroed=None, accumulate_dx=False):
         r = oracle.conv_bwd(np_(x, reverse), np_(w), np_(b), np_(dout, reverse), silu, prec="f64")
         dx = dx_ if dx_ is not None else torch.empty_like(x)
-        dx.copy_(torch.from_numpy(un(r["dx"], reverse)))
+        if accumulate_dx:
+            dx.add_(torch.from_numpy(un(r["dx"], reverse)).to(dx.dtype))
+        else:
+            dx.copy_(torch.from_numpy(un(r["dx"], reverse)))
         return [dx, torch.from_numpy(r["dweight"]), torch.from_numpy(r["dbias"]) if b is not None else None]
 
 
-    fs = types.SimpleNamespace(fwd=fwd, bwd=bwd)
+    def n_acc(A, B, C, D_, delta_bias_):
+        return A.numel() + B.numel() + C.numel() + (D_.numel() if D_ is not None else 0) + (
+            delta_bias_.numel() if delta_bias_ is not None else 0)
+
+    fs = types.SimpleNamespace(fwd=fwd, bwd=bwd, bwd_accumulator_elems=n_acc)
     fc = types.SimpleNamespace(causal_conv1d_fwd=cfwd, causal_conv1d_bwd=cbwd)
     return fs, fc
 

@@ -252,6 +252,96 @@ def test_conv_reverse_equals_flipped(seqlen, width, itype):
     check(db_r, db_f.cpu().numpy(), 1e-4, "dbias")
 
 
+@pytest.mark.parametrize("impl", ["pair", "fast", "generic"])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_scan_bwd_accumulates_dz(itype, impl, reverse, monkeypatch):
+    """accumulate_dz (vms_hip.h dz_accumulate): dz += this call's gradient, in every backward kernel."""
+    import selective_scan_cuda
+    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    g = _rows_problem((2, 64, 1160, 1), itype, True, seed=11)
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
+                                        f("D", torch.float32), f("z"), f("delta_bias", torch.float32), f("g"))
+    out, x, _ = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
+    plain = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse)
+    start = torch.randn_like(z)
+    dz = start.clone()
+    acc = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, dz, True, False, reverse,
+                                  accumulate_dz=True)
+    assert acc[7].data_ptr() == dz.data_ptr()
+    want = (start.float() + plain[7].float()).cpu().numpy()
+    check(dz, want, 1e-6 if itype == torch.float32 else 1e-2, "dz accumulated")
+    for name, a, b_ in zip(("du", "ddelta"), acc, plain):
+        assert torch.equal(a, b_), name
+    with pytest.raises(RuntimeError):
+        selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse, accumulate_dz=True)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["seq", "seq_ragged", "channel_last"])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_conv_bwd_accumulates_dx(layout, itype, reverse):
+    """accumulate_dx (vms_hip.h dx_accumulate): dx += this call's gradient (buffer-addressed, generic and
+    channel-last kernels)."""
+    import causal_conv1d_cuda
+    if layout == "channel_last" and reverse:
+        pytest.skip("reverse needs the seqlen-contiguous layout")
+    torch.manual_seed(3)
+    b, d, L = 2, 48, 1134 if layout == "seq_ragged" else 1136
+    mk = lambda: torch.randn(b, d, L, device=DEV).to(itype)
+    x, dout, start = mk(), mk(), mk()
+    if layout == "channel_last":
+        cl = lambda t: t.transpose(1, 2).contiguous().transpose(1, 2)
+        x, dout, start = cl(x), cl(dout), cl(start)
+    w, bias = torch.randn(d, 4, device=DEV), torch.randn(d, device=DEV)
+    plain = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, None, True, reverse)
+    dx = start.clone()  # keeps start's (possibly channel-last) strides
+    acc = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, dx, True, reverse, accumulate_dx=True)
+    assert acc[0].data_ptr() == dx.data_ptr()
+    want = (start.float() + plain[0].float()).cpu().numpy()
+    check(dx, want, 1e-6 if itype == torch.float32 else 1e-2, "dx accumulated")
+    check(acc[1], plain[1].cpu().numpy(), 1e-5, "dweight")
+    with pytest.raises(RuntimeError):
+        causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, None, True, reverse, accumulate_dx=True)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+def test_bidirectional_node_equals_two_nodes(itype):
+    """BiMambaInnerFnNoOutProj (one node, dx / dz accumulated by the kernels) == the sum of a left-to-right and a
+    right-to-left MambaInnerFnNoOutProj, values and every gradient."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    torch.manual_seed(5)
+    b, d, L, n, R = 2, 64, 1100 if itype == torch.float32 else 1104, 16, 4
+
+    def params():
+        return [torch.randn(d, 1, 4, device=DEV) * 0.3, torch.randn(d, device=DEV) * 0.1,
+                torch.randn(R + 2 * n, d, device=DEV) * 0.1, torch.randn(d, R, device=DEV) * 0.3,
+                -torch.rand(d, n, device=DEV) - 0.5, torch.randn(d, device=DEV), torch.randn(d, device=DEV) * 0.1]
+    pf, pb = params(), params()
+    xz0 = (torch.randn(b, 2 * d, L, device=DEV) * 0.5).to(itype)
+    gout = torch.randn(b, d, L, device=DEV).to(itype)
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_() for t in [xz0] + pf + pb]
+        xz, f, bk = leaves[0], leaves[1:8], leaves[8:]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=itype == torch.bfloat16):
+            if fused:
+                out = ssi.bimamba_inner_fn_no_out_proj(xz, tuple(f), tuple(bk))
+            else:
+                one = lambda q, rev: ssi.mamba_inner_fn_no_out_proj(xz, q[0], q[1], q[2], q[3], q[4], None, None, q[5],
+                                                                    delta_bias=q[6], delta_softplus=True, reverse=rev)
+                out = one(f, False) + one(bk, True)
+        out.backward(gout)
+        return out, [t.grad for t in leaves]
+    out_a, g_a = run(True)
+    out_b, g_b = run(False)
+    tol = 1e-5 if itype == torch.float32 else 2e-2
+    check(out_a, out_b.float().detach().cpu().numpy(), tol, "out")
+    for i, (a, b_) in enumerate(zip(g_a, g_b)):
+        check(a, b_.float().cpu().numpy(), tol * (1 if i == 0 else 5), f"grad {i}")
+
+
 def test_scan_rows_checkpoint_region(oracle, monkeypatch):
     """x returned by the rows forward: reference-shaped slots plus the chunk-start states that follow them
     in the same allocation (include/vms_hip.h, x_has_sub == 2)."""

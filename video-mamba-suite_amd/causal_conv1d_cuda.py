@@ -44,7 +44,7 @@ def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
     return out
 
 
-def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False):
+def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False, zeroed=None, accumulate_dx=False):
     """-> [dx, dweight, dbias]   (causal_conv1d.cpp:191-268)"""
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
@@ -66,9 +66,17 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=Fals
         dx = torch.empty_like(x)
         if channel_last and dx.stride(1) != 1:
             dx = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=x.dtype, device=x.device).transpose(1, 2)
-    dweight = torch.zeros_like(weight, dtype=torch.float32)
-    dbias = torch.zeros_like(bias_, dtype=torch.float32) if bias_ is not None else None
-    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation, reverse)
+    if zeroed is not None:  # extension: the caller's zero fp32 scratch holds the two atomics targets
+        nw, nb = weight.numel(), bias_.numel() if bias_ is not None else 0
+        _check(zeroed.dtype == torch.float32 and zeroed.is_cuda and zeroed.dim() == 1 and zeroed.is_contiguous()
+               and zeroed.numel() >= nw + nb, "zeroed must be a flat float32 tensor of weight.numel() + bias.numel() elements")
+        dweight = zeroed[:nw].view(weight.shape)
+        dbias = zeroed[nw:nw + nb] if bias_ is not None else None
+    else:
+        dweight = torch.zeros_like(weight, dtype=torch.float32)
+        dbias = torch.zeros_like(bias_, dtype=torch.float32) if bias_ is not None else None
+    _check(not accumulate_dx or dx_ is not None, "accumulate_dx needs the dx tensor to add to")
+    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation, reverse, bool(accumulate_dx))
     return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]
 
 

@@ -258,6 +258,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
             for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], g[s][i + 3 - k], acc);
             o[i] = acc;
         }
+        if (q.dx_accumulate) {  // dx += (vms_hip.h): the other direction's gradient is already there
+            float old[E];
+            dx.load(base + s * 64 * E, old);
+#pragma unroll
+            for (int i = 0; i < E; ++i) o[i] += old[i];
+        }
         dx.store(base + s * 64 * E, o);
 #pragma unroll
         for (int i = 0; i < E; ++i) {
@@ -405,6 +411,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_cl_bwd_kernel(const vms_con
 #pragma unroll
                 for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[e][k], gw[3 - k][e], acc);
                 o[e] = static_cast<T>(acc);
+            }
+            if (q.dx_accumulate) {
+                const V old = *reinterpret_cast<const V*>(dx + (int64_t)l * q.dx_l_stride);
+#pragma unroll
+                for (int e = 0; e < E; ++e) o[e] = static_cast<T>(static_cast<float>(o[e]) + static_cast<float>(old[e]));
             }
             *reinterpret_cast<V*>(dx + (int64_t)l * q.dx_l_stride) = o;
         }

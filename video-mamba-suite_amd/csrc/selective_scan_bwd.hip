@@ -123,6 +123,12 @@ __global__ __launch_bounds__(kBwdRows* kWave) void scan_bwd_kernel(const vms_sca
                 dy[i] *= silu;
                 ov[i] *= silu;
             }
+            if (q.dz_accumulate) {  // dz += (vms_hip.h)
+                float old[K];
+                load_dir<T, K, VEC>(dz, l0, Lr, rev, old);
+#pragma unroll
+                for (int i = 0; i < K; ++i) dzv[i] += old[i];
+            }
             store_dir<T, K, VEC>(dz, l0, Lr, rev, dzv);
             if (out_z) store_dir<T, K, VEC>(out_z, l0, Lr, rev, ov);
         }

@@ -217,6 +217,12 @@ __global__ __launch_bounds__(kMQ* NSPLIT* kWave) void scan_bwd_mfma_kernel(const
                 ov[i] *= silu;
             }
             if (ok && half == 0) {
+                if (q.dz_accumulate) {  // dz += (vms_hip.h)
+                    float old[K];
+                    load_blocked<T, K, true>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + l0), K, old);
+#pragma unroll
+                    for (int i = 0; i < K; ++i) dzv[i] += old[i];
+                }
                 store_blocked<T, K, true>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + l0), K, dzv);
                 if (out_z_b) store_blocked<T, K, true>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + l0), K, ov);
             }

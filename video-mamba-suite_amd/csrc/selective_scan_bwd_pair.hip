@@ -284,6 +284,12 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 ov[i] *= silu;
             }
             if (ok) {
+                if (q.dz_accumulate) {  // dz += (vms_hip.h)
+                    RawB<T, REV> od;
+                    od.load(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0, true);
+#pragma unroll
+                    for (int i = 0; i < K; ++i) dzv[i] += od.at(i);
+                }
                 store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
                 if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
             }

@@ -22,7 +22,8 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from mamba_ssm.ops.selective_scan_interface import (mamba_inner_fn, mamba_inner_fn_no_out_proj,
+from mamba_ssm.ops.selective_scan_interface import (bimamba_inner_fn_no_out_proj, mamba_inner_fn,
+                                                     mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
 from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
 from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
@@ -146,9 +147,15 @@ class MambaCore(nn.Module):
             None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True,
             reverse=reverse)
 
+    def _direction_params(self, suffix):
+        g = lambda name: getattr(self, name + suffix)
+        A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
+        return (g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A, g("D").float(),
+                g("dt_proj").bias.float())
+
     def _merge_and_project(self, out, out_b):
-        """out_b: the backward direction's output, already in the original sequence order."""
-        y = out + out_b  # (B, d_inner, L)
+        """out_b: the backward direction's output, already in the original sequence order (None: out is the sum)."""
+        y = out if out_b is None else out + out_b  # (B, d_inner, L)
         if self.if_devide_out:
             if self.variant == "vim_norm":
                 return F.linear(self.norm(y.transpose(1, 2)), self.out_proj.weight, self.out_proj.bias)
@@ -170,15 +177,16 @@ class MambaCore(nn.Module):
             return self._forward_dbm(xz, inference_params)
         fast = self.use_fast_path and inference_params is None
         if self.bimamba_type == "v2":
+            if fast and _USE_REVERSE_KERNELS:
+                # the reference flips xz, runs the same causal node and flips the result back
+                # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values without the
+                # four full-tensor copies (two here, two in autograd), and both directions form one autograd
+                # node, whose backward accumulates the two dxz in the kernels
+                return self._merge_and_project(
+                    bimamba_inner_fn_no_out_proj(xz, self._direction_params(""), self._direction_params("_b")), None)
             if fast:
                 out = self._direction(xz, "")
-                # the reference flips xz, runs the same causal node and flips the result back
-                # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values
-                # without the four full-tensor copies (two here, two in autograd)
-                if _USE_REVERSE_KERNELS:
-                    out_b = self._direction(xz, "_b", reverse=True)
-                else:
-                    out_b = self._direction(xz.flip([-1]), "_b").flip([-1])
+                out_b = self._direction(xz.flip([-1]), "_b").flip([-1])
             else:
                 A = -torch.exp(self.A_log.float())
                 A_b = -torch.exp(self.A_b_log.float())

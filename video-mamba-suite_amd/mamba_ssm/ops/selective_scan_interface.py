@@ -279,7 +279,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     return F.linear(out_z.transpose(1, 2), out_w, out_bias)
 
 
-def _inner_backward(ctx, dout):
+def _inner_backward(ctx, dout, dxz_into=None):
+    """dxz_into: a dxz that already holds the gradient xz received through another node (the other direction of
+    a bidirectional block); this node's dx / dz are ADDED to it by the kernels instead of by a separate pass."""
     (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, out_w, conv_out, delta,
      A, B, C, D, delta_bias, ckpt, out, A_b, ckpt_b, out_b) = ctx.saved_tensors
     batch, _, L = xz.shape
@@ -292,7 +294,8 @@ def _inner_backward(ctx, dout):
     if ctx.checkpoint_lvl == 1:
         conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse)
         delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
-    dxz = torch.empty_like(xz)
+    dxz = torch.empty_like(xz) if dxz_into is None else dxz_into
+    acc = dxz_into is not None
     dx, dz = dxz[:, :d_inner], dxz[:, d_inner:]
 
     dout_2d = None
@@ -301,13 +304,19 @@ def _inner_backward(ctx, dout):
         dy = (out_w.t() @ dout_2d).view(d_inner, batch, L).permute(1, 0, 2)  # (b, d, l) d-slowest
     else:
         dy = dout
+    # one zero fill for every fp32 atomics target of this node (scan: dA, dB, dC, dD, ddelta_bias; conv: dweight, dbias)
+    n_scan = selective_scan_cuda.bwd_accumulator_elems(A, B, C, D, delta_bias)
+    n_conv = conv_w.numel() + (conv_b.numel() if conv_b is not None else 0)
+    zeros = torch.zeros(n_scan * (2 if ctx.bidirectional else 1) + n_conv, dtype=torch.float32, device=xz.device)
     dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_cuda.bwd(
-        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True, ctx.reverse)
+        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True, ctx.reverse,
+        zeroed=zeros[:n_scan], keep_fp32=True, accumulate_dz=acc)
     dA_b = None
     if ctx.bidirectional:
         dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, out_z_b = selective_scan_cuda.bwd(
             conv_out, delta, A_b, B, C, D, z, delta_bias, dy,
-            ckpt_b, out_b, torch.empty_like(dz), ctx.delta_softplus, True, not ctx.reverse)
+            ckpt_b, out_b, dz, ctx.delta_softplus, True, not ctx.reverse,
+            zeroed=zeros[n_scan:2 * n_scan], keep_fp32=True, accumulate_dz=True)
         dconv_out = dconv_out + dconv_b
         ddelta = ddelta + ddelta_b
         dB = dB + dB_b
@@ -316,7 +325,6 @@ def _inner_backward(ctx, dout):
             dD = dD + dD_b
         if ddelta_bias is not None:
             ddelta_bias = ddelta_bias + ddelta_bias_b
-        dz.add_(dz_b)
         out_z = out_z + out_z_b
 
     dout_proj_weight = dout_proj_bias = None
@@ -345,7 +353,8 @@ def _inner_backward(ctx, dout):
     dx_proj_weight = torch.matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0)              # (R+2N, d)
     # in place: dconv_out is this node's own buffer (the scan's du); out-of-place baddbmm copies it first
     dconv_out.baddbmm_(x_proj_weight.t().expand(batch, -1, -1), dx_dbl)                 # + W_x^T dx_dbl
-    _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse)
+    _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse,
+                                                               zeroed=zeros[zeros.numel() - n_conv:], accumulate_dx=acc)
     return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
                 dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
                 dout_proj_weight=dout_proj_weight, dout_proj_bias=dout_proj_bias,
@@ -373,6 +382,60 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
                 g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
                 None, None, None)
+
+
+class _SubCtx:
+    """What _inner_forward / _inner_backward need from an autograd ctx, for nodes that run them more than once."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class BiMambaInnerFnNoOutProj(torch.autograd.Function):
+    """Both directions of a ViM block (two parameter sets, the second scanned the other way) as ONE node:
+    out = inner(xz; set 1, left-to-right) + inner(xz; set 2, right-to-left).  The reference builds this from
+    two MambaInnerFnNoOutProj nodes on xz and xz.flip (mamba_simple.py:234-258); as one node the second
+    direction's dx / dz are accumulated into the first's by the kernels (no dxz_1 + dxz_2 pass in autograd)."""
+
+    N_PER_DIR = 7  # conv1d weight, conv1d bias, x_proj weight, dt_proj weight, A, D, dt_proj bias
+
+    @staticmethod
+    @custom_fwd
+    def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
+        n = BiMambaInnerFnNoOutProj.N_PER_DIR
+        assert len(params) == 2 * n
+        subs, outs = [], []
+        for i in range(2):
+            cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
+            sub = _SubCtx()
+            outs.append(_inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
+                                       delta_softplus, checkpoint_lvl, reverse=(i == 1)))
+            subs.append(sub)
+        ctx.counts = [len(sub.saved_tensors) for sub in subs]
+        ctx.save_for_backward(*subs[0].saved_tensors, *subs[1].saved_tensors)
+        for sub in subs:
+            sub.saved_tensors = None
+        ctx.subs = subs
+        return outs[0].add_(outs[1])
+
+    @staticmethod
+    @custom_bwd
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        first, second = ctx.subs
+        first.saved_tensors, second.saved_tensors = saved[:ctx.counts[0]], saved[ctx.counts[0]:]
+        g2 = _inner_backward(second, dout)
+        g1 = _inner_backward(first, dout, dxz_into=g2["dxz"])
+        first.saved_tensors = second.saved_tensors = None
+        per_dir = lambda g: (g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"], g["dA"], g["dD"],
+                             g["ddelta_bias"])
+        return (g1["dxz"], None, None) + per_dir(g1) + per_dir(g2)
+
+
+def bimamba_inner_fn_no_out_proj(xz, params, params_b, delta_softplus=True, checkpoint_lvl=1):
+    """params / params_b: (conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias) of the
+    left-to-right and of the right-to-left direction -> out_z_fwd + out_z_bwd, (batch, dim, seqlen)."""
+    return BiMambaInnerFnNoOutProj.apply(xz, delta_softplus, checkpoint_lvl, *params, *params_b)
 
 
 class MambaInnerFn(torch.autograd.Function):

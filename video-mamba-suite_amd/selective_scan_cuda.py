@@ -84,8 +84,23 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
-def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False):
-    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)"""
+def bwd_accumulator_elems(A, B, C, D_, delta_bias_):
+    """fp32 elements of zeroed scratch bwd(..., zeroed=) carves its atomics targets from."""
+    return A.numel() + B.numel() + C.numel() + (D_.numel() if D_ is not None else 0) + (
+        delta_bias_.numel() if delta_bias_ is not None else 0)
+
+
+def _carve(flat, offset, like):
+    n = like.numel()
+    return flat[offset:offset + n].view(like.shape), offset + n
+
+
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False,
+        zeroed=None, keep_fp32=False, accumulate_dz=False):
+    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)
+    zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
+    ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
+    accumulate_dz: dz_ += instead of dz_ = (dz_ must be given)."""
     batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
     _check(dout.is_cuda, "dout.is_cuda()")
@@ -97,6 +112,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         out = out_
         _check(out.dtype == u.dtype and out.is_cuda and out.stride(-1) == 1 and
                tuple(out.shape) == (batch, dim, seqlen), "out must be (batch, dim, seqlen), input dtype, unit last stride")
+        _check(not accumulate_dz or dz_ is not None, "accumulate_dz needs the dz tensor to add to")
         if dz_ is not None:
             dz = dz_
             _check(dz.dtype == u.dtype and dz.is_cuda and dz.stride(-1) == 1 and
@@ -117,14 +133,29 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         _check(seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024")
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
-    dA = torch.zeros_like(A)
-    dB = torch.zeros_like(B, dtype=torch.float32)
-    dC = torch.zeros_like(C, dtype=torch.float32)
-    dD = torch.zeros_like(D_) if D_ is not None else None
-    ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
+    if zeroed is not None and not A.is_complex():
+        _check(zeroed.dtype == torch.float32 and zeroed.is_cuda and zeroed.dim() == 1 and zeroed.is_contiguous()
+               and zeroed.numel() >= bwd_accumulator_elems(A, B, C, D_, delta_bias_),
+               "zeroed must be a flat float32 tensor of at least bwd_accumulator_elems() elements")
+        dA, o = _carve(zeroed, 0, A)
+        dB, o = _carve(zeroed, o, B)
+        dC, o = _carve(zeroed, o, C)
+        dD = ddelta_bias = None
+        if D_ is not None:
+            dD, o = _carve(zeroed, o, D_)
+        if delta_bias_ is not None:
+            ddelta_bias, o = _carve(zeroed, o, delta_bias_)
+    else:
+        dA = torch.zeros_like(A)
+        dB = torch.zeros_like(B, dtype=torch.float32)
+        dC = torch.zeros_like(C, dtype=torch.float32)
+        dD = torch.zeros_like(D_) if D_ is not None else None
+        ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     _k.scan_bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
-                ddelta_bias, dz, delta_softplus, reverse)
-    result = [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]
+                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz))
+    if not keep_fp32:
+        dB, dC = dB.to(B.dtype), dC.to(C.dtype)
+    result = [du, ddelta, dA, dB, dC, dD, ddelta_bias]
     if z_ is not None:
         result.append(dz)
     if recompute_out_z:

@@ -44,6 +44,7 @@ class ScanBwdParams(ctypes.Structure):
             "dA_d_stride", "dA_dstate_stride",
             "dB_batch_stride", "dB_group_stride", "dB_d_stride", "dB_dstate_stride",
             "dC_batch_stride", "dC_group_stride", "dC_d_stride", "dC_dstate_stride")]
+        + [("dz_accumulate", _i32), ("reserved0", _i32)]
     )
 
 
@@ -64,6 +65,7 @@ class ConvBwdParams(ctypes.Structure):
         + [(n, _i64) for n in ("dout_batch_stride", "dout_c_stride", "dout_l_stride",
                                "dx_batch_stride", "dx_c_stride", "dx_l_stride",
                                "dweight_c_stride", "dweight_width_stride")]
+        + [("dx_accumulate", _i32), ("reserved0", _i32)]
     )
 
 
@@ -261,7 +263,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
-             ddelta_bias, dz, delta_softplus, reverse=False):
+             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     if is_rows_x(x, rows_x_elems(Q.f)):
@@ -282,6 +284,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
         Q.dC_batch_stride, Q.dC_group_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1), dC.stride(2)
     else:
         Q.dC_d_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1)
+    Q.dz_accumulate = int(bool(dz_accumulate))
     _call("vms_selective_scan_bwd", Q, u)
 
 
@@ -304,13 +307,14 @@ def conv_fwd(x, weight, bias, out, silu, reverse=False):
     _call("vms_causal_conv1d_fwd", P, x)
 
 
-def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False):
+def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False, dx_accumulate=False):
     Q = ConvBwdParams()
     fill_conv_fwd(Q.f, x, weight, bias, None, silu, reverse)
     Q.dout, Q.dx, Q.dweight, Q.dbias = _ptr(dout), _ptr(dx), _ptr(dweight), _ptr(dbias)
     Q.dout_batch_stride, Q.dout_c_stride, Q.dout_l_stride = dout.stride()
     Q.dx_batch_stride, Q.dx_c_stride, Q.dx_l_stride = dx.stride()
     Q.dweight_c_stride, Q.dweight_width_stride = dweight.stride()
+    Q.dx_accumulate = int(bool(dx_accumulate))
     _call("vms_causal_conv1d_bwd", Q, x)
 
 
