@@ -177,7 +177,9 @@ def main():
             "config": {"workload": "configs[1]: single ViM (bimamba v2) Mamba block fwd+bwd, autocast bf16, "
                                    "B=8 per GPU, L=8192, d_model=1024, expand=1 (d_inner=1024), d_state=16, d_conv=4",
                        "step": "fwd+bwd" + (" + DDP RCCL all-reduce" if distributed else ""),
-                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
+                       "input_grad": True,
+                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))},
             "roofline": roofline,
             "kernels": kern,
         }

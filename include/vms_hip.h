@@ -98,6 +98,10 @@ typedef struct {
      * reference's bidirectional blocks pay (mamba_simple.py:244,258, mamba_new.py:193,213).
      * x keeps scan order (chunk c = the c-th 2048 elements visited). */
     int32_t reverse;
+    /* out_z_accumulate != 0 (an extension): out_z += instead of out_z = ; the caller's out_z already holds the
+     * other direction's gated output of a bidirectional block (z must be given; the "rows" kernels decline). */
+    int32_t out_z_accumulate;
+    int32_t reserved1;
     /* optional scratch for the fast kernels (vms_scan_fwd_workspace_bytes / _bwd_; 16-byte aligned,
      * contents undefined on entry and exit, private to this call until the stream reaches its end).
      * NULL / too small -> the generic kernels run. */

@@ -18,14 +18,15 @@ def make_fakes(oracle):
     def un(a, rev):
         return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
 
-    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
+    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None):
         rv = reverse
         r = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
                             np_(delta_bias_), delta_softplus, prec="f64")
         out = torch.empty_like(delta).copy_(torch.from_numpy(un(r["out"], rv)))
         res = [out, torch.from_numpy(r["x"])]
         if z_ is not None:
-            res.append(torch.empty_like(z_).copy_(torch.from_numpy(un(r["out_z"], rv))))
+            oz = torch.from_numpy(un(r["out_z"], rv))
+            res.append(torch.empty_like(z_).copy_(oz) if out_z_into is None else out_z_into.add_(oz.to(out_z_into.dtype)))
         return res
 
     def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,

@@ -278,6 +278,28 @@ def test_scan_bwd_accumulates_dz(itype, impl, reverse, monkeypatch):
         selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse, accumulate_dz=True)
 
 
+@pytest.mark.parametrize("impl", ["rows", "pair", "fast", "generic"])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_scan_fwd_accumulates_out_z(itype, impl, reverse, monkeypatch):
+    """out_z_into (vms_hip.h out_z_accumulate): out_z += this call's gated output; out and x are unchanged.  With
+    the rows kernels selected the call is served by the next eligible kernel."""
+    import selective_scan_cuda
+    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    g = _rows_problem((2, 64, 1168, 1), itype, True, seed=13)
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
+                                  f("D", torch.float32), f("z"), f("delta_bias", torch.float32))
+    out, x, oz = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
+    start = torch.randn_like(z)
+    acc = start.clone()
+    out2, x2, oz2 = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse, out_z_into=acc)
+    assert oz2.data_ptr() == acc.data_ptr()
+    check(acc, (start.float() + oz.float()).cpu().numpy(), 1e-6 if itype == torch.float32 else 1e-2, "out_z accumulated")
+    check(out2, out.float().cpu().numpy(), 1e-6 if itype == torch.float32 else 1e-2, "out")
+    check(x2[..., 1::2], x[..., 1::2].cpu().numpy(), 1e-5, "checkpoints")
+
+
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("layout", ["seq", "seq_ragged", "channel_last"])
 @pytest.mark.parametrize("reverse", [False, True])

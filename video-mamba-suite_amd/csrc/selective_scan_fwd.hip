@@ -123,6 +123,12 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
             load_dir<T, K, VEC>(z, l0, L, rev, zv);
 #pragma unroll
             for (int i = 0; i < K; ++i) y[i] *= zv[i] * sigmoidf_(zv[i]);
+            if (p.out_z_accumulate) {  // out_z += (vms_hip.h)
+                float old[K];
+                load_dir<T, K, VEC>(out_z, l0, L, rev, old);
+#pragma unroll
+                for (int i = 0; i < K; ++i) y[i] += old[i];
+            }
             store_dir<T, K, VEC>(out_z, l0, L, rev, y);
         }
         // checkpoints every 1024 elements (and at the end of the sequence)
@@ -232,6 +238,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     if (int rc = validate_scan_common(p)) return rc;
     VMS_CHECK(p.out && p.x, "out and x must be provided by the caller");
     VMS_CHECK((p.z == nullptr) == (p.out_z == nullptr), "out_z must be given iff z is given");
+    VMS_CHECK(!p.out_z_accumulate || p.z != nullptr, "out_z_accumulate needs z / out_z");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
     const int knob = scan_impl_knob();

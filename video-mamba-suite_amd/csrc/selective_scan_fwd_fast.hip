@@ -180,12 +180,17 @@ __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast
         }
         if (ok) store_vec<T, K, REV>(out_b + (o_out + pl0), y);
         if (HZ) {
-            RawVecF<T, K, REV> tz;
+            RawVecF<T, K, REV> tz, told;
             tz.load(z_b, o_z + pl0, ok);
+            if (p.out_z_accumulate) told.load(outz_b, o_oz + pl0, ok);  // out_z += (vms_hip.h)
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float zv = tz.at(i);
                 y[i] *= zv * sigmoidf_(zv);
+            }
+            if (p.out_z_accumulate) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) y[i] += told.at(i);
             }
             if (ok) store_vec<T, K, REV>(outz_b + (o_oz + pl0), y);
         }

@@ -200,6 +200,12 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
                 const float zv = tz.at(i);
                 y[i] *= zv * sigmoidf_(zv);
             }
+            if (p.out_z_accumulate) {  // out_z += (vms_hip.h); loaded only now: the kernel sits at 128 VGPRs
+                RawP<T, REV> told;
+                told.load(outz_b, o_oz + pl0, ok);
+#pragma unroll
+                for (int i = 0; i < K; ++i) y[i] += told.at(i);
+            }
             if (ok) store_p<T, REV>(outz_b + (o_oz + pl0), y);
         }
         // reference-shaped checkpoints every 1024 elements (vms_hip.h): even slot = state after the

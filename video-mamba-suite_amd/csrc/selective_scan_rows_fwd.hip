@@ -46,7 +46,7 @@ struct RowsGeom {
 };
 
 bool scan_rows_eligible(const vms_scan_fwd_params& p) {
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kRN) return false;
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kRN || p.out_z_accumulate) return false;
     if (p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % 64 != 0) return false;
     if (p.seqlen % kRTE != 0) return false;
     return true;

@@ -32,6 +32,11 @@ from mamba_ssm.ops.triton.selective_state_update import selective_state_update, 
 
 # VMS_NO_REVERSE=1: run the backward direction the reference's way (flipped copies through the causal ops)
 _USE_REVERSE_KERNELS = os.environ.get("VMS_NO_REVERSE", "0") != "1"
+# Recompute policy of the fused nodes.  The reference rebuilds conv_out and delta in backward (checkpoint_lvl=1,
+# selective_scan_interface.py:167, written for 40-80 GB parts); with 288 GB of HBM per MI355X the blocks keep
+# them (2 x batch x d_inner x seqlen elements per direction) and skip a conv forward and a GEMM per direction.
+# VMS_CHECKPOINT_LVL=1 restores the reference's policy; the values are identical either way.
+_CHECKPOINT_LVL = int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))
 
 
 def _s4d_real_log(d_inner, d_state, device):
@@ -145,7 +150,7 @@ class MambaCore(nn.Module):
         return mamba_inner_fn_no_out_proj(
             xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A,
             None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True,
-            reverse=reverse)
+            reverse=reverse, checkpoint_lvl=_CHECKPOINT_LVL)
 
     def _direction_params(self, suffix):
         g = lambda name: getattr(self, name + suffix)
@@ -183,7 +188,8 @@ class MambaCore(nn.Module):
                 # four full-tensor copies (two here, two in autograd), and both directions form one autograd
                 # node, whose backward accumulates the two dxz in the kernels
                 return self._merge_and_project(
-                    bimamba_inner_fn_no_out_proj(xz, self._direction_params(""), self._direction_params("_b")), None)
+                    bimamba_inner_fn_no_out_proj(xz, self._direction_params(""), self._direction_params("_b"),
+                                                 checkpoint_lvl=_CHECKPOINT_LVL), None)
             if fast:
                 out = self._direction(xz, "")
                 out_b = self._direction(xz.flip([-1]), "_b").flip([-1])

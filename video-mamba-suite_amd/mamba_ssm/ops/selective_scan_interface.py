@@ -215,7 +215,7 @@ def _bc_from_x_dblT(x_dblT, lo, hi, bias):
 
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                   checkpoint_lvl, reverse=False):
+                   checkpoint_lvl, reverse=False, out_z_into=None):
     """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A.
     reverse: the whole node runs right-to-left (== flip o node o flip, without the copies)."""
     assert checkpoint_lvl in (0, 1)
@@ -252,7 +252,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     if D is not None:
         D = D.contiguous()
 
-    out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse)
+    # out_z_into: the gated output is added to that tensor by the kernel (second direction of a bidirectional node)
+    out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse,
+                                               **({} if out_z_into is None else {"out_z_into": out_z_into}))
     saved_b = (None, None, None)
     if A_b is not None:
         assert not A_b.is_complex(), "A should not be complex!!"
@@ -404,19 +406,20 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
     def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
         n = BiMambaInnerFnNoOutProj.N_PER_DIR
         assert len(params) == 2 * n
-        subs, outs = [], []
+        subs, out = [], None
         for i in range(2):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
             sub = _SubCtx()
-            outs.append(_inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
-                                       delta_softplus, checkpoint_lvl, reverse=(i == 1)))
+            # the second direction's scan adds its gated output to the first's
+            out = _inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
+                                 delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out)
             subs.append(sub)
         ctx.counts = [len(sub.saved_tensors) for sub in subs]
         ctx.save_for_backward(*subs[0].saved_tensors, *subs[1].saved_tensors)
         for sub in subs:
             sub.saved_tensors = None
         ctx.subs = subs
-        return outs[0].add_(outs[1])
+        return out
 
     @staticmethod
     @custom_bwd
@@ -509,12 +512,15 @@ def bimamba_inner_fn(
 def mamba_inner_fn_no_out_proj(
     xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-    C_proj_bias=None, delta_softplus=True, reverse=False
+    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1
 ):
     """reverse (extension, default off): the node runs right-to-left over xz -- the value of
-    flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for."""
+    flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for.
+    checkpoint_lvl (extension; the reference hard-wires its default 1 here): 0 keeps conv_out and delta for the
+    backward instead of rebuilding them."""
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
-                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus, 1, reverse)
+                                       A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
+                                       checkpoint_lvl, reverse)
 
 
 # ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------

@@ -71,16 +71,25 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, var_B, var_C
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False):
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None):
     """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)
-    reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies."""
+    reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies.
+    out_z_into (extension): a (batch, dim, seqlen) tensor the gated output is ADDED to (and that is returned as
+    out_z) -- the other direction's output of a bidirectional block."""
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
     out_z = torch.empty_like(z_) if z_ is not None else None
+    if out_z_into is not None:
+        _check(z_ is not None, "out_z_into needs z")
+        _check(out_z_into.dtype == u.dtype and out_z_into.is_cuda and out_z_into.stride(-1) == 1 and
+               tuple(out_z_into.shape) == (batch, dim, seqlen),
+               "out_z_into must be (batch, dim, seqlen), input dtype, unit last stride")
+        out_z = out_z_into
     # x: the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor, allocated by the binding as a view
     # of a larger buffer that also carries the finer checkpoints the backward kernels start from
-    x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse)
+    x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse,
+                    out_z_into is not None)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 

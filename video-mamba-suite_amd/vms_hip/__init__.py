@@ -30,7 +30,8 @@ class ScanFwdParams(ctypes.Structure):
             "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
-        + [("x_has_sub", _i32), ("reverse", _i32), ("workspace", _vp), ("workspace_bytes", _i64)]
+        + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("reserved1", _i32),
+           ("workspace", _vp), ("workspace_bytes", _i64)]
     )
 
 
@@ -237,10 +238,12 @@ def is_rows_x(x, n_elems):
             and x.untyped_storage().nbytes() == (X_HEADER + n_elems) * 4)
 
 
-def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False):
+def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False,
+             out_z_accumulate=False):
     """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
     P = ScanFwdParams()
     fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
+    P.out_z_accumulate = int(bool(out_z_accumulate))
     ws = None
     if x is None:
         batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
