@@ -261,7 +261,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 const float e = fast_exp(t);
                 const float w = 1.f + e;
                 const float rw = fast_rcp(w);
-                const float sp = (w == 1.f) ? e : fast_log(w) * (e * fast_rcp(w - 1.f));
+                const float sp = fmaf(e - (w - 1.f), rw, fast_log(w));  // log1p(e), see softplusf_
                 sg = t <= 20.f ? e * rw : 1.f;
                 t = t <= 20.f ? sp : t;
             }

@@ -36,12 +36,13 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
 __device__ __forceinline__ float sigmoidf_(float x) { return fast_rcp(1.f + fast_exp(-x)); }
 
-// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-156); log1p is
-// evaluated as log(w) * t / (w - 1), w = 1 + t, so that small t keeps full relative accuracy.
+// softplus with the reference's threshold (selective_scan_fwd_kernel.cuh:153-156); log1p(t) is
+// evaluated as log(w) + (t - (w - 1)) / w, w = 1 + t: the first-order correction for the rounding of
+// 1 + t keeps full relative accuracy for small t (w == 1 gives t itself) with one rcp and no select.
 __device__ __forceinline__ float softplusf_(float x) {
     float t = fast_exp(x);
     float w = 1.f + t;
-    float r = (w == 1.f) ? t : fast_log(w) * (t * fast_rcp(w - 1.f));
+    float r = fmaf(t - (w - 1.f), fast_rcp(w), fast_log(w));
     return x <= 20.f ? r : x;
 }
 

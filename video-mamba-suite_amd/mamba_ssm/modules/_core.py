@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from mamba_ssm.ops.selective_scan_interface import (bimamba_inner_fn_no_out_proj, mamba_inner_fn,
+from mamba_ssm.ops.selective_scan_interface import (NegExpPairFn, bimamba_inner_fn_no_out_proj, mamba_inner_fn,
                                                      mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
 from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
@@ -152,9 +152,10 @@ class MambaCore(nn.Module):
             None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True,
             reverse=reverse, checkpoint_lvl=_CHECKPOINT_LVL)
 
-    def _direction_params(self, suffix):
+    def _direction_params(self, suffix, A=None):
         g = lambda name: getattr(self, name + suffix)
-        A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
+        if A is None:
+            A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
         return (g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A, g("D").float(),
                 g("dt_proj").bias.float())
 
@@ -187,8 +188,9 @@ class MambaCore(nn.Module):
                 # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values without the
                 # four full-tensor copies (two here, two in autograd), and both directions form one autograd
                 # node, whose backward accumulates the two dxz in the kernels
+                A, A_b = NegExpPairFn.apply(self.A_log, self.A_b_log)
                 return self._merge_and_project(
-                    bimamba_inner_fn_no_out_proj(xz, self._direction_params(""), self._direction_params("_b"),
+                    bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                                  checkpoint_lvl=_CHECKPOINT_LVL), None)
             if fast:
                 out = self._direction(xz, "")

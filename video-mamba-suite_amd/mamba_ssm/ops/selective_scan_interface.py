@@ -386,6 +386,25 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
                 None, None, None)
 
 
+class NegExpPairFn(torch.autograd.Function):
+    """(A_log, A_b_log) -> (-exp(A_log), -exp(A_b_log)) in fp32 as multi-tensor kernels: 2 launches forward and 1
+    backward for both directions of a block, where `-torch.exp(x.float())` twice costs 4 + 4 (each ~5 us on an
+    otherwise idle GPU queue: they sit between the big kernels of every step)."""
+
+    @staticmethod
+    def forward(ctx, a_log, b_log):
+        outs = torch._foreach_exp([a_log.float(), b_log.float()])
+        torch._foreach_neg_(outs)
+        ctx.save_for_backward(*outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        a, b = ctx.saved_tensors
+        da, db = torch._foreach_mul([ga, gb], [a, b])   # d(-exp(x)) = -exp(x) dx
+        return da, db
+
+
 class _SubCtx:
     """What _inner_forward / _inner_backward need from an autograd ctx, for nodes that run them more than once."""
 
@@ -406,6 +425,15 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
     def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
         n = BiMambaInnerFnNoOutProj.N_PER_DIR
         assert len(params) == 2 * n
+        if torch.is_autocast_enabled():  # the four small projection weights of both directions: one cast kernel
+            params = list(params)
+            idx = [2, 3, n + 2, n + 3]
+            dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+            if all(params[i].dtype != dt for i in idx):
+                low = [torch.empty_like(params[i], dtype=dt) for i in idx]
+                torch._foreach_copy_(low, [params[i] for i in idx])
+                for i, t in zip(idx, low):
+                    params[i] = t
         subs, out = [], None
         for i in range(2):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
