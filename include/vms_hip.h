@@ -101,7 +101,11 @@ typedef struct {
     /* out_z_accumulate != 0 (an extension): out_z += instead of out_z = ; the caller's out_z already holds the
      * other direction's gated output of a bidirectional block (z must be given; the "rows" kernels decline). */
     int32_t out_z_accumulate;
-    int32_t reserved1;
+    /* bc_pad (an extension): the caller guarantees that every B and C row (variable B / C) is readable and FINITE for
+     * bc_pad elements past its logical end -- after element seqlen-1, or before element 0 when reverse != 0 (e.g. zero
+     * padding to the next multiple of 16).  With it the fast kernels also take seqlen % 16 != 0 (they read B / C in
+     * 16-byte vectors); 0 = no guarantee, such lengths run on the generic kernels. */
+    int32_t bc_pad;
     /* optional scratch for the fast kernels (vms_scan_fwd_workspace_bytes / _bwd_; 16-byte aligned,
      * contents undefined on entry and exit, private to this call until the stream reaches its end).
      * NULL / too small -> the generic kernels run. */

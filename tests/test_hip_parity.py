@@ -141,6 +141,29 @@ def test_scan_bwd_fast_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
         check(got[k], want[k], tol * 5, k)
 
 
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 64, 1569, 1), (1, 128, 300, 2), (1, 64, 2049, 1), (2, 32, 17, 1), (1, 64, 1575, 1),
+                                   (1, 96, 1031, 1)])
+@pytest.mark.parametrize("has_z", [True, False])
+def test_scan_ragged_lengths_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
+    """seqlen % 16 != 0 (e.g. 8 x 196 patches + 1 class token = 1569): the extension mirror zero-pads B / C
+    (vms_hip.h bc_pad) and the paired kernels run with per-element masks and a scalar last vector; rows are not
+    16-byte aligned either.  Parity with the oracle and agreement with the generic kernels."""
+    batch, dim, L, groups = shape
+    g = _rows_problem(shape, itype, has_z, seed=L)
+    tol = TOL[itype]
+    got, want = run_scan(g, itype, oracle)
+    monkeypatch.setenv("VMS_FORCE_GENERIC", "1")
+    got_gen, _ = run_scan(g, itype, oracle)
+    monkeypatch.delenv("VMS_FORCE_GENERIC")
+    for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
+        if want.get(k) is not None:
+            check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k} vs oracle")
+            check(got[k], got_gen[k].detach().float().cpu().numpy(), tol * 2, f"{k} paired vs generic kernel")
+    for k in ("dA", "dD", "ddelta_bias"):
+        check(got[k], want[k], tol * 5, k)
+
+
 ROWS_SHAPES = [(2, 64, 128, 1), (1, 128, 144, 2), (2, 64, 1024, 1), (1, 64, 2064, 1), (1, 192, 4096, 1),
                (3, 64, 1168, 1), (1, 256, 16, 1)]
 
@@ -187,7 +210,7 @@ def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
 
 @pytest.mark.parametrize("impl", ["rows", "pair", "fast", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 64, 144, 1)])
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 64, 144, 1), (2, 64, 1569, 1)])
 def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     """reverse=True == flip(fwd(flip(every seqlen-indexed tensor))) for every forward implementation."""
     import selective_scan_cuda
@@ -207,7 +230,7 @@ def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
 
 @pytest.mark.parametrize("impl", ["pair", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 6, 300, 1)])
+@pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 6, 300, 1), (2, 64, 1569, 1), (1, 32, 303, 1)])
 def test_scan_bwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     """bwd(reverse=True) == the causal backward on flipped copies, gradients flipped back."""
     import selective_scan_cuda

@@ -53,11 +53,31 @@ struct RawB {
 #pragma unroll
         for (int i = 0; i < kBK / EPV; ++i) v[i] = vp[i];
     }
+    // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad
+    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0));
+#pragma unroll
+        for (int i = 0; i < kBK / EPV; ++i) v[i] = vp[i];
+    }
+    // ragged rows: the nv (< K) valid logical elements [l0, l0 + nv) of the row one by one, zeros behind them
+    __device__ __forceinline__ void load_partial(const T* __restrict__ row, int l0, int L, int nv) {
+#pragma unroll
+        for (int i = 0; i < kBK; ++i) {
+            const int e = REV ? kBK - 1 - i : i;
+            v[e / EPV][e % EPV] = i < nv ? row[REV ? L - 1 - (l0 + i) : l0 + i] : static_cast<T>(0.f);
+        }
+    }
     __device__ __forceinline__ float at(int i) const {
         const int e = REV ? kBK - 1 - i : i;
         return static_cast<float>(v[e / EPV][e % EPV]);
     }
 };
+template <typename T, bool REV>
+__device__ __forceinline__ void store_partial_b(T* __restrict__ row, int l0, int L, int nv, const float (&in)[kBK]) {
+#pragma unroll
+    for (int i = 0; i < kBK; ++i)
+        if (i < nv) row[REV ? L - 1 - (l0 + i) : l0 + i] = static_cast<T>(in[i]);
+}
 template <typename T, bool REV>
 __device__ __forceinline__ void store_b(T* __restrict__ ptr, const float (&in)[kBK]) {
     constexpr int EPV = 16 / sizeof(T);
@@ -114,7 +134,9 @@ __device__ __forceinline__ float row_allsum_b(float v) {
 }
 
 
-template <typename T, bool HZ, bool REV>
+// RAG: seqlen % 8 != 0 -- the last valid lane of a row owns nv < 8 elements: its activations move one by one
+// (once per row), masks are per element, B / C come through the caller's padding (vms_hip.h bc_pad).
+template <typename T, bool HZ, bool REV, bool RAG>
 __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_scan_bwd_params q) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -176,7 +198,8 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     auto stage_issue = [&](int cc) __attribute__((always_inline)) {
         const int ll = cc * CH + j * K;
         st_ok = cc >= 0 && ll < L;
-        stg.load(st_src, REV ? L - ll - K : ll, st_ok);
+        if (RAG) stg.load_s(st_src, REV ? L - ll - K : ll, st_ok);
+        else stg.load(st_src, REV ? L - ll - K : ll, st_ok);
     };
     auto stage_commit = [&]() __attribute__((always_inline)) {
         f32x4 lo, hi;
@@ -223,12 +246,23 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         const int ll = cc * CH + j * K;
         const bool v = cc >= 0 && ll < L && row_ok;
         const uint32_t pl = REV ? L - ll - K : ll;
-        pu.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl, v);
-        pdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl, v);
-        pdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
-        if (HZ) {
-            pz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
-            pout.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+        if (!RAG || !v || L - ll >= K) {
+            pu.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl, v);
+            pdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl, v);
+            pdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
+            if (HZ) {
+                pz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
+                pout.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+            }
+        } else {  // the row's last, partly valid vector
+            const int nvn = L - ll;
+            pu.load_partial(u_b + VMS_OFF(p.u_batch_stride, p.u_d_stride), ll, L, nvn);
+            pdt.load_partial(dt_b + VMS_OFF(p.delta_batch_stride, p.delta_d_stride), ll, L, nvn);
+            pdo.load_partial(dout_b + VMS_OFF(q.dout_batch_stride, q.dout_d_stride), ll, L, nvn);
+            if (HZ) {
+                pz.load_partial(z_b + VMS_OFF(p.z_batch_stride, p.z_d_stride), ll, L, nvn);
+                pout.load_partial(outp_b + VMS_OFF(p.out_batch_stride, p.out_d_stride), ll, L, nvn);
+            }
         }
         // state entering chunk cc = 128-element sub-checkpoint cc-1 (vms_hip.h); lane j loads state j
         const int e128 = cc * (CH / 128) - 1;
@@ -246,6 +280,8 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     for (int c = n_c - 1; c >= 0; --c) {
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
+        const int nv = !ok ? 0 : (RAG && L - l0 < K ? L - l0 : K);   // valid elements of the lane
+        const bool full = !RAG || nv == K || nv == 0;
         const uint32_t pl0 = REV ? L - l0 - K : l0;      // physical start of the lane's K elements
         const int rd_lo = c * CH + rd_pos;
         float* const rd_dst_c = rd_dst + (REV ? L - 1 - rd_lo : rd_lo);
@@ -255,7 +291,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             uv[i] = pu.at(i);
-            dy[i] = ok ? pdo.at(i) : 0.f;  // past the end: c = 0, a = 1 (identity for the suffix scan)
+            dy[i] = (RAG ? i < nv : ok) ? pdo.at(i) : 0.f;  // past the end: c = 0, a = 1 (identity for the suffix scan)
             float t = pdt.at(i) + bias, sg = 1.f;
             if (p.delta_softplus) {  // selective_scan_fwd_kernel.cuh:153-156 and bwd_kernel.cuh:439-452
                 const float e = fast_exp(t);
@@ -265,7 +301,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 sg = t <= 20.f ? e * rw : 1.f;
                 t = t <= 20.f ? sp : t;
             }
-            t = ok ? t : 0.f;
+            t = (RAG ? i < nv : ok) ? t : 0.f;
             dl2[i / 2][i % 2] = t;
             sg2[i / 2][i % 2] = sg;
             sdl += t;
@@ -283,7 +319,17 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 dy[i] *= silu;
                 ov[i] *= silu;
             }
-            if (ok) {
+            if (!full) {  // the row's last, partly valid vector
+                T* const dzr = dz_b + VMS_OFF(q.dz_batch_stride, q.dz_d_stride);
+                if (q.dz_accumulate) {
+                    RawB<T, REV> od;
+                    od.load_partial(dzr, l0, L, nv);
+#pragma unroll
+                    for (int i = 0; i < K; ++i) dzv[i] += od.at(i);
+                }
+                store_partial_b<T, REV>(dzr, l0, L, nv, dzv);
+                if (out_z_b) store_partial_b<T, REV>(out_z_b + VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride), l0, L, nv, ov);
+            } else if (ok) {
                 if (q.dz_accumulate) {  // dz += (vms_hip.h)
                     RawB<T, REV> od;
                     od.load(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0, true);
@@ -433,9 +479,12 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
                 duv[i] = fmaf(dl2[i / 2][i % 2], s1, Dd * dy2[i / 2][i % 2]);
                 ddl[i] = fmaf(uv[i], s1, s2);
                 ddl[i] *= sg2[i / 2][i % 2];
-                dbias_acc += ok ? ddl[i] : 0.f;
+                dbias_acc += (RAG ? i < nv : ok) ? ddl[i] : 0.f;
             }
-            if (ok) {
+            if (!full) {
+                store_partial_b<T, REV>(du_b + VMS_OFF(q.du_batch_stride, q.du_d_stride), l0, L, nv, duv);
+                store_partial_b<T, REV>(ddelta_b + VMS_OFF(q.ddelta_batch_stride, q.ddelta_d_stride), l0, L, nv, ddl);
+            } else if (ok) {
                 store_b<T, REV>(du_b + (VMS_OFF(q.du_batch_stride, q.du_d_stride) + pl0), duv);
                 store_b<T, REV>(ddelta_b + (VMS_OFF(q.ddelta_batch_stride, q.ddelta_d_stride) + pl0), ddl);
             }
@@ -461,10 +510,11 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
     const vms_scan_fwd_params& p = q.f;
-    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || p.x_has_sub != 1) return false;
+    (void)vec;  // 16-byte vector accesses need no alignment on gfx950
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || p.x_has_sub != 1) return false;
     const int dpg = p.dim / p.n_groups;
     if (dpg % kBRows != 0) return false;     // a workgroup's rows must share one B/C group
-    if (p.seqlen % kBK != 0) return false;   // a lane's K elements are all in range or all out
+    if (p.seqlen % kBK != 0 && p.bc_pad < kBK - p.seqlen % kBK) return false;   // ragged: B / C padding needed
     // 32-bit element offsets inside the kernel
     const int64_t lim = (int64_t)1 << 31;
     auto span = [&](int64_t bs, int64_t ds) { return (p.batch - 1) * bs + (p.dim - 1) * ds + p.seqlen; };
@@ -488,12 +538,19 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     static bool once = false;  // more than the default 64 KB of LDS per workgroup
     if (!once) {
         once = true;
-#define VMS_A(Z_, R_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair_kernel<T, Z_, R_>), \
+#define VMS_A(Z_, R_) VMS_A2(Z_, R_, true); VMS_A2(Z_, R_, false)
+#define VMS_A2(Z_, R_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair_kernel<T, Z_, R_, G_>), \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
         VMS_A(true, true); VMS_A(true, false); VMS_A(false, true); VMS_A(false, false);
 #undef VMS_A
+#undef VMS_A2
     }
-#define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_>), grid, block, smem, stream, q)
+    const bool rag = p.seqlen % kBK != 0;
+#define VMS_L(Z_, R_)                                                                                              \
+    do {                                                                                                           \
+        if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q);        \
+        else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q);           \
+    } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L

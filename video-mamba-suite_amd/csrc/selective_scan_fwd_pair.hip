@@ -36,11 +36,31 @@ struct RawP {
 #pragma unroll
         for (int i = 0; i < kPK / EPV; ++i) v[i] = vp[i];
     }
+    // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad
+    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0));
+#pragma unroll
+        for (int i = 0; i < kPK / EPV; ++i) v[i] = vp[i];
+    }
+    // ragged rows: the nv (< K) valid logical elements [l0, l0 + nv) of the row one by one, zeros behind them
+    __device__ __forceinline__ void load_partial(const T* __restrict__ row, int l0, int L, int nv) {
+#pragma unroll
+        for (int i = 0; i < kPK; ++i) {
+            const int e = REV ? kPK - 1 - i : i;
+            v[e / EPV][e % EPV] = i < nv ? row[REV ? L - 1 - (l0 + i) : l0 + i] : static_cast<T>(0.f);
+        }
+    }
     __device__ __forceinline__ float at(int i) const {
         const int e = REV ? kPK - 1 - i : i;
         return static_cast<float>(v[e / EPV][e % EPV]);
     }
 };
+template <typename T, bool REV>
+__device__ __forceinline__ void store_partial_p(T* __restrict__ row, int l0, int L, int nv, const float (&in)[kPK]) {
+#pragma unroll
+    for (int i = 0; i < kPK; ++i)
+        if (i < nv) row[REV ? L - 1 - (l0 + i) : l0 + i] = static_cast<T>(in[i]);
+}
 template <typename T, bool REV>
 __device__ __forceinline__ void store_p(T* __restrict__ ptr, const float (&in)[kPK]) {
     constexpr int EPV = 16 / sizeof(T);
@@ -77,7 +97,10 @@ __device__ __forceinline__ f2 pk_fma_p(f2 a, f2 b, f2 c) {
 #ifndef VMS_PAIR_MINWAVES
 #define VMS_PAIR_MINWAVES 3
 #endif
-template <typename T, bool HZ, bool REV>
+// RAG: seqlen is not a multiple of K.  The last valid lane of a row then owns nv < K elements: it reads / writes
+// its activations one by one (once per row), every lane masks per element, and B / C rows are read through the
+// padding the caller guarantees behind their logical end (vms_hip.h bc_pad).  RAG = false is the tuned path.
+template <typename T, bool HZ, bool REV, bool RAG>
 __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pair_kernel(const vms_scan_fwd_params p) {
     constexpr int K = kPK, N = kPN, CS = kWave * K;
     const int lane = threadIdx.x & 63;
@@ -114,24 +137,36 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
     for (int c = 0; c < n_kchunks; ++c) {
         const int l0 = c * CS + lane * K;            // logical start of this lane's K elements
         const bool ok = l0 < L;
-        const uint32_t pl0 = REV ? L - l0 - K : l0;  // physical start (seqlen % K == 0)
+        const int nv = RAG ? (L - l0 >= K ? K : (L - l0 > 0 ? L - l0 : 0)) : (ok ? K : 0);  // valid elements of the lane
+        const bool full = !RAG || nv == K;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;  // physical start (as int32: negative in a partly valid REV lane)
         const bool okn = l0 + CS < L;                // the same lane in the next chunk
         const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
         if (c == 0) {
-            rB0.load(Bv, pl0, ok);
-            rC0.load(Cv, pl0, ok);
+            if (RAG) {
+                rB0.load_s(Bv, (int32_t)pl0, ok);
+                rC0.load_s(Cv, (int32_t)pl0, ok);
+            } else {
+                rB0.load(Bv, pl0, ok);
+                rC0.load(Cv, pl0, ok);
+            }
         }
         f2 dl2[K / 2], du2[K / 2], y2[K / 2];
         float sdl = 0.f;
         {
             RawP<T, REV> t0, t1;
-            t0.load(u_b, o_u + pl0, ok);
-            t1.load(dt_b, o_dt + pl0, ok);
+            if (full) {
+                t0.load(u_b, o_u + pl0, ok);
+                t1.load(dt_b, o_dt + pl0, ok);
+            } else {
+                t0.load_partial(u_b + o_u, l0, L, nv);
+                t1.load_partial(dt_b + o_dt, l0, L, nv);
+            }
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 float t = t1.at(i) + bias;
                 if (p.delta_softplus) t = softplusf_(t);
-                t = ok ? t : 0.f;  // past the end: delta = 0 -> a = 1, b = 0 (identity)
+                t = (RAG ? i < nv : ok) ? t : 0.f;  // past the end: delta = 0 -> a = 1, b = 0 (identity)
                 const float uv = t0.at(i);
                 dl2[i / 2][i % 2] = t;
                 du2[i / 2][i % 2] = t * uv;
@@ -146,8 +181,13 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
                 const bool wrap = n + 1 == N;
                 const uint32_t po = wrap ? pl0n : pl0;
                 const bool pok = wrap ? okn : ok;
-                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
-                nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
+                if (RAG) {
+                    nB.load_s(Bv + (int64_t)nn * p.B_dstate_stride, (int32_t)po, pok);
+                    nC.load_s(Cv + (int64_t)nn * p.C_dstate_stride, (int32_t)po, pok);
+                } else {
+                    nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
+                    nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
+                }
             }
             const float An = readlane_f(A_mine, n);
             const float hin = readlane_f(hreg, n);
@@ -191,10 +231,15 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
         float y[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) y[i] = VMS_ELP(y2, i);
-        if (ok) store_p<T, REV>(out_b + (o_out + pl0), y);
+        if (full) {
+            if (ok) store_p<T, REV>(out_b + (o_out + pl0), y);
+        } else {
+            store_partial_p<T, REV>(out_b + o_out, l0, L, nv, y);
+        }
         if (HZ) {
             RawP<T, REV> tz;
-            tz.load(z_b, o_z + pl0, ok);
+            if (full) tz.load(z_b, o_z + pl0, ok);
+            else tz.load_partial(z_b + o_z, l0, L, nv);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float zv = tz.at(i);
@@ -202,11 +247,16 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
             }
             if (p.out_z_accumulate) {  // out_z += (vms_hip.h); loaded only now: the kernel sits at 128 VGPRs
                 RawP<T, REV> told;
-                told.load(outz_b, o_oz + pl0, ok);
+                if (full) told.load(outz_b, o_oz + pl0, ok);
+                else told.load_partial(outz_b + o_oz, l0, L, nv);
 #pragma unroll
                 for (int i = 0; i < K; ++i) y[i] += told.at(i);
             }
-            if (ok) store_p<T, REV>(outz_b + (o_oz + pl0), y);
+            if (full) {
+                if (ok) store_p<T, REV>(outz_b + (o_oz + pl0), y);
+            } else {
+                store_partial_p<T, REV>(outz_b + o_oz, l0, L, nv, y);
+            }
         }
         // reference-shaped checkpoints every 1024 elements (vms_hip.h): even slot = state after the
         // first 1024 elements of a 2048-chunk, odd slot = state after the chunk (or the sequence)
@@ -222,9 +272,12 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
     }
 }
 
+// 16-byte vector accesses need no alignment on gfx950 (measured: global and buffer dwordx4 at 2-byte aligned
+// addresses), so `vec` (16-byte aligned bases and strides) is not required; ragged lengths need readable B / C padding
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec) {
-    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kPN) return false;
-    if (p.seqlen % kPK != 0) return false;
+    (void)vec;
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kPN) return false;
+    if (p.seqlen % kPK != 0 && p.bc_pad < kPK - p.seqlen % kPK) return false;
     const int64_t lim = (int64_t)1 << 31;
     auto span = [&](int64_t bs, int64_t ds) { return (p.batch - 1) * bs + (p.dim - 1) * ds + p.seqlen; };
     if (span(p.u_batch_stride, p.u_d_stride) >= lim || span(p.delta_batch_stride, p.delta_d_stride) >= lim ||
@@ -239,7 +292,12 @@ template <typename T>
 static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     const int tiles = (p.dim + kPRows - 1) / kPRows;
     dim3 grid(p.batch * tiles), block(kPRows * kWave);
-#define VMS_L(Z_, R_) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_>), grid, block, 0, stream, p)
+    const bool rag = p.seqlen % kPK != 0;
+#define VMS_L(Z_, R_)                                                                                              \
+    do {                                                                                                           \
+        if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p);           \
+        else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p);              \
+    } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L

@@ -10,6 +10,7 @@ Differences that are visible only to someone poking at the raw extension:
   * 64-bit strides: no 2^32-element limit on batch_stride * batch.
 """
 import torch
+import torch.nn.functional as F
 
 import vms_hip as _k
 
@@ -71,11 +72,26 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, var_B, var_C
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None):
+def pad_bc(B, C, reverse=False):
+    """Variable B, C (batch, groups, dstate, seqlen) -> (B', C', pad): the same values as views of zero-padded
+    copies whose rows stay readable (zeros) for `pad` elements past their logical end -- after the last element, or
+    before the first one for a right-to-left scan.  With that guarantee (vms_hip.h bc_pad) the fast kernels, which
+    read B / C in 16-byte vectors, also take sequence lengths that are not a multiple of 16.  pad == 0: untouched."""
+    seqlen = B.shape[-1]
+    pad = (-seqlen) % 16
+    if pad == 0 or B.dim() != 4 or C.dim() != 4:
+        return B, C, 0
+    if reverse:
+        return F.pad(B, (pad, 0))[..., pad:], F.pad(C, (pad, 0))[..., pad:], pad
+    return F.pad(B, (0, pad))[..., :seqlen], F.pad(C, (0, pad))[..., :seqlen], pad
+
+
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, bc_pad=None):
     """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)
     reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies.
     out_z_into (extension): a (batch, dim, seqlen) tensor the gated output is ADDED to (and that is returned as
-    out_z) -- the other direction's output of a bidirectional block."""
+    out_z) -- the other direction's output of a bidirectional block.
+    bc_pad (extension): None = pad B / C here when the length needs it (pad_bc); an int = the caller already did."""
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
@@ -88,8 +104,10 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
         out_z = out_z_into
     # x: the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor, allocated by the binding as a view
     # of a larger buffer that also carries the finer checkpoints the backward kernels start from
+    if bc_pad is None:
+        B, C, bc_pad = pad_bc(B, C, reverse)
     x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse,
-                    out_z_into is not None)
+                    out_z_into is not None, bc_pad)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
@@ -105,7 +123,7 @@ def _carve(flat, offset, like):
 
 
 def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False,
-        zeroed=None, keep_fp32=False, accumulate_dz=False):
+        zeroed=None, keep_fp32=False, accumulate_dz=False, bc_pad=None):
     """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)
     zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
     ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
@@ -142,6 +160,10 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         _check(seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024")
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
+    if bc_pad is None:
+        Bk, Ck, bc_pad = pad_bc(B, C, reverse)   # B / C themselves keep their shapes for the gradients below
+    else:
+        Bk, Ck = B, C
     if zeroed is not None and not A.is_complex():
         _check(zeroed.dtype == torch.float32 and zeroed.is_cuda and zeroed.dim() == 1 and zeroed.is_contiguous()
                and zeroed.numel() >= bwd_accumulator_elems(A, B, C, D_, delta_bias_),
@@ -160,8 +182,8 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         dC = torch.zeros_like(C, dtype=torch.float32)
         dD = torch.zeros_like(D_) if D_ is not None else None
         ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
-    _k.scan_bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
-                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz))
+    _k.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
+                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz), bc_pad)
     if not keep_fp32:
         dB, dC = dB.to(B.dtype), dC.to(C.dtype)
     result = [du, ddelta, dA, dB, dC, dD, ddelta_bias]

@@ -30,7 +30,7 @@ class ScanFwdParams(ctypes.Structure):
             "out_z_batch_stride", "out_z_d_stride", "A_d_stride", "A_dstate_stride",
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
-        + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("reserved1", _i32),
+        + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("bc_pad", _i32),
            ("workspace", _vp), ("workspace_bytes", _i64)]
     )
 
@@ -239,11 +239,12 @@ def is_rows_x(x, n_elems):
 
 
 def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False,
-             out_z_accumulate=False):
+             out_z_accumulate=False, bc_pad=0):
     """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
     P = ScanFwdParams()
     fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     P.out_z_accumulate = int(bool(out_z_accumulate))
+    P.bc_pad = int(bc_pad)
     ws = None
     if x is None:
         batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
@@ -266,7 +267,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
-             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False):
+             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     if is_rows_x(x, rows_x_elems(Q.f)):
@@ -288,6 +289,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
     else:
         Q.dC_d_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1)
     Q.dz_accumulate = int(bool(dz_accumulate))
+    Q.f.bc_pad = int(bc_pad)
     _call("vms_selective_scan_bwd", Q, u)
 
 
