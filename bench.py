@@ -31,7 +31,7 @@ B, L, D_MODEL, D_STATE, EXPAND, D_CONV = 8, 8192, 1024, 16, 1, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01f_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01g_traffic.json")
 
 
 def profiled_traffic(kernel):

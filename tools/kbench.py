@@ -17,7 +17,7 @@ def timeit(fn, n=10, warm=3):
     return e0.elapsed_time(e1) / n
 
 def main():
-    which = sys.argv[1:] or ["fwd", "bwd", "conv"]
+    which = [a for a in sys.argv[1:] if a != "norm"] or ["fwd", "bwd", "conv"]
     dt = torch.bfloat16 if os.environ.get("KB_DTYPE", "bf16") == "bf16" else torch.float32
     b, d, L, N = [int(x) for x in os.environ.get("KB_SHAPE", "8,1024,8192,16").split(",")]
     dev = "cuda"
@@ -64,7 +64,9 @@ def norm_bench():
     print(f"layernorm_fwd (bf16 -> bf16) {t*1e3:7.1f} us  {by/t/1e6:8.1f} GB/s  {by/t/1e6/8000*100:5.1f}% of 8 TB/s")
 
 
-if "norm" in sys.argv[1:]:
-    norm_bench()
-else:
-    main()
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if not args or any(a in ("fwd", "bwd", "conv") for a in args):
+        main()
+    if "norm" in args:
+        norm_bench()
