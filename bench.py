@@ -93,6 +93,48 @@ def cpu_baseline(seconds_budget=25.0):
                       "projection GEMMs not included"}
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
+
+
+def projection_mfma(block, hidden, iters=20):
+    """The block's two large projections (library GEMMs on the matrix cores, mamba_ssm/ops/projections.py) timed on
+    their own AFTER the timed region: forward + backward of in_proj and of out_proj, as TFLOP/s against the dense
+    bf16 MFMA peak (north_star: "MFMA utilisation for the projections")."""
+    from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
+    out = {}
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        cases = {
+            "in_proj": (lambda x: in_proj_fn(x, block.in_proj.weight, block.in_proj.bias),
+                        hidden.detach().clone().requires_grad_(), block.in_proj.weight),
+            "out_proj": (lambda y: out_proj_fn(y, block.out_proj.weight, block.out_proj.bias),
+                         torch.randn(hidden.shape[0], block.d_inner, hidden.shape[1], device=hidden.device,
+                                     dtype=torch.bfloat16, requires_grad=True), block.out_proj.weight),
+        }
+        for name, (fn, x, w) in cases.items():
+            y = fn(x)
+            g = torch.randn_like(y)
+
+            def fb():
+                x.grad = None
+                w.grad = None
+                fn(x).backward(g)
+            for _ in range(3):
+                fb()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fb()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            flops = 3 * 2.0 * x.shape[0] * hidden.shape[1] * w.shape[0] * w.shape[1]   # fwd + dgrad + wgrad
+            out[name] = {"fwd_bwd_ms": ms, "tflops": flops / ms / 1e9,
+                         "mfma_frac": flops / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS}
+    block.zero_grad(set_to_none=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +225,8 @@ def main():
             "roofline": roofline,
             "kernels": kern,
         }
+        if world == 1:
+            res["projections"] = projection_mfma(block, hidden)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
