@@ -175,7 +175,10 @@ def main():
             out = model(hidden)
         out.backward(gout)
 
-    for _ in range(args.warmup):
+    # the GPU's clocks need ~20 steps (0.1 s) to settle: with fewer the first timed steps run 1-2 % slow.  The extra
+    # untimed steps below are reported as config.clock_ramp_steps; the timed region is exactly --steps steps.
+    ramp = max(0, 20 - args.warmup)
+    for _ in range(args.warmup + ramp):
         step()
     if distributed:
         dist.barrier()
@@ -220,7 +223,7 @@ def main():
                                    "B=8 per GPU, L=8192, d_model=1024, expand=1 (d_inner=1024), d_state=16, d_conv=4",
                        "step": "fwd+bwd" + (" + DDP RCCL all-reduce" if distributed else ""),
                        "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
-                       "input_grad": True,
+                       "input_grad": True, "clock_ramp_steps": ramp,
                        "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))},
             "roofline": roofline,
             "kernels": kern,
