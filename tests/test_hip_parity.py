@@ -275,6 +275,37 @@ def test_conv_reverse_equals_flipped(seqlen, width, itype):
     check(db_r, db_f.cpu().numpy(), 1e-4, "dbias")
 
 
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("has_z", [True, False])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("shape,segments", [((2, 64, 2048, 1), "3"), ((1, 32, 1160, 1), "5"), ((1, 64, 16384, 1), None),
+                                            ((2, 32, 384, 1), "16")])
+def test_scan_bwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, reverse, monkeypatch):
+    """Few rows, long sequences: the backward runs as n ranges of chunks per row, chained by the (P, q) adjoint carries
+    of scan_bwd_carry_kernel (VMS_BWD_SEGMENTS forces a count; None = the kernel's own choice, 16 here).  Every result
+    equals the unsplit kernel's."""
+    import selective_scan_cuda
+    g = _rows_problem(shape, itype, has_z, seed=shape[2])
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                     f("delta_bias", torch.float32), f("g"))
+    z = f("z") if has_z else None
+    res = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
+    out, x = res[0], res[1]
+    monkeypatch.setenv("VMS_BWD_SEGMENTS", "1")
+    plain = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out if has_z else None, None, True, has_z, reverse)
+    if segments is None:
+        monkeypatch.delenv("VMS_BWD_SEGMENTS")
+    else:
+        monkeypatch.setenv("VMS_BWD_SEGMENTS", segments)
+    split = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out if has_z else None, None, True, has_z, reverse)
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z")
+    tol = 2e-5 if itype == torch.float32 else 1e-2
+    for name, a, b_ in zip(names, split, plain):
+        wide = 20 if name in ("dA", "dD", "ddelta_bias") else 1   # atomics: summation order differs
+        check(a, b_.float().cpu().numpy(), tol * wide, name)
+
+
 @pytest.mark.parametrize("impl", ["pair", "fast", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("reverse", [False, True])
@@ -873,3 +904,41 @@ def test_block_step_matches_full_forward():
             outs.append(o)
         stepped = torch.cat(outs, dim=1)
     check(stepped, full.float().cpu().numpy(), 1e-3, "step-by-step vs fused forward")
+
+
+@pytest.mark.parametrize("seqlen", [304, 301])
+def test_block_step_is_hip_graph_capturable(seqlen):
+    """Forward + backward of the ViM block captured into a HIP graph (torch.cuda.CUDAGraph) and replayed: the path does
+    no host synchronisation, allocates only through torch's caching allocator and sets its launch attributes at
+    warm-up, so small / launch-bound problems can run as one graph launch.  Replayed results == eager results."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(128, expand=1, bimamba_type="v2").to(DEV)
+    params = list(m.parameters())
+    x = torch.randn(2, seqlen, 128, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(2, seqlen, 128, device=DEV, dtype=torch.bfloat16)
+
+    def step():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        return (y,) + torch.autograd.grad(y, [x] + params, g)
+    eager = [t.detach().clone() for t in step()]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = step()
+    x0 = x.detach().clone()
+    x.data.copy_(torch.randn_like(x))          # another input in the captured buffer: the replay recomputes
+    graph.replay()
+    assert not torch.equal(outs[0], eager[0])
+    x.data.copy_(x0)
+    graph.replay()
+    torch.cuda.synchronize()
+    for i, (a, b_) in enumerate(zip(outs, eager)):
+        check(a, b_.float().cpu().numpy(), 2e-2, f"graph output {i}")

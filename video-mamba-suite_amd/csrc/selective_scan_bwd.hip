@@ -25,6 +25,8 @@ bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
 int scan_impl_knob();
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream);
+int scan_bwd_pair_segments(const vms_scan_bwd_params& q);
+int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q);
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
@@ -330,7 +332,12 @@ static int dispatch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t s) {
 
 using namespace vms;
 
-extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) { return 0; }
+// scratch the paired kernel wants when it splits the sequence into ranges (few rows, long sequences): the (P, q)
+// adjoint carries of selective_scan_bwd_pair.hip; 0 = no scratch needed for this problem
+extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
+    if (q == nullptr || scan_impl_knob() < 2 || !scan_bwd_pair_eligible(*q, true)) return 0;
+    return scan_bwd_pair_segments(*q) > 1 ? scan_bwd_pair_ws_bytes(*q) : 0;
+}
 
 extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* stream) {
     VMS_CHECK(qq != nullptr, "null params");

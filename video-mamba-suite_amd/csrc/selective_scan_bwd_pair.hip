@@ -137,7 +137,8 @@ __device__ __forceinline__ float row_allsum_b(float v) {
 // RAG: seqlen % 8 != 0 -- the last valid lane of a row owns nv < 8 elements: its activations move one by one
 // (once per row), masks are per element, B / C come through the caller's padding (vms_hip.h bc_pad).
 template <typename T, bool HZ, bool REV, bool RAG>
-__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_scan_bwd_params q) {
+__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_scan_bwd_params q, const int n_seg,
+                                                                       const float2* __restrict__ seg_carry) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN;
@@ -158,8 +159,12 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
     // consecutive workgroups share a row tile across batches -> batch = blockIdx % batch keeps the
     // B/C of one batch on one XCD's L2 when batch == 8
-    const int b = blockIdx.x % p.batch;
-    const int d0 = (blockIdx.x / p.batch) * kBRows;
+    // n_seg > 1 (few rows, long sequences): the grid repeats n_seg times and copy `seg` walks only the chunks
+    // [c_lo, c_hi) of every row; the adjoint entering that range from the right comes from scan_bwd_carry_kernel
+    const int wg_per_seg = gridDim.x / n_seg;
+    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
+    const int b = wg % p.batch;
+    const int d0 = (wg / p.batch) * kBRows;
     const int d = d0 + quad * 4 + r;
     const bool row_ok = d < p.dim;
     const int dc = row_ok ? d : p.dim - 1;
@@ -269,15 +274,29 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
         hck_next = x_b[xo];
     };
-    request_row(n_c - 1);
-    stage_issue(n_c - 1);
+    const int cps = (n_c + n_seg - 1) / n_seg;                        // chunks per segment
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
+    float g_in = 0.f, anx_in = 1.f;                                   // lane j <-> state j
+    if (seg < n_seg - 1) {
+        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_seg) * N + j;
+        for (int s2 = n_seg - 1; s2 > seg; --s2) {                    // g entering segment s = P_{s+1} g_{s+1} + q_{s+1}
+            const float2 pq = cp[(int64_t)s2 * N];
+            g_in = fmaf(pq.x, g_in, pq.y);
+        }
+        const int lr = c_hi * CH;                                     // first element to the right of this range
+        float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
+        if (p.delta_softplus) t = softplusf_(t);
+        anx_in = fast_exp2(t * A_mine * kLog2e);
+    }
+    request_row(c_hi - 1);
+    stage_issue(c_hi - 1);
     stage_commit();
-    rec4[j] = f32x4{A_mine, n_c > 1 ? hck_next : 0.f, 1.f, 0.f};   // lane j <-> state j
+    rec4[j] = f32x4{A_mine, c_hi > 1 ? hck_next : 0.f, anx_in, g_in};   // lane j <-> state j
     lds_barrier_b();
     bc_fetch(bcA, 0);
     f32x4 bc = rec4[0];   // record of the state about to run
     const bool is_first = j == 0, is_last = j == 15;
-    for (int c = n_c - 1; c >= 0; --c) {
+    for (int c = c_hi - 1; c >= c_lo; --c) {
         const int l0 = c * CH + j * K;
         const bool okb = l0 < L, ok = okb && row_ok;
         const int nv = !ok ? 0 : (RAG && L - l0 < K ? L - l0 : K);   // valid elements of the lane
@@ -508,6 +527,152 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     }
 }
 
+
+// ---- adjoint carries of a segmented backward --------------------------------------------------------------------
+// With few rows and long sequences (batch 1, 768 channels, 65,536 tokens: 24 workgroups for 256 CUs) the grid
+// above is repeated over n_seg ranges of chunks.  The adjoint entering a range from the right depends linearly on
+// the one entering the range after it:  g_out = P g_in + q  per (row, state), with P = the product of a_{i+1}
+// over the range and q = the reverse recurrence g_i = a_{i+1} g_{i+1} + C_i dy_i run from g = 0.  This kernel
+// computes (P, q) for the ranges 1 .. n_seg-1 -- one exp, the C dy products, one fma chain and the reverse half of
+// the row scan per (element, state), about a fifth of the full backward -- and the main kernel chains them.
+template <int CTRL>
+__device__ __forceinline__ float row_newbcast(float v) { return bdpp<0x150 + CTRL>(0.f, v); }
+
+template <typename T, bool HZ, bool REV>
+__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_scan_bwd_params q, const int n_seg,
+                                                                        float2* __restrict__ seg_carry) {
+    const vms_scan_fwd_params& p = q.f;
+    constexpr int K = kBK, N = kBN, CH = kCH;
+    const int lane = threadIdx.x & 63;
+    const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, r = lane >> 4;
+    const int wg_per_seg = gridDim.x / (n_seg - 1);
+    const int seg = 1 + blockIdx.x / wg_per_seg, wg = blockIdx.x % wg_per_seg;   // range 0 has nothing to its left
+    const int b = wg % p.batch;
+    const int d0 = (wg / p.batch) * kBRows;
+    const int d = d0 + quad * 4 + r;
+    const bool row_ok = d < p.dim;
+    const int dc = row_ok ? d : p.dim - 1;
+    const int g = d0 / (p.dim / p.n_groups);
+    const int L = p.seqlen;
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    const T* const dout_b = static_cast<const T*>(q.dout);
+    const T* const z_b = static_cast<const T*>(p.z);
+#define VMS_OFF(bs, ds) static_cast<uint32_t>((int64_t)b * (bs) + (int64_t)dc * (ds))
+    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride] * kLog2e;
+    const int n_c = (L + CH - 1) / CH;
+    const int cps = (n_c + n_seg - 1) / n_seg;
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
+    float gcar = 0.f, pacc = 1.f, anx = 1.f;   // lane j <-> state j
+    if (c_hi < n_c) {
+        const int lr = c_hi * CH;
+        float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
+        if (p.delta_softplus) t = softplusf_(t);
+        anx = fast_exp2(t * A_mine);
+    }
+    const bool is_last = j == 15;
+    for (int c = c_hi - 1; c >= c_lo; --c) {
+        const int l0 = c * CH + j * K;
+        const bool ok = l0 < L && row_ok;              // seqlen % K == 0 (host): all or nothing
+        const uint32_t pl0 = REV ? L - l0 - K : l0;
+        RawB<T, REV> rdt, rdo, rz;
+        rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
+        rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
+        if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
+        f2 dl2[K / 2], dy2[K / 2];
+        float sdl = 0.f, dl_first = 0.f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            float t = rdt.at(i) + bias;
+            if (p.delta_softplus) t = softplusf_(t);
+            t = ok ? t : 0.f;
+            float dyv = ok ? rdo.at(i) : 0.f;
+            if (HZ) {
+                const float zv = rz.at(i);
+                dyv *= zv * sigmoidf_(zv);
+            }
+            dl2[i / 2][i % 2] = t;
+            dy2[i / 2][i % 2] = dyv;
+            sdl += t;
+            if (i == 0) dl_first = t;
+        }
+#define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
+#define VMS_CARRY_STATE(n)                                                                                          \
+        {                                                                                                           \
+            RawB<T, REV> rc;                                                                                        \
+            rc.load(Cv + (int64_t)(n) * p.C_dstate_stride, pl0, l0 < L);                                            \
+            const float An = row_newbcast<n>(A_mine), anx_n = row_newbcast<n>(anx), gin = row_newbcast<n>(gcar);    \
+            const f2 An2 = f2{An, An};                                                                              \
+            f2 a2[K / 2], c2[K / 2];                                                                                \
+            _Pragma("unroll") for (int k = 0; k < K / 2; ++k) {                                                     \
+                const f2 t = dl2[k] * An2;                                                                          \
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};                                                         \
+                c2[k] = f2{rc.at(2 * k), rc.at(2 * k + 1)} * dy2[k];                                                \
+            }                                                                                                       \
+            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);                                               \
+            float rg = 0.f;                                                                                         \
+            _Pragma("unroll") for (int i = K - 1; i >= 0; --i)                                                      \
+                rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));                             \
+            float ra = fast_exp2((sdl - dl_first) * An) * a_right;                                                  \
+            rg = fmaf(ra, is_last ? gin : 0.f, rg);                                                                 \
+            asm volatile("s_nop 1\n\t"                                                                              \
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"                       \
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"                       \
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"                       \
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"                       \
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"      \
+                         : "+v"(rg), "+v"(ra));                                                                     \
+            const float g0 = row_newbcast<0>(rg), p0 = row_newbcast<0>(ra), a0 = row_newbcast<0>(a2[0].x);          \
+            if (j == (n)) { gcar = g0; pacc *= p0; anx = a0; }                                                      \
+        }
+        VMS_CARRY_STATE(0) VMS_CARRY_STATE(1) VMS_CARRY_STATE(2) VMS_CARRY_STATE(3)
+        VMS_CARRY_STATE(4) VMS_CARRY_STATE(5) VMS_CARRY_STATE(6) VMS_CARRY_STATE(7)
+        VMS_CARRY_STATE(8) VMS_CARRY_STATE(9) VMS_CARRY_STATE(10) VMS_CARRY_STATE(11)
+        VMS_CARRY_STATE(12) VMS_CARRY_STATE(13) VMS_CARRY_STATE(14) VMS_CARRY_STATE(15)
+#undef VMS_CARRY_STATE
+#undef VMS_EL
+    }
+    if (row_ok) seg_carry[(((int64_t)b * p.dim + d) * n_seg + seg) * N + j] = float2{pacc, gcar};
+#undef VMS_OFF
+}
+
+// how many ranges of chunks the backward is split into (1 = not split): enough to give every CU two workgroups,
+// at least 8 chunks (1024 elements) per range; VMS_BWD_SEGMENTS forces a count (tests)
+int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
+    const vms_scan_fwd_params& p = q.f;
+    if (p.seqlen % kBK != 0) return 1;
+    const int n_c = (p.seqlen + kCH - 1) / kCH;
+    const int n_wg = p.batch * ((p.dim + kBRows - 1) / kBRows);
+    int want;
+    if (const char* e = getenv("VMS_BWD_SEGMENTS")) {
+        want = atoi(e);
+    } else {
+        // run time ~ rounds of workgroups over the 256 CUs (one workgroup per CU) x range length, + ~25 % for the
+        // carry pass: take the count that minimises it, and split only for a clear win
+        const int most = n_c / 8 < 16 ? n_c / 8 : 16;
+        double best = 1.0 * ((n_wg + 255) / 256);
+        want = 1;
+        for (int s = 2; s <= most; ++s) {
+            const double cost = 1.25 * ((n_wg * s + 255) / 256) / s;
+            if (cost < 0.9 * best) { best = cost; want = s; }
+        }
+    }
+    if (want > 16) want = 16;
+    if (want > n_c) want = n_c;
+    if (want < 2) return 1;
+    const int cps = (n_c + want - 1) / want;
+    return (n_c + cps - 1) / cps;   // no empty range
+}
+
+int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q) {
+    return (int64_t)q.f.batch * q.f.dim * 16 * kBN * (int64_t)sizeof(float2);   // up to 16 ranges
+}
+
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
     const vms_scan_fwd_params& p = q.f;
     (void)vec;  // 16-byte vector accesses need no alignment on gfx950
@@ -546,10 +711,24 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
 #undef VMS_A2
     }
     const bool rag = p.seqlen % kBK != 0;
+    int n_seg = 1;
+    float2* carry = nullptr;
+    if (p.workspace != nullptr && p.workspace_bytes >= scan_bwd_pair_ws_bytes(q)) {
+        n_seg = scan_bwd_pair_segments(q);
+        carry = static_cast<float2*>(p.workspace);
+    }
+    if (n_seg > 1) {
+        dim3 cgrid(p.batch * tiles * (n_seg - 1));
+#define VMS_C(Z_, R_) hipLaunchKernelGGL((scan_bwd_carry_kernel<T, Z_, R_>), cgrid, block, 0, stream, q, n_seg, carry)
+        if (p.reverse) { if (p.z) VMS_C(true, true); else VMS_C(false, true); }
+        else { if (p.z) VMS_C(true, false); else VMS_C(false, false); }
+#undef VMS_C
+        grid = dim3(p.batch * tiles * n_seg);
+    }
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
-        if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q);        \
-        else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q);           \
+        if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q, 1, carry); \
+        else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q, n_seg, carry); \
     } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }

@@ -290,6 +290,10 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
         Q.dC_d_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1)
     Q.dz_accumulate = int(bool(dz_accumulate))
     Q.f.bc_pad = int(bc_pad)
+    nws = lib().vms_scan_bwd_workspace_bytes(ctypes.byref(Q))   # adjoint carries of a sequence-split backward
+    if nws > 0:
+        ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
+        Q.f.workspace, Q.f.workspace_bytes = _ptr(ws), nws
     _call("vms_selective_scan_bwd", Q, u)
 
 
