@@ -108,7 +108,10 @@ typedef struct {
     int32_t bc_pad;
     /* optional scratch for the fast kernels (vms_scan_fwd_workspace_bytes / _bwd_; 16-byte aligned,
      * contents undefined on entry and exit, private to this call until the stream reaches its end).
-     * NULL / too small -> the generic kernels run. */
+     * NULL / too small -> the kernels that need none run.  Forward: only the opt-in "rows" kernels use it.
+     * Backward: with few rows and long sequences (e.g. batch 1, 768 channels, 65,536 tokens = 24 workgroups for 256 CUs)
+     * the paired kernel splits every row into up to 16 ranges of chunks; the scratch holds the (P, q) adjoint carries
+     * that chain them (vms_scan_bwd_workspace_bytes() > 0 exactly when it wants to split). */
     void *workspace;
     int64_t workspace_bytes;
 } vms_scan_fwd_params;
