@@ -278,6 +278,38 @@ def test_conv_reverse_equals_flipped(seqlen, width, itype):
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("has_z", [True, False])
 @pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("shape,segments", [((2, 8, 4096, 1), "2"), ((1, 4, 5136, 1), "6"), ((1, 16, 65536, 1), None),
+                                            ((2, 4, 3072, 1), "16")])
+def test_scan_fwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, reverse, monkeypatch):
+    """Few rows, long sequences: the forward runs as n ranges of 1024-element chunks per row, each started from the
+    state the (P, q) pairs of scan_fwd_carry_kernel give (VMS_FWD_SEGMENTS forces a count; None = the kernel's own
+    choice, 16 here).  out, out_z and every checkpoint equal the unsplit kernel's, and the backward runs from them."""
+    import selective_scan_cuda
+    g = _rows_problem(shape, itype, has_z, seed=shape[2])
+    f = lambda k, dt=itype: G(g[k], dt)
+    u, dl, A, B, C, D, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                     f("delta_bias", torch.float32), f("g"))
+    z = f("z") if has_z else None
+    monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+    plain = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
+    if segments is None:
+        monkeypatch.delenv("VMS_FWD_SEGMENTS")
+    else:
+        monkeypatch.setenv("VMS_FWD_SEGMENTS", segments)
+    split = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
+    tol = 2e-5 if itype == torch.float32 else 1e-2
+    for name, a, b_ in zip(("out", "x", "out_z"), split, plain):
+        check(a, b_.float().cpu().numpy(), tol, name)
+    # the finer checkpoints behind the reference-shaped view feed the backward: same gradients from either forward
+    ga = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, split[1], split[0] if has_z else None, None, True, False, reverse)
+    gb = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, plain[1], plain[0] if has_z else None, None, True, False, reverse)
+    for name, a, b_ in zip(("du", "ddelta", "dA", "dB", "dC"), ga, gb):
+        check(a, b_.float().cpu().numpy(), tol * (20 if name == "dA" else 2), name)
+
+
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("has_z", [True, False])
+@pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("shape,segments", [((2, 64, 2048, 1), "3"), ((1, 32, 1160, 1), "5"), ((1, 64, 16384, 1), None),
                                             ((2, 32, 384, 1), "16")])
 def test_scan_bwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, reverse, monkeypatch):

@@ -196,6 +196,8 @@ int64_t scan_rows_fwd_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_rows(const vms_scan_fwd_params& p, hipStream_t stream);
 
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec);
+int scan_fwd_pair_segments(const vms_scan_fwd_params& p);
+int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
 
 // which implementations a call may use: VMS_SCAN_IMPL = generic (0) | fast (1) | pair (2) | rows (3), a
@@ -260,8 +262,12 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 }
 
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
-    if (p == nullptr || scan_impl_knob() < 3 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return 0;
-    return scan_rows_fwd_ws_bytes(*p);
+    if (p == nullptr) return 0;
+    if (scan_impl_knob() >= 3 && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return scan_rows_fwd_ws_bytes(*p);
+    // the paired kernel's (P, q) state carries when it wants to split long rows into ranges
+    if (scan_impl_knob() >= 2 && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_segments(*p) > 1)
+        return scan_fwd_pair_ws_bytes(*p);
+    return 0;
 }
 extern "C" int64_t vms_scan_x_elems(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;

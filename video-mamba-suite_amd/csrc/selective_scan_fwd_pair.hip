@@ -101,13 +101,19 @@ __device__ __forceinline__ f2 pk_fma_p(f2 a, f2 b, f2 c) {
 // its activations one by one (once per row), every lane masks per element, and B / C rows are read through the
 // padding the caller guarantees behind their logical end (vms_hip.h bc_pad).  RAG = false is the tuned path.
 template <typename T, bool HZ, bool REV, bool RAG>
-__global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pair_kernel(const vms_scan_fwd_params p) {
+__global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pair_kernel(const vms_scan_fwd_params p,
+                                                                                          const int n_seg,
+                                                                                          const float2* __restrict__ seg_carry) {
     constexpr int K = kPK, N = kPN, CS = kWave * K;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // batch = blockIdx % batch: workgroups of one batch land on one XCD (blockIdx % 8) when batch == 8
-    const int b = blockIdx.x % p.batch;
-    const int d = (blockIdx.x / p.batch) * kPRows + wave;
+    // n_seg > 1 (few rows, long sequences): the grid repeats n_seg times, copy `seg` walks the chunks [c_lo, c_hi) of
+    // every row from the state scan_fwd_carry_kernel's (P, q) pairs give for the chunks before them
+    const int wg_per_seg = gridDim.x / n_seg;
+    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
+    // batch = wg % batch: workgroups of one batch land on one XCD (blockIdx % 8) when batch == 8
+    const int b = wg % p.batch;
+    const int d = (wg / p.batch) * kPRows + wave;
     if (d >= p.dim) return;  // no barriers in this kernel
     const int g = d / (p.dim / p.n_groups);
     const int L = p.seqlen;
@@ -134,7 +140,16 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 
     RawP<T, REV> rB0, rC0, rB1, rC1;  // two named sets: explicit double buffering
     const int n_kchunks = (L + CS - 1) / CS;
-    for (int c = 0; c < n_kchunks; ++c) {
+    const int cps = (n_kchunks + n_seg - 1) / n_seg;
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_kchunks) ? c_lo + cps : n_kchunks;
+    if (seg > 0 && lane < N) {  // state entering this range: x = P x + q over the ranges to its left
+        const float2* cp = seg_carry + (((int64_t)b * p.dim + d) * n_seg) * N + lane;
+        for (int s2 = 0; s2 < seg; ++s2) {
+            const float2 pq = cp[(int64_t)s2 * N];
+            hreg = fmaf(pq.x, hreg, pq.y);
+        }
+    }
+    for (int c = c_lo; c < c_hi; ++c) {
         const int l0 = c * CS + lane * K;            // logical start of this lane's K elements
         const bool ok = l0 < L;
         const int nv = RAG ? (L - l0 >= K ? K : (L - l0 > 0 ? L - l0 : 0)) : (ok ? K : 0);  // valid elements of the lane
@@ -142,7 +157,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
         const uint32_t pl0 = REV ? L - l0 - K : l0;  // physical start (as int32: negative in a partly valid REV lane)
         const bool okn = l0 + CS < L;                // the same lane in the next chunk
         const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
-        if (c == 0) {
+        if (c == c_lo) {
             if (RAG) {
                 rB0.load_s(Bv, (int32_t)pl0, ok);
                 rC0.load_s(Cv, (int32_t)pl0, ok);
@@ -272,6 +287,117 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
     }
 }
 
+
+// ---- state carries of a sequence-split forward --------------------------------------------------------------------
+// (P, q) per (row, state) and range of chunks: the state leaving the range is P x_in + q, P = exp2(A sum(delta)),
+// q = the recurrence run from x = 0.  The forward kernel without its C / y / z half (~60 % of its work).
+template <typename T, bool REV>
+__global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_carry_kernel(const vms_scan_fwd_params p,
+                                                                                           const int n_seg,
+                                                                                           float2* __restrict__ seg_carry) {
+    constexpr int K = kPK, N = kPN, CS = kWave * K;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg_per_seg = gridDim.x / (n_seg - 1);
+    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;   // ranges 0 .. n_seg-2
+    const int b = wg % p.batch;
+    const int d = (wg / p.batch) * kPRows + wave;
+    if (d >= p.dim) return;
+    const int g = d / (p.dim / p.n_groups);
+    const int L = p.seqlen;
+    const T* const u_b = static_cast<const T*>(p.u);
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    const uint32_t o_u = static_cast<uint32_t>((int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride);
+    const uint32_t o_dt = static_cast<uint32_t>((int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride);
+    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)d * p.A_d_stride + (int64_t)(lane & 15) * p.A_dstate_stride] * kLog2e;
+    float hreg = 0.f, sdl_acc = 0.f;
+    const int n_kchunks = (L + CS - 1) / CS;
+    const int cps = (n_kchunks + n_seg - 1) / n_seg;
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_kchunks) ? c_lo + cps : n_kchunks;
+    RawP<T, REV> rB0, rB1;
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int l0 = c * CS + lane * K;
+        const bool ok = l0 < L;                       // seqlen % K == 0 (host)
+        const uint32_t pl0 = REV ? L - l0 - K : l0;
+        const bool okn = l0 + CS < L;
+        const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
+        if (c == c_lo) rB0.load(Bv, pl0, ok);
+        f2 dl2[K / 2], du2[K / 2];
+        float sdl = 0.f;
+        {
+            RawP<T, REV> t0, t1;
+            t0.load(u_b, o_u + pl0, ok);
+            t1.load(dt_b, o_dt + pl0, ok);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float t = t1.at(i) + bias;
+                if (p.delta_softplus) t = softplusf_(t);
+                t = ok ? t : 0.f;
+                dl2[i / 2][i % 2] = t;
+                du2[i / 2][i % 2] = t * t0.at(i);
+                sdl += t;
+            }
+        }
+        sdl_acc += sdl;
+        auto do_state = [&](const int n, const RawP<T, REV>& cB, RawP<T, REV>& nB) __attribute__((always_inline)) {
+            {
+                const int nn = (n + 1) & (N - 1);
+                const bool wrap = n + 1 == N;
+                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, wrap ? pl0n : pl0, wrap ? okn : ok);
+            }
+            const float An = readlane_f(A_mine, n);
+            const float hin = readlane_f(hreg, n);
+            const f2 An2 = f2{An, An};
+            float px = 0.f;
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 t = dl2[k] * An2;
+                const f2 a = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                const f2 bx = du2[k] * f2{cB.at(2 * k), cB.at(2 * k + 1)};
+                px = fmaf(a.x, px, bx.x);
+                px = fmaf(a.y, px, bx.y);
+            }
+            float pa = fast_exp2(sdl * An);
+            wave_scan_fused_p(pa, px);
+            const float hout = readlane_f(fmaf(pa, hin, px), 63);
+            if (lane == n) hreg = hout;
+        };
+#pragma unroll 1
+        for (int n = 0; n < N; n += 2) {
+            do_state(n, rB0, rB1);
+            do_state(n + 1, rB1, rB0);
+        }
+    }
+    const float tot = wave_sum(sdl_acc);
+    if (lane < N) seg_carry[(((int64_t)b * p.dim + d) * n_seg + seg) * N + lane] = float2{fast_exp2(A_mine * tot), hreg};
+}
+
+// ranges a forward is split into (1 = not split): only when the rows do not give every SIMD a wave; aims at ~2.5 waves
+// per SIMD, at least 4 chunks (4096 elements) per range; VMS_FWD_SEGMENTS forces a count (tests)
+int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
+    if (p.seqlen % kPK != 0) return 1;
+    const int n_k = (p.seqlen + kWave * kPK - 1) / (kWave * kPK);
+    const int64_t waves = (int64_t)p.batch * p.dim;
+    int want = 1;
+    if (const char* e = getenv("VMS_FWD_SEGMENTS")) {
+        want = atoi(e);
+    } else if (waves <= 1024) {
+        want = (int)((2560 + waves - 1) / waves);
+        if (want > n_k / 4) want = n_k / 4;
+    }
+    if (want > 16) want = 16;
+    if (want > n_k) want = n_k;
+    if (want < 2) return 1;
+    const int cps = (n_k + want - 1) / want;
+    return (n_k + cps - 1) / cps;
+}
+
+int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p) {
+    return (int64_t)p.batch * p.dim * 16 * kPN * (int64_t)sizeof(float2);
+}
+
 // 16-byte vector accesses need no alignment on gfx950 (measured: global and buffer dwordx4 at 2-byte aligned
 // addresses), so `vec` (16-byte aligned bases and strides) is not required; ragged lengths need readable B / C padding
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec) {
@@ -293,10 +419,22 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     const int tiles = (p.dim + kPRows - 1) / kPRows;
     dim3 grid(p.batch * tiles), block(kPRows * kWave);
     const bool rag = p.seqlen % kPK != 0;
+    int n_seg = 1;
+    float2* carry = nullptr;
+    if (p.workspace != nullptr && p.workspace_bytes >= scan_fwd_pair_ws_bytes(p) && p.x_has_sub != 2) {
+        n_seg = scan_fwd_pair_segments(p);
+        carry = static_cast<float2*>(p.workspace);
+    }
+    if (n_seg > 1) {
+        dim3 cgrid(p.batch * tiles * (n_seg - 1));
+        if (p.reverse) hipLaunchKernelGGL((scan_fwd_carry_kernel<T, true>), cgrid, block, 0, stream, p, n_seg, carry);
+        else hipLaunchKernelGGL((scan_fwd_carry_kernel<T, false>), cgrid, block, 0, stream, p, n_seg, carry);
+        grid = dim3(p.batch * tiles * n_seg);
+    }
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
-        if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p);           \
-        else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p);              \
+        if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p, 1, carry); \
+        else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p, n_seg, carry); \
     } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }

@@ -262,6 +262,11 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
             x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=torch.float32)[..., :dstate * 2]
             P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
             P.x_has_sub = 1
+    if not P.workspace:
+        nws = lib().vms_scan_fwd_workspace_bytes(ctypes.byref(P))   # state carries of a sequence-split forward
+        if nws > 0:
+            ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
+            P.workspace, P.workspace_bytes = _ptr(ws), nws
     _call("vms_selective_scan_fwd", P, u)
     return x
 
