@@ -59,7 +59,9 @@ __device__ __forceinline__ float lane_value(float v, int src_lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
 }
 
-template <typename T, int DIR>
+// RAGC: rows that are not 16-byte aligned and / or seqlen % E != 0.  gfx950 serves 16-byte buffer accesses at any
+// 2-byte alignment; the row's single partly valid vector moves element by element (one lane, once per row).
+template <typename T, int DIR, bool RAGC>
 struct RowIO {
     static constexpr int E = 16 / sizeof(T);
     __amdgpu_buffer_rsrc_t rsrc;
@@ -70,16 +72,33 @@ struct RowIO {
     // byte offset of the vector holding logical elements [l0, l0 + E); negative = out of range
     __device__ __forceinline__ int voff(int l0) const { return (DIR == 2 ? L - l0 - E : l0) * (int)sizeof(T); }
     __device__ __forceinline__ void load(int l0, float (&out)[E]) const {
-        const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(l0), 0, 0);
-        const vec_t<T, E> t = __builtin_bit_cast(vec_t<T, E>, raw);
+        if (!RAGC || l0 + E <= L || l0 >= L) {
+            const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff(l0), 0, 0);
+            const vec_t<T, E> t = __builtin_bit_cast(vec_t<T, E>, raw);
 #pragma unroll
-        for (int e = 0; e < E; ++e) out[DIR == 2 ? E - 1 - e : e] = static_cast<float>(t[e]);
+            for (int e = 0; e < E; ++e) out[DIR == 2 ? E - 1 - e : e] = static_cast<float>(t[e]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) out[i] = elem(l0 + i, true);
+        }
     }
     __device__ __forceinline__ void store(int l0, const float (&in)[E]) const {
-        vec_t<T, E> t;
+        if (!RAGC || l0 + E <= L || l0 >= L) {
+            vec_t<T, E> t;
 #pragma unroll
-        for (int e = 0; e < E; ++e) t[e] = static_cast<T>(in[DIR == 2 ? E - 1 - e : e]);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rsrc, voff(l0), 0, 0);
+            for (int e = 0; e < E; ++e) t[e] = static_cast<T>(in[DIR == 2 ? E - 1 - e : e]);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), rsrc, voff(l0), 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < E; ++i) {   // stores past the row are dropped by the bounds check
+                const int phys = DIR == 2 ? L - 1 - (l0 + i) : l0 + i;
+                const T v = static_cast<T>(in[i]);
+                if constexpr (sizeof(T) == 2)
+                    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), rsrc, phys * 2, 0, 0);
+                else
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), rsrc, phys * 4, 0, 0);
+            }
+        }
     }
     // one logical element, 0 outside [0, L); lanes with `active` false do not touch memory
     __device__ __forceinline__ float elem(int l, bool active) const {
@@ -108,15 +127,16 @@ struct RowIOGeneric {
     }
 };
 
+// DIR 1 / 2: VEC = false selects the ragged / unaligned flavour of the buffer-addressed rows
 template <typename T, bool VEC, int DIR>
-struct RowIOSel { using type = RowIO<T, DIR>; };
+struct RowIOSel { using type = RowIO<T, DIR, !VEC>; };
 template <typename T, bool VEC>
 struct RowIOSel<T, VEC, 0> { using type = RowIOGeneric<T, VEC>; };
 
 template <typename T, bool VEC, int DIR>
 __device__ __forceinline__ typename RowIOSel<T, VEC, DIR>::type make_row(const T* row, int L, bool rev) {
     if constexpr (DIR == 0) return RowIOGeneric<T, VEC>(row, L, rev);
-    else return RowIO<T, DIR>(row, L);
+    else return RowIO<T, DIR, !VEC>(row, L);
 }
 
 template <typename T, bool SILU, bool VEC, int NV, int DIR>
@@ -470,19 +490,24 @@ static int conv_fwd_dispatch(const vms_conv_fwd_params& p, hipStream_t s) {
         const bool vec = aligned16(p.x) && aligned16(p.out) && mult16(p.x_batch_stride, es) && mult16(p.x_c_stride, es) &&
                          mult16(p.out_batch_stride, es) && mult16(p.out_c_stride, es);
         // 16-byte rows with whole vectors: buffer-addressed kernels, 4 strips per wave when the row is long
-        const bool full = vec && p.seqlen % E == 0 && (int64_t)p.seqlen * es < ((int64_t)1 << 31);
-        const int nv = full && p.seqlen > 64 * E ? 4 : 1;
+        // buffer-addressed rows whenever a row fits 31-bit byte offsets; `even` = 16-byte aligned rows of whole vectors
+        const bool full = (int64_t)p.seqlen * es < ((int64_t)1 << 31);
+        const bool even = vec && p.seqlen % E == 0;
+        // 4 strips per wave need rows long enough to keep a workgroup's 4 waves busy (4 x 4 x 64 vectors)
+        const int nv = full && p.seqlen >= 12 * 64 * E ? 4 : 1;
         const int per_wg = kConvThreads * E * nv;
         dim3 grid((p.seqlen + per_wg - 1) / per_wg, p.dim, p.batch), block(kConvThreads);
 #define VMS_K(S_, V_, N_, D_) hipLaunchKernelGGL((conv_fwd_kernel<T, S_, V_, N_, D_>), grid, block, 0, s, p)
+#define VMS_D(S_, N_, D_) do { if (even) VMS_K(S_, true, N_, D_); else VMS_K(S_, false, N_, D_); } while (0)
 #define VMS_L(S_)                                                                       \
     do {                                                                                \
         if (!full) { if (vec) VMS_K(S_, true, 1, 0); else VMS_K(S_, false, 1, 0); }      \
-        else if (nv == 4) { if (p.reverse) VMS_K(S_, true, 4, 2); else VMS_K(S_, true, 4, 1); } \
-        else { if (p.reverse) VMS_K(S_, true, 1, 2); else VMS_K(S_, true, 1, 1); }       \
+        else if (nv == 4) { if (p.reverse) VMS_D(S_, 4, 2); else VMS_D(S_, 4, 1); }      \
+        else { if (p.reverse) VMS_D(S_, 1, 2); else VMS_D(S_, 1, 1); }                   \
     } while (0)
         if (p.silu_activation) VMS_L(true); else VMS_L(false);
 #undef VMS_L
+#undef VMS_D
 #undef VMS_K
     } else {
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
@@ -509,19 +534,23 @@ static int conv_bwd_dispatch(const vms_conv_bwd_params& q, hipStream_t s) {
         const bool vec = aligned16(p.x) && aligned16(q.dout) && aligned16(q.dx) && mult16(p.x_batch_stride, es) &&
                          mult16(p.x_c_stride, es) && mult16(q.dout_batch_stride, es) && mult16(q.dout_c_stride, es) &&
                          mult16(q.dx_batch_stride, es) && mult16(q.dx_c_stride, es);
-        const bool full = vec && p.seqlen % E == 0 && (int64_t)p.seqlen * es < ((int64_t)1 << 31);
-        const int nv = full && p.seqlen > 64 * E ? 4 : 1;
+        const bool full = (int64_t)p.seqlen * es < ((int64_t)1 << 31);
+        const bool even = vec && p.seqlen % E == 0;
+        // 4 strips per wave need rows long enough to keep a workgroup's 4 waves busy (4 x 4 x 64 vectors)
+        const int nv = full && p.seqlen >= 12 * 64 * E ? 4 : 1;
         const int per_wg = kConvThreads * E * nv;
         dim3 grid((p.seqlen + per_wg - 1) / per_wg, p.dim, p.batch), block(kConvThreads);
 #define VMS_K(S_, V_, N_, D_) hipLaunchKernelGGL((conv_bwd_kernel<T, S_, V_, N_, D_>), grid, block, 0, s, q)
+#define VMS_D(S_, N_, D_) do { if (even) VMS_K(S_, true, N_, D_); else VMS_K(S_, false, N_, D_); } while (0)
 #define VMS_L(S_)                                                                       \
     do {                                                                                \
         if (!full) { if (vec) VMS_K(S_, true, 1, 0); else VMS_K(S_, false, 1, 0); }      \
-        else if (nv == 4) { if (p.reverse) VMS_K(S_, true, 4, 2); else VMS_K(S_, true, 4, 1); } \
-        else { if (p.reverse) VMS_K(S_, true, 1, 2); else VMS_K(S_, true, 1, 1); }       \
+        else if (nv == 4) { if (p.reverse) VMS_D(S_, 4, 2); else VMS_D(S_, 4, 1); }      \
+        else { if (p.reverse) VMS_D(S_, 1, 2); else VMS_D(S_, 1, 1); }                   \
     } while (0)
         if (p.silu_activation) VMS_L(true); else VMS_L(false);
 #undef VMS_L
+#undef VMS_D
 #undef VMS_K
     } else {
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
