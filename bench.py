@@ -31,7 +31,7 @@ B, L, D_MODEL, D_STATE, EXPAND, D_CONV = 8, 8192, 1024, 16, 1, 4
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01g_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01h_traffic.json")
 
 
 def profiled_traffic(kernel):
@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-projections", action="store_true", help="skip the separate projection GEMM timing (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -228,7 +229,7 @@ def main():
             "roofline": roofline,
             "kernels": kern,
         }
-        if world == 1:
+        if world == 1 and not args.no_projections:
             res["projections"] = projection_mfma(block, hidden)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
