@@ -142,11 +142,12 @@ class MambaCore(nn.Module):
             ssm_state.copy_(last_state)
         return y
 
-    def _direction(self, xz, suffix, reverse=False):
+    def _direction(self, xz, suffix, reverse=False, A=None):
         """One fused direction of the ViM block with parameter set `suffix` ('' or '_b').
         reverse: right-to-left over the sequence; the result is in the ORIGINAL order."""
         g = lambda name: getattr(self, name + suffix)
-        A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
+        if A is None:
+            A = -torch.exp(getattr(self, "A" + suffix + "_log").float())
         return mamba_inner_fn_no_out_proj(
             xz, g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A,
             None, None, g("D").float(), delta_bias=g("dt_proj").bias.float(), delta_softplus=True,
@@ -220,8 +221,9 @@ class MambaCore(nn.Module):
         if _USE_REVERSE_KERNELS:
             # shared weights, the second half scanned right-to-left: no cat / flip copies
             # (the reference stacks the flipped half on the batch axis, mamba_new.py:192-213)
-            out_f = self._direction(xz_f, "")
-            out_b = self._direction(xz_b, "", reverse=True)
+            A = -torch.exp(self.A_log.float())   # shared by both halves
+            out_f = self._direction(xz_f, "", A=A)
+            out_b = self._direction(xz_b, "", reverse=True, A=A)
             return out_proj_fn(torch.cat([out_f, out_b], dim=1), self.out_proj.weight, self.out_proj.bias)
         else:
             # the reversed sequence rides along as extra batch entries: one fused call, shared weights
