@@ -216,6 +216,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
 #pragma unroll
         for (int i = 0; i < E; ++i) { xv[s][3 + i] = cur[i]; g[s][i] = gc[i]; }
     }
+    float dx_old[NV][E];
+    if (q.dx_accumulate) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s) dx.load(base + s * 64 * E, dx_old[s]);
+    }
     // what precedes the wave's first element (lane 0) and what follows its last (lane 63)
     const int lend = base + (NV - 1) * 64 * E + E;
     float edge[3], xr[3], gr[3];
@@ -278,11 +283,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_b
             for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], g[s][i + 3 - k], acc);
             o[i] = acc;
         }
-        if (q.dx_accumulate) {  // dx += (vms_hip.h): the other direction's gradient is already there
-            float old[E];
-            dx.load(base + s * 64 * E, old);
+        if (q.dx_accumulate) {  // dx += (vms_hip.h): the other direction's gradient, requested with x and dout above
 #pragma unroll
-            for (int i = 0; i < E; ++i) o[i] += old[i];
+            for (int i = 0; i < E; ++i) o[i] += dx_old[s][i];
         }
         dx.store(base + s * 64 * E, o);
 #pragma unroll
