@@ -573,14 +573,18 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_sc
         anx = fast_exp2(t * A_mine);
     }
     const bool is_last = j == 15;
+    RawB<T, REV> rcA, rcB, rdt, rdo, rz;
     for (int c = c_hi - 1; c >= c_lo; --c) {
         const int l0 = c * CH + j * K;
         const bool ok = l0 < L && row_ok;              // seqlen % K == 0 (host): all or nothing
         const uint32_t pl0 = REV ? L - l0 - K : l0;
-        RawB<T, REV> rdt, rdo, rz;
-        rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
-        rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
-        if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
+        const uint32_t pl0n = REV ? L - (l0 - CH) - K : l0 - CH;   // the same lane in the next chunk (c - 1)
+        if (c == c_hi - 1) {
+            rcA.load(Cv, pl0, l0 < L);
+            rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
+            rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
+            if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
+        }
         f2 dl2[K / 2], dy2[K / 2];
         float sdl = 0.f, dl_first = 0.f;
 #pragma unroll
@@ -598,11 +602,18 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_sc
             sdl += t;
             if (i == 0) dl_first = t;
         }
+        {   // the next chunk's row data travels while this chunk's 16 states compute
+            const bool okn = c > c_lo && row_ok;
+            rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0n, okn);
+            rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0n, okn);
+            if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0n, okn);
+        }
 #define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
-#define VMS_CARRY_STATE(n)                                                                                          \
+#define VMS_CARRY_STATE(n, rc, rn)                                                                                  \
         {                                                                                                           \
-            RawB<T, REV> rc;                                                                                        \
-            rc.load(Cv + (int64_t)(n) * p.C_dstate_stride, pl0, l0 < L);                                            \
+            /* C of the next state -- after the last one: state 0 of the next chunk (to the left) -- while this one computes */ \
+            rn.load(Cv + (int64_t)(((n) + 1) & (N - 1)) * p.C_dstate_stride, (n) == N - 1 ? pl0n : pl0,             \
+                    (n) == N - 1 ? c > c_lo : l0 < L);                                                              \
             const float An = row_newbcast<n>(A_mine), anx_n = row_newbcast<n>(anx), gin = row_newbcast<n>(gcar);    \
             const f2 An2 = f2{An, An};                                                                              \
             f2 a2[K / 2], c2[K / 2];                                                                                \
@@ -630,10 +641,10 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_sc
             const float g0 = row_newbcast<0>(rg), p0 = row_newbcast<0>(ra), a0 = row_newbcast<0>(a2[0].x);          \
             if (j == (n)) { gcar = g0; pacc *= p0; anx = a0; }                                                      \
         }
-        VMS_CARRY_STATE(0) VMS_CARRY_STATE(1) VMS_CARRY_STATE(2) VMS_CARRY_STATE(3)
-        VMS_CARRY_STATE(4) VMS_CARRY_STATE(5) VMS_CARRY_STATE(6) VMS_CARRY_STATE(7)
-        VMS_CARRY_STATE(8) VMS_CARRY_STATE(9) VMS_CARRY_STATE(10) VMS_CARRY_STATE(11)
-        VMS_CARRY_STATE(12) VMS_CARRY_STATE(13) VMS_CARRY_STATE(14) VMS_CARRY_STATE(15)
+        VMS_CARRY_STATE(0, rcA, rcB) VMS_CARRY_STATE(1, rcB, rcA) VMS_CARRY_STATE(2, rcA, rcB) VMS_CARRY_STATE(3, rcB, rcA)
+        VMS_CARRY_STATE(4, rcA, rcB) VMS_CARRY_STATE(5, rcB, rcA) VMS_CARRY_STATE(6, rcA, rcB) VMS_CARRY_STATE(7, rcB, rcA)
+        VMS_CARRY_STATE(8, rcA, rcB) VMS_CARRY_STATE(9, rcB, rcA) VMS_CARRY_STATE(10, rcA, rcB) VMS_CARRY_STATE(11, rcB, rcA)
+        VMS_CARRY_STATE(12, rcA, rcB) VMS_CARRY_STATE(13, rcB, rcA) VMS_CARRY_STATE(14, rcA, rcB) VMS_CARRY_STATE(15, rcB, rcA)
 #undef VMS_CARRY_STATE
 #undef VMS_EL
     }
