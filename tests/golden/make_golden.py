@@ -231,6 +231,40 @@ def gen_block(mods, name, which, d_model=32, L=33, batch=2, expand=2, d_state=8,
     save(name, x=npf(x), y=npf(y), g=npf(g), dx=npf(x.grad), **arrs)
 
 
+def gen_stack(mods, name, norm="ln", residual_in_fp32=False, n_layers=3, d_model=32, L=37, batch=2, seed=0):
+    """A stack of the reference's own Block (mamba_simple.py:381-437, fused_add_norm=False: no Triton) around its ViM
+    mixer (use_fast_path=False), closed the way the suite's backbones close it (final add + norm_f).  norm = "ln":
+    nn.LayerNorm; "rms": the RMSNorm stand-in of load_reference_modules (the math of rms_norm_ref)."""
+    from functools import partial
+    torch.random.manual_seed(seed)
+    ref = mods["simple"]
+    RMS = sys.modules["mamba_ssm.ops.triton.layernorm"].RMSNorm
+    norm_cls = partial(torch.nn.LayerNorm, eps=1e-5) if norm == "ln" else partial(RMS, eps=1e-5)
+    mixer_cls = partial(ref.Mamba, d_state=8, d_conv=4, expand=2, bimamba_type="v2", use_fast_path=False)
+    layers = torch.nn.ModuleList([ref.Block(d_model, mixer_cls, norm_cls=norm_cls, fused_add_norm=False,
+                                            residual_in_fp32=residual_in_fp32) for _ in range(n_layers)])
+    norm_f = norm_cls(d_model)
+    with torch.no_grad():
+        for k, p_ in list(layers.named_parameters()) + list(norm_f.named_parameters()):
+            if k.endswith("A_log") or k.endswith("A_b_log"):
+                p_.add_(0.3 * torch.randn_like(p_))
+            elif k.endswith(".D") or k.endswith(".D_b") or "norm" in k or k in ("weight", "bias"):
+                p_.add_(0.3 * torch.randn_like(p_))
+    x = torch.randn(batch, L, d_model).requires_grad_()
+    h, res = x, None
+    for blk in layers:
+        h, res = blk(h, res)
+    y = norm_f((h + res).to(norm_f.weight.dtype))
+    g = torch.randn_like(y)
+    y.backward(g)
+    arrs = {"sd.layers." + k: npf(v) for k, v in layers.state_dict().items()}
+    arrs.update({"sd.norm_f." + k: npf(v) for k, v in norm_f.state_dict().items()})
+    arrs.update({"grad.layers." + k: npf(p_.grad) for k, p_ in layers.named_parameters()})
+    arrs.update({"grad.norm_f." + k: npf(p_.grad) for k, p_ in norm_f.named_parameters()})
+    save(name, x=npf(x), y=npf(y), g=npf(g), dx=npf(x.grad), norm=np.array(norm),
+         residual_in_fp32=np.array(int(residual_in_fp32)), n_layers=np.array(n_layers), **arrs)
+
+
 def load_reference_norm_refs():
     """layer_norm_ref / rms_norm_ref (mamba/mamba_ssm/ops/triton/layernorm.py:19-48) without importing the
     module (its top imports triton, absent here): the two pure-PyTorch function definitions are taken out of
@@ -310,6 +344,12 @@ def main():
         gen_state_update(ref, "ssu_N64_noz", 2, 40, 64, True, False, True, True, seed=3)
         gen_state_update(ref, "ssu_N5_odd", 1, 9, 5, True, True, False, False, seed=4)
         return
+    if os.environ.get("GOLDEN_ONLY") == "stack":  # add the Block-stack fixtures without touching the others
+        cci, ssi = load_reference()
+        mods = load_reference_modules(ssi)
+        gen_stack(mods, "stack_ln", "ln", False, seed=11)
+        gen_stack(mods, "stack_rms_fp32res", "rms", True, seed=12)
+        return
     if os.environ.get("GOLDEN_ONLY") == "norm":  # add the norm fixtures without touching the others
         refs = load_reference_norm_refs()
         k = 0
@@ -373,6 +413,9 @@ def main():
     gen_block(mods, "block_vim_div", "simple", if_devide_out=True, L=257, batch=1)
     gen_block(mods, "block_vim_norm", "norm", if_devide_out=True)
     gen_block(mods, "block_dbm", "new", expand=1)
+    print("block stacks:")
+    gen_stack(mods, "stack_ln", "ln", False, seed=11)
+    gen_stack(mods, "stack_rms_fp32res", "rms", True, seed=12)
 
 
 if __name__ == "__main__":

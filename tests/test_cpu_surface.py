@@ -256,3 +256,26 @@ def test_projection_nodes_match_plain_autograd():
         torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
     assert got[0].stride(2) == 1   # (B, C, L) with a unit seqlen stride: what the scan backward reads
     assert _k_splits(8 * 8192) == 8 and _k_splits(197) == 1 and _k_splits(3 * 8192 + 8192 * 13) == 16
+
+
+@pytest.mark.parametrize("name", ["stack_ln", "stack_rms_fp32res"])
+@pytest.mark.parametrize("fused_add_norm", [False, True])
+def test_block_stack_host_logic(fake_extensions, name, fused_add_norm):
+    """Block.forward (reference mamba_simple.py:381-437) wired three deep + the closing add / norm_f, against the
+    fixture the reference's own Block produced: residual dtype, prenorm return order, eps, both add+norm forms."""
+    from conftest import build_stack
+    g = load_golden(name)
+    layers, norm_f, run = build_stack(g, fused_add_norm=fused_add_norm)
+    x = T(g["x"], grad=True)
+    y = run(x)
+    ref = T(g["y"])
+    assert y.dtype == ref.dtype
+    assert (y - ref).abs().max().item() <= 5e-4 * max(1.0, ref.abs().max().item())
+    y.backward(T(g["g"]))
+    ref_dx = T(g["dx"])
+    assert (x.grad - ref_dx).abs().max().item() <= 2e-3 * max(1.0, ref_dx.abs().max().item())
+    for prefix, mod in (("layers.", layers), ("norm_f.", norm_f)):
+        for k, p in mod.named_parameters():
+            rg = T(g["grad." + prefix + k])
+            err = (p.grad - rg).abs().max().item()
+            assert err <= 3e-3 * max(1.0, rg.abs().max().item()), (prefix + k, err, rg.abs().max().item())

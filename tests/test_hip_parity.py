@@ -696,6 +696,71 @@ def test_conv_deterministic_outputs():
         assert (db - outs[0][3]).abs().max() <= 1e-4 * outs[0][3].abs().max()
 
 
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("seqlen", [6144, 8191, 8192, 65536])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv_long_rows_vs_oracle(oracle, seqlen, itype, reverse, accumulate):
+    """Row lengths that take the 4-strips-per-wave kernels (seqlen >= 768 vectors: 6144 for 16-bit, 3072 for fp32;
+    conv_fwd/bwd_kernel<T, SILU, VEC, 4, DIR> -- what the benchmark at L = 8192 and the L = 65536 config launch),
+    in the layout the block uses: x = the first channel half of an xz buffer (batch stride 2 D L, SSI:175), dx
+    written into / accumulated onto the matching half of dxz.  Every element against the oracle; reverse = the
+    oracle on flipped copies; 8191 = ragged rows on the same kernels."""
+    import causal_conv1d_cuda
+    torch.manual_seed(seqlen % 1000 + 7 * reverse)
+    b, d = 2, 40
+    xz = torch.randn(b, 2 * d, seqlen, device=DEV).to(itype)
+    x = xz[:, :d]
+    w, bias = torch.randn(d, 4, device=DEV), torch.randn(d, device=DEV)
+    dout = torch.randn(b, d, seqlen, device=DEV).to(itype)
+    f = lambda t: t.detach().float().cpu().numpy()
+    fl = (lambda a: np.ascontiguousarray(a[..., ::-1])) if reverse else (lambda a: a)
+    tol = TOL[itype]
+    out = causal_conv1d_cuda.causal_conv1d_fwd(x, w, bias, True, reverse)
+    check(out, fl(oracle.conv_fwd(fl(f(x)), f(w), f(bias), True, prec="f64")), tol, "out")
+    dxz = torch.randn(b, 2 * d, seqlen, device=DEV).to(itype)
+    start = dxz.clone()
+    dx, dw, db = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, dxz[:, :d], True, reverse, accumulate_dx=accumulate)
+    assert dx.data_ptr() == dxz.data_ptr()
+    ob = oracle.conv_bwd(fl(f(x)), f(w), f(bias), fl(f(dout)), True, prec="f64")
+    want = fl(ob["dx"]) + (f(start[:, :d]) if accumulate else 0.0)
+    check(dx, want, tol, "dx")
+    assert torch.equal(dxz[:, d:], start[:, d:]), "the z half of dxz was touched"
+    check(dw, ob["dweight"], tol * 3, "dweight")
+    check(db, ob["dbias"], tol * 3, "dbias")
+
+
+@pytest.mark.parametrize("cfg", ["cfg2_8x1024x8192", "cfg5_1x768x65536"])
+def test_conv_full_size_block_layout(oracle, cfg):
+    """The conv launches of the benchmark itself ((8, 1024, 8192) bf16 inside a (8, 2048, 8192) xz buffer, both
+    directions, dx accumulated by the second direction as BiMambaInnerFnNoOutProj does) and of the long-video config
+    ((1, 768, 65536)): a spread of channels (rows are independent) against the oracle, all batches, so dweight / dbias
+    of those channels are checked too."""
+    import causal_conv1d_cuda
+    (b, d, L) = FULL_SIZES[cfg]
+    torch.manual_seed(1)
+    xz = torch.randn(b, 2 * d, L, device=DEV, dtype=torch.bfloat16)
+    x = xz[:, :d]
+    w, bias = torch.randn(d, 4, device=DEV), torch.randn(d, device=DEV)
+    dout = torch.randn(b, d, L, device=DEV, dtype=torch.bfloat16)
+    rows = [0, 1, 63, 64, d // 2 - 1, d // 2, d - 2, d - 1]
+    f = lambda t: t.detach().float().cpu().numpy()
+    dxz = torch.zeros_like(xz)
+    for reverse in (False, True):
+        fl = (lambda a: np.ascontiguousarray(a[..., ::-1])) if reverse else (lambda a: a)
+        out = causal_conv1d_cuda.causal_conv1d_fwd(x, w, bias, True, reverse)
+        check(out[:, rows], fl(oracle.conv_fwd(fl(f(x[:, rows])), f(w[rows]), f(bias[rows]), True, prec="f64")), 1e-2,
+              f"out rows reverse={reverse}")
+        before = f(dxz[:, rows])
+        dx, dw, db = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, dxz[:, :d], True, reverse,
+                                                          accumulate_dx=reverse)
+        ob = oracle.conv_bwd(fl(f(x[:, rows])), f(w[rows]), f(bias[rows]), fl(f(dout[:, rows])), True, prec="f64")
+        check(dx[:, rows], fl(ob["dx"]) + (before if reverse else 0.0), 1e-2, f"dx rows reverse={reverse}")
+        check(dw[rows], ob["dweight"], 3e-2, "dweight rows")
+        check(db[rows], ob["dbias"], 3e-2, "dbias rows")
+    assert float(dxz[:, d:].abs().max()) == 0.0
+
+
 # =================================================================================================
 # fused nodes and modules vs golden (reference CPU path)
 # =================================================================================================
@@ -751,6 +816,141 @@ def test_block_vs_golden(name, which, kw, fast):
     check(x.grad, g["dx"], 5e-3, "dx")
     for k, p in m.named_parameters():
         check(p.grad, g["grad." + k], 1e-2, "grad " + k)
+
+
+@pytest.mark.parametrize("name", ["stack_ln", "stack_rms_fp32res"])
+@pytest.mark.parametrize("fused_add_norm", [False, True])
+@pytest.mark.parametrize("fast", [True, False])
+def test_block_stack_vs_golden(name, fused_add_norm, fast):
+    """Three reference Blocks (Add -> Norm -> ViM mixer, mamba_simple.py:381-437) + the closing add / norm_f, from the
+    fixture the reference's own Block class produced on CPU: the fused add+norm HIP kernels (prenorm,
+    residual_in_fp32) and the unfused form, through the one-node mixer and the unfused mixer."""
+    from conftest import build_stack
+    g = load_golden(name)
+    layers, norm_f, run = build_stack(g, device=DEV, fused_add_norm=fused_add_norm, use_fast_path=fast)
+    x = G(g["x"], grad=True)
+    y = run(x)
+    check(y, g["y"], 2e-3, "y")
+    y.backward(G(g["g"]))
+    check(x.grad, g["dx"], 5e-3, "dx")
+    for prefix, mod in (("layers.", layers), ("norm_f.", norm_f)):
+        for k, p in mod.named_parameters():
+            check(p.grad, g["grad." + prefix + k], 1e-2, "grad " + prefix + k)
+
+
+def _vim_torch_reference(m, h):
+    """The ViM block written with torch ops only (F.conv1d, F.linear, selective_scan_ref's L-step recurrence), the way
+    the reference's slow path composes it (mamba_simple.py:201-290 with use_fast_path=False and the flips of :244,
+    :258): the full-size check's independent statement of the block."""
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_ref
+    import torch.nn.functional as F
+    Bt, L, _ = h.shape
+    d, R, N = m.d_inner, m.dt_rank, m.d_state
+    xz = F.linear(h, m.in_proj.weight, m.in_proj.bias).transpose(1, 2)
+
+    def direction(xz_, sfx):
+        conv, xp, dtp = getattr(m, "conv1d" + sfx), getattr(m, "x_proj" + sfx), getattr(m, "dt_proj" + sfx)
+        x, z = xz_.chunk(2, dim=1)
+        x = F.silu(F.conv1d(x, conv.weight, conv.bias, padding=m.d_conv - 1, groups=d)[..., :L])
+        x_dbl = F.linear(x.transpose(1, 2), xp.weight)
+        dt, Bm, Cm = torch.split(x_dbl, [R, N, N], dim=-1)
+        delta = F.linear(dt, dtp.weight).transpose(1, 2)
+        A = -torch.exp(getattr(m, "A" + sfx + "_log").float())
+        return selective_scan_ref(x, delta, A, Bm.transpose(1, 2).contiguous(), Cm.transpose(1, 2).contiguous(),
+                                  getattr(m, "D" + sfx).float(), z=z, delta_bias=dtp.bias.float(), delta_softplus=True)
+    y = direction(xz, "") + direction(xz.flip(-1), "_b").flip(-1)
+    return F.linear(y.transpose(1, 2), m.out_proj.weight, m.out_proj.bias)
+
+
+def test_block_L8192_fp32_vs_torch_reference():
+    """The benchmark's block shape (d_model 1024, expand 1, L = 8192; batch 2 to bound the reference's L-step
+    autograd graph) in fp32 against the torch-only statement of the block: output and every gradient at the fp32 bar."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(1024, expand=1, bimamba_type="v2").to(DEV)
+    h = torch.randn(2, 8192, 1024, device=DEV, requires_grad=True)
+    g = torch.randn(2, 8192, 1024, device=DEV)
+    y = m(h)
+    got = torch.autograd.grad(y, [h] + list(m.parameters()), g)
+    yr = _vim_torch_reference(m, h)
+    want = torch.autograd.grad(yr, [h] + list(m.parameters()), g)
+    check(y, yr.detach().cpu().numpy(), 1e-3, "y")
+    names = ["dh"] + [k for k, _ in m.named_parameters()]
+    for k, a, b_ in zip(names, got, want):
+        check(a, b_.cpu().numpy(), 1e-3 if k == "dh" else 5e-3, "grad " + k)
+
+
+def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
+    """configs[1] exactly as bench.py runs it: Mamba(1024, expand=1, "v2") at (8, 8192) under autocast(bf16), forward +
+    backward.  (a) the one-node reverse-kernel path == the reference's form (flipped copies through the causal ops,
+    conv_out / delta recomputed in backward: VMS_NO_REVERSE=1, VMS_CHECKPOINT_LVL=1); (b) the stages of the path, run
+    with the public ops on the block's own tensors, against the oracle on sampled rows: conv (both directions) and the
+    scan given (delta, B, C) (both directions); (c) the composition of those ops == the fused block output."""
+    import mamba_ssm.modules._core as core
+    from causal_conv1d import causal_conv1d_fn
+    from mamba_ssm.modules.mamba_simple import Mamba
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    torch.manual_seed(0)
+    m = Mamba(1024, expand=1, bimamba_type="v2").to(DEV)
+    with torch.no_grad():  # move A / D off their deterministic init
+        for k, p in m.named_parameters():
+            if k.endswith("_log"):
+                p.add_(0.3 * torch.randn_like(p))
+            elif k in ("D", "D_b"):
+                p.add_(0.5 * torch.randn_like(p))
+    h = torch.randn(8, 8192, 1024, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    gout = torch.randn(8, 8192, 1024, device=DEV, dtype=torch.bfloat16)
+    params = list(m.parameters())
+    names = ["dh"] + [k for k, _ in m.named_parameters()]
+
+    def run():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(h)
+        return y, torch.autograd.grad(y, [h] + params, gout)
+    assert core._USE_REVERSE_KERNELS and core._CHECKPOINT_LVL == 0
+    y1, g1 = run()
+    monkeypatch.setattr(core, "_USE_REVERSE_KERNELS", False)
+    monkeypatch.setattr(core, "_CHECKPOINT_LVL", 1)
+    y2, g2 = run()
+    monkeypatch.undo()
+    check(y1, y2.float().cpu().numpy(), 1e-2, "y: one node vs reference form")
+    for k, a, b_ in zip(names, g1, g2):
+        check(a, b_.float().cpu().numpy(), 1e-2 if k == "dh" else 2e-2, f"grad {k}: one node vs reference form")
+
+    # (b) stage by stage against the oracle, on the tensors of this very block
+    f = lambda t: t.detach().float().cpu().numpy()
+    rows = [0, 1, 511, 512, 1022, 1023]
+    d, R, N, L = m.d_inner, m.dt_rank, m.d_state, 8192
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        xz = m._in_projection(h)
+        x, z = xz[:, :d], xz[:, d:]
+        ys = []
+        for sfx, rev in (("", False), ("_b", True)):
+            fl = (lambda a: np.ascontiguousarray(a[..., ::-1])) if rev else (lambda a: a)
+            conv, xp, dtp = getattr(m, "conv1d" + sfx), getattr(m, "x_proj" + sfx), getattr(m, "dt_proj" + sfx)
+            cw, cb = conv.weight.squeeze(1).float(), conv.bias.float()
+            xc = causal_conv1d_cuda.causal_conv1d_fwd(x, cw, cb, True, rev)
+            for bi in (0, 7):
+                o = oracle.conv_fwd(fl(f(x[bi:bi + 1, rows])), f(cw[rows]), f(cb[rows]), True, prec="f64")
+                check(xc[bi:bi + 1, rows], fl(o), 1e-2, f"conv{sfx} rows batch {bi}")
+            x_dbl = torch.nn.functional.linear(xc.transpose(1, 2), xp.weight.to(torch.bfloat16))     # (b, l, R + 2N)
+            delta = torch.nn.functional.linear(x_dbl[..., :R], dtp.weight.to(torch.bfloat16)).transpose(1, 2).contiguous()
+            Bm = x_dbl[..., R:R + N].transpose(1, 2).contiguous()[:, None]
+            Cm = x_dbl[..., R + N:].transpose(1, 2).contiguous()[:, None]
+            A = -torch.exp(getattr(m, "A" + sfx + "_log").float())
+            Dv, bias = getattr(m, "D" + sfx).float(), dtp.bias.float()
+            out, _, out_z = selective_scan_cuda.fwd(xc, delta, A, Bm, Cm, Dv, z, bias, True, rev)
+            for bi in (0, 7):
+                sl = (slice(bi, bi + 1), rows)
+                o = oracle.scan_fwd(fl(f(xc[sl])), fl(f(delta[sl])), f(A[rows]), fl(f(Bm[bi:bi + 1])), fl(f(Cm[bi:bi + 1])),
+                                    f(Dv[rows]), fl(f(z[sl])), f(bias[rows]), True, prec="f64")
+                check(out_z[sl], fl(o["out_z"]), 1e-2, f"scan{sfx} rows batch {bi}")
+            ys.append(out_z)
+        yc = torch.nn.functional.linear((ys[0].float() + ys[1].float()).to(torch.bfloat16).transpose(1, 2),
+                                        m.out_proj.weight.to(torch.bfloat16))
+    check(y1, yc.float().cpu().numpy(), 1e-2, "fused block vs composition of the checked stages")
 
 
 def test_block_bf16_autocast_runs_and_matches_fp32():
