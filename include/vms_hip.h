@@ -26,11 +26,17 @@
  *   - plain C: POD parameter blocks, raw device pointers, sizes; no torch types.
  *   - every stride is in ELEMENTS of the tensor's own dtype and 64-bit (the
  *     reference stores 32-bit strides, selective_scan.h:27).
- *   - the library never allocates, never synchronises and keeps no state: all
- *     outputs (and accumulators that must start at zero, marked [zeroed]) are
- *     provided by the caller, exactly the tensors the reference host functions
- *     allocate.  Calls are re-entrant and are enqueued on `stream`
- *     (a hipStream_t passed as void*; NULL = the null stream).
+ *   - the library never allocates, never synchronises, reads no environment
+ *     variable and keeps no mutable state: all outputs (and accumulators that must
+ *     start at zero, marked [zeroed]) are provided by the caller, exactly the
+ *     tensors the reference host functions allocate; every choice a call makes
+ *     follows from its parameter block.  What it caches is immutable per-device
+ *     information, filled once per device under std::call_once (the CU count,
+ *     and the one-time hipFuncSetAttribute that admits > 64 KB of dynamic LDS).
+ *     Calls are re-entrant from any number of host threads, on any device (the
+ *     current device of the calling thread, as for the reference's extensions,
+ *     selective_scan.cpp:326-327) and are enqueued on `stream` (a hipStream_t
+ *     passed as void*; NULL = the null stream).
  *   - return value: VMS_OK or a negative vms_status; vms_last_error() gives a
  *     thread-local message naming the failed check (the reference raises
  *     RuntimeError from TORCH_CHECK with the failing expression).
@@ -44,7 +50,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 3
+#define VMS_ABI_VERSION 4
 
 typedef enum {
     VMS_OK = 0,
@@ -54,6 +60,15 @@ typedef enum {
 } vms_status;
 
 typedef enum { VMS_F32 = 0, VMS_F16 = 1, VMS_BF16 = 2 } vms_dtype;
+
+/* kernel generations of the selective scan: a call runs the highest one that is <= `impl`, built into this
+ * library (vms_build_flags) and eligible for the problem; AUTO = PAIR.  GENERIC takes every problem the
+ * reference takes; the others are fast paths (variable B / C, dstate 16, ...).  FAST, ROWS and the MFMA
+ * backward are experiments kept for tests and profiling, present only in a `make EXPERIMENTAL=1` build. */
+typedef enum {
+    VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_FAST = 2, VMS_IMPL_PAIR = 3, VMS_IMPL_ROWS = 4
+} vms_scan_impl;
+#define VMS_BUILD_EXPERIMENTAL 1   /* bit of vms_build_flags(): the FAST / ROWS / MFMA generations are built in */
 
 /* ---- selective scan ------------------------------------------------------------------
  * u, delta, z, out, out_z : (batch, dim, seqlen), unit seqlen stride, free batch/dim strides
@@ -114,6 +129,11 @@ typedef struct {
      * that chain them (vms_scan_bwd_workspace_bytes() > 0 exactly when it wants to split). */
     void *workspace;
     int64_t workspace_bytes;
+    /* ABI v4: the knobs that used to be environment variables read inside the library.  impl: one of vms_scan_impl, 0 = the
+     * default.  segments: 0 = the library decides whether to split long rows of a small grid into ranges of chunks
+     * (from the device's CU count); n >= 1 forces n ranges (1 = never split) -- tests and profiling. */
+    int32_t impl;
+    int32_t segments;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).
@@ -250,6 +270,11 @@ int vms_selective_state_update(const vms_state_update_params *p, void *stream);
 /* ---- misc ---------------------------------------------------------------------------- */
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
+/* thread-local: the kernel family the last successful launch call of this thread enqueued, e.g. "scan_fwd_pair",
+ * "scan_bwd_pair+split", "scan_fwd_generic", "conv_fwd_strips4", "conv_bwd_strips1", "conv_fwd_channel_last" --
+ * lets a caller (and the tests) see when a problem was declined by a fast path */
+const char *vms_last_kernel(void);
+int vms_build_flags(void);              /* VMS_BUILD_* bits */
 /* sizes of the parameter blocks as compiled, so a binding can verify its mirror */
 int vms_sizeof_scan_fwd_params(void);
 int vms_sizeof_scan_bwd_params(void);

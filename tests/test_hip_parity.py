@@ -35,6 +35,14 @@ def check(a, ref, tol, what):
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
 
 
+def need_impl(impl):
+    """The FAST / ROWS / MFMA kernel generations exist only in a `make EXPERIMENTAL=1` library (vms_hip.h)."""
+    import vms_hip
+    if impl in ("rows", "fast") and not vms_hip.has_experimental():
+        pytest.skip("needs the experimental kernel generations: make -C video-mamba-suite_amd/csrc EXPERIMENTAL=1 "
+                    "OUT=../vms_hip/libvms_hip_exp.so and VMS_HIP_LIB=<that file>")
+
+
 def itype_of(g):
     s = str(g.get("itype", "torch.float32"))
     return torch.bfloat16 if "bfloat16" in s else (torch.float16 if "float16" in s else torch.float32)
@@ -189,6 +197,7 @@ def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
     agreement with the generic kernels on the same inputs."""
     import selective_scan_cuda
     import vms_hip
+    need_impl("rows")
     monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
     g = _rows_problem(shape, itype, has_z)
     tol = TOL[itype]
@@ -214,6 +223,7 @@ def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
 def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     """reverse=True == flip(fwd(flip(every seqlen-indexed tensor))) for every forward implementation."""
     import selective_scan_cuda
+    need_impl(impl)
     monkeypatch.setenv("VMS_SCAN_IMPL", impl)
     g = _rows_problem(shape, itype, True, seed=3)
     f = lambda k, dt=itype: G(g[k], dt)
@@ -344,6 +354,7 @@ def test_scan_bwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, r
 def test_scan_bwd_accumulates_dz(itype, impl, reverse, monkeypatch):
     """accumulate_dz (vms_hip.h dz_accumulate): dz += this call's gradient, in every backward kernel."""
     import selective_scan_cuda
+    need_impl(impl)
     monkeypatch.setenv("VMS_SCAN_IMPL", impl)
     g = _rows_problem((2, 64, 1160, 1), itype, True, seed=11)
     f = lambda k, dt=itype: G(g[k], dt)
@@ -371,6 +382,7 @@ def test_scan_fwd_accumulates_out_z(itype, impl, reverse, monkeypatch):
     """out_z_into (vms_hip.h out_z_accumulate): out_z += this call's gated output; out and x are unchanged.  With
     the rows kernels selected the call is served by the next eligible kernel."""
     import selective_scan_cuda
+    need_impl(impl)
     monkeypatch.setenv("VMS_SCAN_IMPL", impl)
     g = _rows_problem((2, 64, 1168, 1), itype, True, seed=13)
     f = lambda k, dt=itype: G(g[k], dt)
@@ -455,6 +467,7 @@ def test_scan_rows_checkpoint_region(oracle, monkeypatch):
     in the same allocation (include/vms_hip.h, x_has_sub == 2)."""
     import selective_scan_cuda
     import vms_hip
+    need_impl("rows")
     monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
     g = _rows_problem((2, 128, 2448, 2), torch.float32, True, seed=5)
     f = lambda k: G(g[k])
@@ -536,6 +549,83 @@ def test_scan_extension_error_behaviour():
         u2 = torch.randn(1, 4, L, device=DEV)
         B2 = torch.randn(1, 1, 8, L, device=DEV)
         selective_scan_cuda.bwd(u2, u2, A, B2, B2, None, None, None, u2, None, None, None, False, False)
+
+
+def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
+    """ABI v4: the library reads no environment; the binding turns VMS_SCAN_IMPL / VMS_*_SEGMENTS into the impl /
+    segments fields, and vms_last_kernel() names what ran -- so a declined fast path is visible to the caller."""
+    import selective_scan_cuda
+    import vms_hip
+    g = _rows_problem((1, 64, 16384, 1), torch.bfloat16, True)
+    f = lambda k, dt=torch.bfloat16: G(g[k], dt)
+    args = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32), f("z"),
+            f("delta_bias", torch.float32), True)
+    selective_scan_cuda.fwd(*args)
+    assert vms_hip.last_kernel() == "scan_fwd_pair+split"       # 64 rows: fewer waves than SIMDs -> ranges of chunks
+    monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+    out, x, _ = selective_scan_cuda.fwd(*args)
+    assert vms_hip.last_kernel() == "scan_fwd_pair"
+    selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
+    assert vms_hip.last_kernel().startswith("scan_bwd_pair")
+    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    out, x, _ = selective_scan_cuda.fwd(*args)
+    assert vms_hip.last_kernel() == "scan_fwd_generic"
+    selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
+    assert vms_hip.last_kernel() == "scan_bwd_generic"
+    monkeypatch.delenv("VMS_SCAN_IMPL")
+    # dstate 8 is outside the fast paths: the generic kernels take it, and say so
+    A8 = -torch.rand(64, 8, device=DEV)
+    B8 = torch.randn(1, 1, 8, 16384, device=DEV, dtype=torch.bfloat16)
+    selective_scan_cuda.fwd(args[0], args[1], A8, B8, B8, None, None, None, True)
+    assert vms_hip.last_kernel() == "scan_fwd_generic"
+
+
+def test_c_abi_is_reentrant_across_threads_and_streams(oracle):
+    """Two host threads, each with its own stream, call the C ABI concurrently (forward + backward of the paired scan
+    kernels -- the backward needs its > 64 KB LDS attribute, set under std::call_once per device -- and the conv): the
+    results equal the single-threaded ones bit for bit where the kernels are deterministic (out, du, ddelta, dz, conv
+    out / dx).  This is how the reference's nn.DataParallel callers drive the extension (train_eval.py:76: one
+    autograd thread per device)."""
+    import threading
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    problems = []
+    for seed in (1, 2):
+        g = _rows_problem((2, 64, 2048, 1), torch.bfloat16, True, seed=seed)
+        f = lambda k, dt=torch.bfloat16: G(g[k], dt)
+        problems.append((f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32), f("z"),
+                         f("delta_bias", torch.float32), f("g")))
+
+    def work(pr):
+        u, dl, A, B, C, D, z, bias, dout = pr
+        out, x, oz = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True)
+        res = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False)
+        w = A[:, :4].contiguous()
+        y = causal_conv1d_cuda.causal_conv1d_fwd(u, w, bias, True)
+        dx = causal_conv1d_cuda.causal_conv1d_bwd(u, w, bias, dout, None, True)[0]
+        return [oz, res[0], res[1], res[7], y, dx]
+    want = [work(pr) for pr in problems]
+    torch.cuda.synchronize()
+    got, errs = [None, None], []
+
+    def runner(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    got[i] = work(problems[i])
+            s.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=runner, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for a, b_ in zip(got[i], want[i]):
+            assert torch.equal(a, b_)
 
 
 # BASELINE.json configs at full size: [1] block shape, [2] TimeMamba-B tokens, [3] DBM feature sequence,
@@ -716,12 +806,14 @@ def test_conv_long_rows_vs_oracle(oracle, seqlen, itype, reverse, accumulate):
     f = lambda t: t.detach().float().cpu().numpy()
     fl = (lambda a: np.ascontiguousarray(a[..., ::-1])) if reverse else (lambda a: a)
     tol = TOL[itype]
+    import vms_hip
     out = causal_conv1d_cuda.causal_conv1d_fwd(x, w, bias, True, reverse)
+    assert vms_hip.last_kernel() == "conv_fwd_strips4"
     check(out, fl(oracle.conv_fwd(fl(f(x)), f(w), f(bias), True, prec="f64")), tol, "out")
     dxz = torch.randn(b, 2 * d, seqlen, device=DEV).to(itype)
     start = dxz.clone()
     dx, dw, db = causal_conv1d_cuda.causal_conv1d_bwd(x, w, bias, dout, dxz[:, :d], True, reverse, accumulate_dx=accumulate)
-    assert dx.data_ptr() == dxz.data_ptr()
+    assert dx.data_ptr() == dxz.data_ptr() and vms_hip.last_kernel() == "conv_bwd_strips4"
     ob = oracle.conv_bwd(fl(f(x)), f(w), f(bias), fl(f(dout)), True, prec="f64")
     want = fl(ob["dx"]) + (f(start[:, :d]) if accumulate else 0.0)
     check(dx, want, tol, "dx")

@@ -15,7 +15,7 @@
 //     with a register sliding window; consecutive lanes = consecutive channels (coalesced).
 //   * widths 2..4 are run as a 4-tap filter whose leading taps are zero.
 //   * dweight / dbias: per-lane partial sums -> DPP wave reduction -> fp32 atomics.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 
@@ -512,7 +512,9 @@ static int conv_fwd_dispatch(const vms_conv_fwd_params& p, hipStream_t s) {
 #undef VMS_L
 #undef VMS_D
 #undef VMS_K
+        set_last_kernel(!full ? "conv_fwd_generic" : (nv == 4 ? "conv_fwd_strips4" : "conv_fwd_strips1"));
     } else {
+        set_last_kernel("conv_fwd_channel_last");
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
         VMS_CHECK(p.out_c_stride == 1, "channel-last x needs a channel-last out");
         VMS_CHECK(aligned16(p.x) && aligned16(p.out) && mult16(p.x_batch_stride, es) && mult16(p.x_l_stride, es) &&
@@ -555,7 +557,9 @@ static int conv_bwd_dispatch(const vms_conv_bwd_params& q, hipStream_t s) {
 #undef VMS_L
 #undef VMS_D
 #undef VMS_K
+        set_last_kernel(!full ? "conv_bwd_generic" : (nv == 4 ? "conv_bwd_strips4" : "conv_bwd_strips1"));
     } else {
+        set_last_kernel("conv_bwd_channel_last");
         VMS_CHECK(p.dim % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
         VMS_CHECK(q.dout_c_stride == 1 && q.dx_c_stride == 1, "channel-last x needs channel-last dout and dx");
         VMS_CHECK(aligned16(p.x) && aligned16(q.dout) && aligned16(q.dx) && mult16(p.x_batch_stride, es) &&

@@ -14,7 +14,7 @@
 // registers over the rows it walks and written as one partial row per wave; the caller sums the partials
 // (the reference does the same with one partial per SM, layernorm.py:316-375).
 // Weight and bias are fp32 (the Python layer widens them: `cols` elements).
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 

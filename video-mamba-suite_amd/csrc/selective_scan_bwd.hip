@@ -16,13 +16,12 @@
 //   * dA, dD, ddelta_bias, constant-B/C gradients: wave reduction, one atomic per row.
 #include <stdlib.h>
 
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 
 int validate_scan_common(const vms_scan_fwd_params& p);
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
-int scan_impl_knob();
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream);
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q);
@@ -302,7 +301,7 @@ static int launch_bwd(const vms_scan_bwd_params& q, bool vec, hipStream_t stream
     const int tiles = (p.dim + kBwdRows - 1) / kBwdRows;
     dim3 grid(p.batch * tiles), block(kBwdRows * kWave);
     const size_t smem = sizeof(float) * (4 * K * kTilePad + kBwdRows * 5 * p.dstate);
-    static const int dbg = getenv("VMS_DEBUG") ? atoi(getenv("VMS_DEBUG")) : 0;  // profiling knob
+    const int dbg = 0;  // ablation bits of the kernel (profiling builds only)
     if (vec)
         hipLaunchKernelGGL((scan_bwd_kernel<T, K, VB, VC, HZ, true>), grid, block, smem, stream, q, dbg);
     else
@@ -335,7 +334,7 @@ using namespace vms;
 // scratch the paired kernel wants when it splits the sequence into ranges (few rows, long sequences): the (P, q)
 // adjoint carries of selective_scan_bwd_pair.hip; 0 = no scratch needed for this problem
 extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
-    if (q == nullptr || scan_impl_knob() < 2 || !scan_bwd_pair_eligible(*q, true)) return 0;
+    if (q == nullptr || scan_impl_level(q->f) < VMS_IMPL_PAIR || !scan_bwd_pair_eligible(*q, true)) return 0;
     return scan_bwd_pair_segments(*q) > 1 ? scan_bwd_pair_ws_bytes(*q) : 0;
 }
 
@@ -358,9 +357,16 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
                mult16(q.du_d_stride, es) && mult16(q.ddelta_batch_stride, es) && mult16(q.ddelta_d_stride, es);
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int knob = scan_impl_knob();
-    if (knob >= 2 && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
-    if (knob >= 1 && !p.reverse && scan_bwd_mfma_eligible(q, vec)) return launch_scan_bwd_mfma(q, s);
+    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
+    const int level = scan_impl_level(p);
+    if (level >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
+#ifdef VMS_EXPERIMENTAL
+    if (level >= VMS_IMPL_FAST && !p.reverse && scan_bwd_mfma_eligible(q, vec)) {
+        set_last_kernel("scan_bwd_mfma");
+        return launch_scan_bwd_mfma(q, s);
+    }
+#endif
+    set_last_kernel("scan_bwd_generic");
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);
         case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);

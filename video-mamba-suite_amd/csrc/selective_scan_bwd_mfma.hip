@@ -29,7 +29,7 @@
 //   * per-(row, state) carries (adjoint entering from the right, a of the next chunk's first
 //     element, dA accumulator) live in ONE register each: lane j of a row keeps the value of
 //     state n = j and hands it out with ds_bpermute (prefetched one state ahead).
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 
@@ -425,15 +425,20 @@ static int launch_mfma(const vms_scan_bwd_params& q, hipStream_t stream) {
     dim3 grid(p.batch * tiles), block(kMQ * NSPLIT * kWave);
     // slabs (+ du/ddelta exchange between the state halves)
     const size_t smem = 16 * (kMQ * NSPLIT * kMSG * 2 * (4 * kMK) + (NSPLIT == 2 ? kMQ * 4 * 64 : 0));
-    // 96 KB of dynamic LDS: above the 64 KB default limit, must be allowed per kernel (once)
-    static const bool attr_set = [&] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_mfma_kernel<T, true, NSPLIT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_mfma_kernel<T, false, NSPLIT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        return true;
-    }();
-    (void)attr_set;
+    // 96 KB of dynamic LDS: above the 64 KB default limit, must be allowed per kernel and per device
+    static PerDeviceOnce attr_once;
+    const hipError_t arc = attr_once.run([&]() -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_mfma_kernel<T, true, NSPLIT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_mfma_kernel<T, false, NSPLIT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        return e;
+    });
+    if (arc != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(arc));
+        return VMS_ERR_LAUNCH;
+    }
     if (p.z) hipLaunchKernelGGL((scan_bwd_mfma_kernel<T, true, NSPLIT>), grid, block, smem, stream, q);
     else hipLaunchKernelGGL((scan_bwd_mfma_kernel<T, false, NSPLIT>), grid, block, smem, stream, q);
     VMS_LAUNCH_CHECK();

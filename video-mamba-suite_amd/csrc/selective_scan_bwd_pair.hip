@@ -24,7 +24,7 @@
 // du / ddelta are accumulated as S1_i = sum_n g B, S2_i = sum_n A g a x_{i-1} and combined once per chunk;
 // the lane aggregates' "a" components come from exp2(A * sum(delta)) instead of running products.
 // `reverse` (vms_hip.h) is supported: the lane's 8 logical elements are read / written right-to-left.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 
@@ -653,23 +653,24 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_sc
 }
 
 // how many ranges of chunks the backward is split into (1 = not split): enough to give every CU two workgroups,
-// at least 8 chunks (1024 elements) per range; VMS_BWD_SEGMENTS forces a count (tests)
+// at least 8 chunks (1024 elements) per range; q.f.segments >= 1 forces a count (vms_hip.h)
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
     const vms_scan_fwd_params& p = q.f;
     if (p.seqlen % kBK != 0) return 1;
     const int n_c = (p.seqlen + kCH - 1) / kCH;
     const int n_wg = p.batch * ((p.dim + kBRows - 1) / kBRows);
     int want;
-    if (const char* e = getenv("VMS_BWD_SEGMENTS")) {
-        want = atoi(e);
+    if (p.segments >= 1) {
+        want = p.segments;
     } else {
-        // run time ~ rounds of workgroups over the 256 CUs (one workgroup per CU) x range length, + ~25 % for the
+        // run time ~ rounds of workgroups over the CUs (one workgroup per CU) x range length, + ~25 % for the
         // carry pass: take the count that minimises it, and split only for a clear win
+        const int cus = device_cu_count();
         const int most = n_c / 8 < 16 ? n_c / 8 : 16;
-        double best = 1.0 * ((n_wg + 255) / 256);
+        double best = 1.0 * ((n_wg + cus - 1) / cus);
         want = 1;
         for (int s = 2; s <= most; ++s) {
-            const double cost = 1.25 * ((n_wg * s + 255) / 256) / s;
+            const double cost = 1.25 * ((n_wg * s + cus - 1) / cus) / s;
             if (cost < 0.9 * best) { best = cost; want = s; }
         }
     }
@@ -711,15 +712,23 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const int tiles = (p.dim + kBRows - 1) / kBRows;
     dim3 grid(p.batch * tiles), block(kBQ * kWave);
     const size_t smem = sizeof(float) * (kBcFloats + 2 * kSlabFloats + kBRows * kBN * 4);  // 16 KB + 2 x 64 KB + 8 KB
-    static bool once = false;  // more than the default 64 KB of LDS per workgroup
-    if (!once) {
-        once = true;
+    // more than the default 64 KB of LDS per workgroup: admitted per kernel AND per device, before the first launch there
+    static PerDeviceOnce attr_once;
+    const hipError_t arc = attr_once.run([&]() -> hipError_t {
+        hipError_t e = hipSuccess;
+#define VMS_A2(Z_, R_, G_)                                                                                               \
+        if (e == hipSuccess)                                                                                             \
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair_kernel<T, Z_, R_, G_>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
 #define VMS_A(Z_, R_) VMS_A2(Z_, R_, true); VMS_A2(Z_, R_, false)
-#define VMS_A2(Z_, R_, G_) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair_kernel<T, Z_, R_, G_>), \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
         VMS_A(true, true); VMS_A(true, false); VMS_A(false, true); VMS_A(false, false);
 #undef VMS_A
 #undef VMS_A2
+        return e;
+    });
+    if (arc != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", (int)smem, hipGetErrorString(arc));
+        return VMS_ERR_LAUNCH;
     }
     const bool rag = p.seqlen % kBK != 0;
     int n_seg = 1;
@@ -745,6 +754,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
+    set_last_kernel(n_seg > 1 ? "scan_bwd_pair+split" : (rag ? "scan_bwd_pair_ragged" : "scan_bwd_pair"));
     return VMS_OK;
 }
 

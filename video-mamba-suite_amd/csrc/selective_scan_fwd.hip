@@ -16,20 +16,9 @@
 #include <stdlib.h>
 #include <stdio.h>
 
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
-
-namespace {
-thread_local char g_err[512] = "";
-}
-void set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-}
-const char* last_error() { return g_err; }
 
 constexpr int kRowsPerWG = 4;
 
@@ -200,19 +189,6 @@ int scan_fwd_pair_segments(const vms_scan_fwd_params& p);
 int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
 
-// which implementations a call may use: VMS_SCAN_IMPL = generic (0) | fast (1) | pair (2) | rows (3), a
-// test / profiling knob read per call; every level also allows the ones below it.  Unset = pair: the
-// row-major kernels are an experiment that is slower than the paired lane-per-position kernels.
-int scan_impl_knob() {
-    const char* e = getenv("VMS_SCAN_IMPL");
-    if (getenv("VMS_FORCE_GENERIC") != nullptr) return 0;
-    if (e == nullptr) return 2;
-    if (e[0] == 'g') return 0;
-    if (e[0] == 'f') return 1;
-    if (e[0] == 'p') return 2;
-    return 3;
-}
-
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
     const int es = p.dtype == VMS_F32 ? 4 : 2;
     bool ok = aligned16(p.u) && aligned16(p.delta) && aligned16(p.out) && mult16(p.u_batch_stride, es) &&
@@ -243,17 +219,29 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     VMS_CHECK(!p.out_z_accumulate || p.z != nullptr, "out_z_accumulate needs z / out_z");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
-    const int knob = scan_impl_knob();
+    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
+    const int level = scan_impl_level(p);
+#ifdef VMS_EXPERIMENTAL
     if (p.x_has_sub == 2) {
         // the caller laid x out for the row-major kernels: nothing else fills its checkpoint region
-        VMS_CHECK(knob >= 3 && vec && scan_rows_eligible(p), "x_has_sub == 2 needs a problem the rows kernels accept");
+        VMS_CHECK(level >= VMS_IMPL_ROWS && vec && scan_rows_eligible(p), "x_has_sub == 2 needs a problem the rows kernels accept");
         VMS_CHECK(p.x_chunk_stride == 0 || p.x_chunk_stride == 2 * p.dstate, "x_has_sub == 2 needs a dense x");
         VMS_CHECK(p.workspace != nullptr && aligned16(p.workspace) && p.workspace_bytes >= scan_rows_fwd_ws_bytes(p),
                   "workspace of vms_scan_fwd_workspace_bytes() bytes is required with x_has_sub == 2");
+        set_last_kernel("scan_fwd_rows");
         return launch_scan_fwd_rows(p, s);
     }
-    if (knob >= 2 && scan_fwd_pair_eligible(p, vec)) return launch_scan_fwd_pair(p, s);
-    if (knob >= 1 && scan_fwd_fast_eligible(p, vec)) return launch_scan_fwd_fast(p, s);
+#else
+    VMS_CHECK(p.x_has_sub != 2, "x_has_sub == 2 (rows layout) needs a library built with EXPERIMENTAL=1");
+#endif
+    if (level >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, vec)) return launch_scan_fwd_pair(p, s);
+#ifdef VMS_EXPERIMENTAL
+    if (level >= VMS_IMPL_FAST && scan_fwd_fast_eligible(p, vec)) {
+        set_last_kernel("scan_fwd_fast");
+        return launch_scan_fwd_fast(p, s);
+    }
+#endif
+    set_last_kernel("scan_fwd_generic");
     switch (p.dtype) {
         case VMS_F32: return dispatch_fwd<float, 16>(p, vec, s);
         case VMS_F16: return dispatch_fwd<f16_t, 16>(p, vec, s);
@@ -263,21 +251,20 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
-    if (scan_impl_knob() >= 3 && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return scan_rows_fwd_ws_bytes(*p);
+    const int level = scan_impl_level(*p);
+#ifdef VMS_EXPERIMENTAL
+    if (level >= VMS_IMPL_ROWS && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return scan_rows_fwd_ws_bytes(*p);
+#endif
     // the paired kernel's (P, q) state carries when it wants to split long rows into ranges
-    if (scan_impl_knob() >= 2 && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_segments(*p) > 1)
+    if (level >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_segments(*p) > 1)
         return scan_fwd_pair_ws_bytes(*p);
     return 0;
 }
 extern "C" int64_t vms_scan_x_elems(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
     const int64_t ref = (int64_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
-    if (scan_impl_knob() < 3 || !scan_rows_eligible(*p) || !scan_fwd_vec_ok(*p)) return ref;
-    return ref + scan_rows_hck_elems(*p);
+#ifdef VMS_EXPERIMENTAL
+    if (scan_impl_level(*p) >= VMS_IMPL_ROWS && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return ref + scan_rows_hck_elems(*p);
+#endif
+    return ref;
 }
-extern "C" const char* vms_last_error(void) { return vms::last_error(); }
-extern "C" int vms_abi_version(void) { return VMS_ABI_VERSION; }
-extern "C" int vms_sizeof_scan_fwd_params(void) { return (int)sizeof(vms_scan_fwd_params); }
-extern "C" int vms_sizeof_scan_bwd_params(void) { return (int)sizeof(vms_scan_bwd_params); }
-extern "C" int vms_sizeof_conv_fwd_params(void) { return (int)sizeof(vms_conv_fwd_params); }
-extern "C" int vms_sizeof_conv_bwd_params(void) { return (int)sizeof(vms_conv_bwd_params); }

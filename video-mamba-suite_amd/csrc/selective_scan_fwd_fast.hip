@@ -18,7 +18,7 @@
 //     current state computes, and are widened to fp32 at the point of use;
 //   * loads are branch-free (seqlen % 16 == 0: a lane's 16 elements are all in range or all out),
 //     row addressing is a uniform base + one 32-bit offset.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 

@@ -14,7 +14,7 @@
 // doubles the cross-lane scan cost per element, and came out slower.)  Loads carry no select (a lane past the
 // end reads the row start and is neutralised through delta = 0), so that the prefetch of the next state's
 // B / C -- after the last state: of the next chunk's first state -- really stays in flight.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 
@@ -374,17 +374,18 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_car
     if (lane < N) seg_carry[(((int64_t)b * p.dim + d) * n_seg + seg) * N + lane] = float2{fast_exp2(A_mine * tot), hreg};
 }
 
-// ranges a forward is split into (1 = not split): only when the rows do not give every SIMD a wave; aims at ~2.5 waves
-// per SIMD, at least 4 chunks (4096 elements) per range; VMS_FWD_SEGMENTS forces a count (tests)
+// ranges a forward is split into (1 = not split): only when the rows do not give every SIMD a wave (4 SIMDs per CU);
+// aims at ~2.5 waves per SIMD, at least 4 chunks (4096 elements) per range; p.segments >= 1 forces a count (vms_hip.h)
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
     if (p.seqlen % kPK != 0) return 1;
     const int n_k = (p.seqlen + kWave * kPK - 1) / (kWave * kPK);
     const int64_t waves = (int64_t)p.batch * p.dim;
+    const int64_t simds = 4 * (int64_t)device_cu_count();
     int want = 1;
-    if (const char* e = getenv("VMS_FWD_SEGMENTS")) {
-        want = atoi(e);
-    } else if (waves <= 1024) {
-        want = (int)((2560 + waves - 1) / waves);
+    if (p.segments >= 1) {
+        want = p.segments;
+    } else if (waves <= simds) {
+        want = (int)((simds * 5 / 2 + waves - 1) / waves);
         if (want > n_k / 4) want = n_k / 4;
     }
     if (want > 16) want = 16;
@@ -440,6 +441,7 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
+    set_last_kernel(n_seg > 1 ? "scan_fwd_pair+split" : (rag ? "scan_fwd_pair_ragged" : "scan_fwd_pair"));
     return VMS_OK;
 }
 

@@ -18,7 +18,7 @@
 //     contracts with C.
 // B/C are first rewritten once per call as fp32 [batch][group][position][B0..B15, C0..C15] (scan order),
 // so that one s_load_dwordx16 brings all states of one position.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 

@@ -8,7 +8,7 @@
 // Layout: 16 lanes per (batch, channel) row, lane j walks the states j, j + 16, ...; a wave = 4 rows; the
 // contraction with C is a 4-step DPP rotation sum inside the 16-lane row.  Memory-bound on `state`
 // (read + written once), everything else is per-row scalars.
-#include "vms_common.cuh"
+#include "vms_common.h"
 
 namespace vms {
 

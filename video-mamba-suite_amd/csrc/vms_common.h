@@ -1,7 +1,9 @@
-// vms_common.cuh -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
+// vms_common.h -- shared device helpers for the gfx950 (CDNA4, wave64) kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <mutex>
 
 #include "../../include/vms_hip.h"
 
@@ -215,8 +217,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return readlane_f(v, 63);  // total, wave-uniform
 }
 
-// ---- host-side error plumbing -------------------------------------------------------------------
-void set_error(const char* fmt, ...);
+// ---- host-side plumbing (vms_host.hip) ---------------------------------------------------------------
+void set_error(const char* fmt, ...);      // thread-local message behind vms_last_error()
+const char* last_error();
+void set_last_kernel(const char* name);    // thread-local name behind vms_last_kernel()
+// compute units of the calling thread's current device; immutable per device, looked up once per device
+int device_cu_count();
+// Runs fn() once per device (the calling thread's current device), from whichever thread gets there first; every
+// caller waits for it and gets its hipError_t.  For hipFuncSetAttribute(MaxDynamicSharedMemorySize), which a
+// kernel needs before its first launch with more than 64 KB of LDS on EACH device it runs on.
+constexpr int kMaxDevices = 64;
+struct PerDeviceOnce {
+    std::once_flag flag[kMaxDevices];
+    hipError_t rc[kMaxDevices];
+    template <typename F>
+    hipError_t run(F&& fn) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return fn();  // uncached, still correct
+        std::call_once(flag[dev], [&] { rc[dev] = fn(); });
+        return rc[dev];
+    }
+};
+// scan kernel generation a call may use (vms_hip.h vms_scan_impl): AUTO = PAIR; FAST / ROWS only when built in
+inline int scan_impl_level(const vms_scan_fwd_params& p) { return p.impl == VMS_IMPL_AUTO ? VMS_IMPL_PAIR : p.impl; }
+#ifdef VMS_EXPERIMENTAL
+constexpr bool kExperimental = true;
+#else
+constexpr bool kExperimental = false;
+#endif
 
 #define VMS_CHECK(cond, ...)                                              \
     do {                                                                  \

@@ -31,7 +31,7 @@ class ScanFwdParams(ctypes.Structure):
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
         + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("bc_pad", _i32),
-           ("workspace", _vp), ("workspace_bytes", _i64)]
+           ("workspace", _vp), ("workspace_bytes", _i64), ("impl", _i32), ("segments", _i32)]
     )
 
 
@@ -106,7 +106,37 @@ EXPORTS = (
     "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems",
     "vms_layer_norm_fwd", "vms_layer_norm_bwd", "vms_layer_norm_bwd_partials", "vms_sizeof_norm_params",
     "vms_sizeof_norm_bwd_params", "vms_selective_state_update", "vms_sizeof_state_update_params",
+    "vms_last_kernel", "vms_build_flags",
 )
+
+# vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
+# VMS_SCAN_IMPL = generic | fast | pair | rows, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
+# per call, and travel in the parameter block.
+IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS = 0, 1, 2, 3, 4
+BUILD_EXPERIMENTAL = 1
+_IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS}
+
+
+def scan_impl_from_env():
+    if "VMS_FORCE_GENERIC" in os.environ:
+        return IMPL_GENERIC
+    e = os.environ.get("VMS_SCAN_IMPL")
+    return IMPL_AUTO if not e else _IMPL_NAMES.get(e[0], IMPL_AUTO)
+
+
+def _segments_from_env(name):
+    e = os.environ.get(name)
+    return max(int(e), 1) if e else 0
+
+
+def has_experimental():
+    """True when the loaded library carries the FAST / ROWS / MFMA kernel generations (make EXPERIMENTAL=1)."""
+    return bool(lib().vms_build_flags() & BUILD_EXPERIMENTAL)
+
+
+def last_kernel():
+    """Kernel family enqueued by this thread's last successful launch call (vms_hip.h vms_last_kernel)."""
+    return lib().vms_last_kernel().decode()
 
 _lib = None
 
@@ -141,6 +171,9 @@ def lib():
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C video-mamba-suite_amd/csrc)")
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
+        L.vms_last_kernel.restype = ctypes.c_char_p
+        if L.vms_abi_version() != 4:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 4: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams)):
@@ -202,6 +235,7 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.dtype = dtype_code(u)
     P.is_variable_B, P.is_variable_C, P.delta_softplus = int(var_B), int(var_C), int(bool(delta_softplus))
     P.reverse = int(bool(reverse))
+    P.impl = scan_impl_from_env()
     P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
     P.out, P.out_z, P.x = _ptr(out), _ptr(out_z), _ptr(x)
@@ -253,10 +287,11 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
     fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
     P.out_z_accumulate = int(bool(out_z_accumulate))
     P.bc_pad = int(bc_pad)
+    P.segments = _segments_from_env("VMS_FWD_SEGMENTS")
     ws = None
     if x is None:
         batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
-        ne = rows_x_elems(P)
+        ne = rows_x_elems(P) if P.impl >= IMPL_ROWS else 0   # the row-major layout is opt-in
         if ne:
             ref = batch * dim * n_chunks * 2 * dstate
             x = torch.empty(X_HEADER + ne, device=u.device, dtype=torch.float32)[X_HEADER:X_HEADER + ref]
@@ -283,7 +318,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
              ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
-    if is_rows_x(x, rows_x_elems(Q.f)):
+    if Q.f.impl >= IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
         Q.f.x_has_sub = 2
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
     Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
@@ -303,6 +338,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
         Q.dC_d_stride, Q.dC_dstate_stride = dC.stride(0), dC.stride(1)
     Q.dz_accumulate = int(bool(dz_accumulate))
     Q.f.bc_pad = int(bc_pad)
+    Q.f.segments = _segments_from_env("VMS_BWD_SEGMENTS")
     nws = lib().vms_scan_bwd_workspace_bytes(ctypes.byref(Q))   # adjoint carries of a sequence-split backward
     if nws > 0:
         ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
