@@ -25,6 +25,8 @@ def G(a, dtype=torch.float32, grad=False):
 
 def rel_err(a, ref):
     a = a.detach().float().cpu().numpy().astype(np.float64)
+    if torch.is_tensor(ref):
+        ref = ref.detach().float().cpu().numpy()
     ref = np.asarray(ref, np.float64)
     assert a.shape == ref.shape, (a.shape, ref.shape)
     return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-6)
@@ -966,7 +968,7 @@ def test_block_L8192_fp32_vs_torch_reference():
     got = torch.autograd.grad(y, [h] + list(m.parameters()), g)
     yr = _vim_torch_reference(m, h)
     want = torch.autograd.grad(yr, [h] + list(m.parameters()), g)
-    check(y, yr.detach().cpu().numpy(), 1e-3, "y")
+    check(y, yr, 1e-3, "y")
     names = ["dh"] + [k for k, _ in m.named_parameters()]
     for k, a, b_ in zip(names, got, want):
         check(a, b_.cpu().numpy(), 1e-3 if k == "dh" else 5e-3, "grad " + k)
@@ -1007,9 +1009,9 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
     monkeypatch.setattr(core, "_CHECKPOINT_LVL", 1)
     y2, g2 = run()
     monkeypatch.undo()
-    check(y1, y2.float().cpu().numpy(), 1e-2, "y: one node vs reference form")
+    check(y1, y2, 1e-2, "y: one node vs reference form")
     for k, a, b_ in zip(names, g1, g2):
-        check(a, b_.float().cpu().numpy(), 1e-2 if k == "dh" else 2e-2, f"grad {k}: one node vs reference form")
+        check(a, b_, 1e-2 if k == "dh" else 2e-2, f"grad {k}: one node vs reference form")
 
     # (b) stage by stage against the oracle, on the tensors of this very block
     f = lambda t: t.detach().float().cpu().numpy()
@@ -1042,7 +1044,7 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
             ys.append(out_z)
         yc = torch.nn.functional.linear((ys[0].float() + ys[1].float()).to(torch.bfloat16).transpose(1, 2),
                                         m.out_proj.weight.to(torch.bfloat16))
-    check(y1, yc.float().cpu().numpy(), 1e-2, "fused block vs composition of the checked stages")
+    check(y1, yc, 1e-2, "fused block vs composition of the checked stages")
 
 
 def test_block_bf16_autocast_runs_and_matches_fp32():
