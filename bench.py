@@ -1,21 +1,27 @@
 """bench.py -- headline benchmark (BASELINE.json): Mamba-block forward+backward tokens/s at
 (B, L, D, d_state) = (8, 8192, 1024, 16) on N GPUs of one node, with the roofline of the dominant
-hot-path kernel and the CPU baseline (the oracle port on the host cores) beside it.
+hot-path kernel and the CPU baseline (the reference's selective_scan_ref path on the host cores) beside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config block|stack|dbm|long]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over one synthetic batch: the ViM ("v2") Mamba block exactly as the
-suite instantiates it (timemamba.py:115, blocks.py:910: d_model=1024, expand=1 -> d_inner=1024,
-d_conv=4, d_state=16) under autocast(bf16), forward + backward (both scan directions, both conv
-directions, the in/x/dt/out projection GEMMs, and -- for N>1 -- DDP's bucketed RCCL all-reduce of
-the gradients).  Inputs are resident in HBM before the timed region.  Per-GPU batch is fixed
-(weak scaling); value = N * B * L * K / max-over-ranks wall time.
+A step = one pass of the hot path over one synthetic batch.  --config (default block = the judged line):
+  block  configs[1]: the ViM ("v2") Mamba block exactly as the suite instantiates it (timemamba.py:115,
+         blocks.py:910: d_model=1024, expand=1 -> d_inner=1024, d_conv=4, d_state=16), B=8 per GPU, L=8192
+  stack  configs[2]: 12 x Block(Add -> RMSNorm -> ViM) at d_model 768, (8, 3136) per GPU, fused add+norm kernels
+  dbm    configs[3]: the DBM block (mamba_new.py) at d_model 512, (2, 2304) per GPU
+  long   configs[4]: the ViM block at d_model 768, (1, 65536) per GPU (sequence-split scans)
+all under autocast(bf16), forward + backward (both scan directions, both conv directions, the in/x/dt/out
+projection GEMMs, and -- for N>1 -- DDP's bucketed RCCL all-reduce of the gradients).  Inputs are resident in
+HBM before the timed region.  Per-GPU batch is fixed (weak scaling); value = N * B * L * K / max-over-ranks wall
+time.
 """
 import argparse
 import json
 import os
+import platform
+import statistics
 import sys
 import time
 
@@ -27,19 +33,30 @@ for _p in (ROOT, os.path.join(ROOT, "video-mamba-suite_amd")):
 import torch
 import torch.distributed as dist
 
-B, L, D_MODEL, D_STATE, EXPAND, D_CONV = 8, 8192, 1024, 16, 1, 4
+D_STATE, D_CONV = 16, 4
+# name -> (what, per-GPU batch, seqlen, d_model, expand, layers)
+WORKLOADS = {
+    "block": ("configs[1]: single ViM (bimamba v2) Mamba block", 8, 8192, 1024, 1, 1),
+    "stack": ("configs[2]: 12 x Block(Add -> RMSNorm -> ViM), fused add+norm", 8, 3136, 768, 1, 12),
+    "dbm": ("configs[3]: DBM bidirectional Mamba block (shared weights, fwd + reversed scan)", 2, 2304, 512, 1, 1),
+    "long": ("configs[4]: ViM block, long-video regime (sequence-split scans)", 1, 65536, 768, 1, 1),
+}
+B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r01h_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r01h_traffic.json")
 
 
 def profiled_traffic(kernel):
-    try:
-        with open(TRAFFIC_PROFILE) as f:
-            return json.load(f)[kernel]["hbm_bytes"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for path in (TRAFFIC_PROFILE, TRAFFIC_FALLBACK):
+        try:
+            with open(path) as f:
+                return json.load(f)[kernel]["hbm_bytes"], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
 def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, groups=1, w=D_CONV):
@@ -56,10 +73,74 @@ def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, g
     }
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle port (oracle/vms_oracle.c, f32 arithmetic, OpenMP over rows) timed on this host's
-    cores on a bounded sample of the same workload: the scan + conv forward and backward of ONE
-    direction for a slice of the batch (the projection GEMMs are not part of the oracle)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _median_time(fn, reps=5, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts)
+
+
+def cpu_baseline_reference_path(reps=5):
+    """north_star / BASELINE.md section 3: the reference's pure-PyTorch CPU path -- selective_scan_ref
+    (mamba/mamba_ssm/ops/selective_scan_interface.py:86-152) + causal_conv1d_ref
+    (causal-conv1d/causal_conv1d/causal_conv1d_interface.py:49-65), as restated in this repo's mamba_ssm / causal_conv1d
+    packages and pinned to the reference by tests/golden -- on all host cores, at BASELINE configs[0]
+    (2, 256, 128, 16) fp32, input recipe of test_selective_scan.py:53-88; median of `reps` after one warm-up."""
+    from causal_conv1d.causal_conv1d_interface import causal_conv1d_ref
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b, l, d, n = 2, 256, 128, 16
+    g = torch.Generator().manual_seed(0)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x0 = r(b, d, l).requires_grad_()
+    w, cb = r(d, D_CONV).requires_grad_(), r(d).requires_grad_()
+    delta = (0.5 * torch.rand(b, d, l, generator=g)).requires_grad_()
+    A = (-0.5 * torch.rand(d, n, generator=g)).requires_grad_()
+    Bm, Cm = r(b, 1, n, l).requires_grad_(), r(b, 1, n, l).requires_grad_()
+    Dv, z = r(d).requires_grad_(), r(b, d, l).requires_grad_()
+    bias = (0.5 * torch.rand(d, generator=g)).requires_grad_()
+    gout = r(b, d, l)
+    leaves = [x0, w, cb, delta, A, Bm, Cm, Dv, z, bias]
+
+    def fwd():
+        u = causal_conv1d_ref(x0, w, cb, activation="silu")
+        return selective_scan_ref(u, delta, A, Bm, Cm, Dv, z=z, delta_bias=bias, delta_softplus=True)
+
+    def fwd_only():
+        with torch.no_grad():
+            fwd()
+
+    def fwd_bwd():
+        for t in leaves:
+            t.grad = None
+        fwd().backward(gout)
+    t_f = _median_time(fwd_only, reps)
+    t_fb = _median_time(fwd_bwd, reps)
+    return {"fwd_ms": t_f * 1e3, "fwd_bwd_ms": t_fb * 1e3, "fwd_tokens_per_s": b * l / t_f,
+            "fwd_bwd_tokens_per_s": b * l / t_fb, "shape": [b, l, d, n], "dtype": "f32", "reps": reps,
+            "threads": cores}
+
+
+def cpu_baseline_c_port(seconds_budget=25.0, min_reps=5):
+    """Second, labelled CPU line: the oracle port (oracle/vms_oracle.c, f32 arithmetic, OpenMP over rows) on a
+    bounded sample of the headline workload: scan + conv forward and backward of ONE direction for one sequence of
+    2048 tokens at all 1024 channels (the projection GEMMs are not part of the oracle); median of >= 5."""
     import numpy as np
     from oracle import oracle as orc
     orc.build()
@@ -67,7 +148,7 @@ def cpu_baseline(seconds_budget=25.0):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rng = np.random.default_rng(0)
     d, n = D_MODEL * EXPAND, D_STATE
-    sb, sl = 1, 2048  # sample: 1 sequence of 2048 tokens (of 8 x 8192), all 1024 channels
+    sb, sl = 1, 2048
     f = lambda *shape: rng.standard_normal(shape, dtype=np.float32)
     u, z, g = f(sb, d, sl), f(sb, d, sl), f(sb, d, sl)
     delta = 0.5 * rng.random((sb, d, sl), dtype=np.float32)
@@ -75,22 +156,42 @@ def cpu_baseline(seconds_budget=25.0):
     Bm, Cm = f(sb, 1, n, sl), f(sb, 1, n, sl)
     Dv, bias = f(d), 0.5 * rng.random(d, dtype=np.float32)
     w, cb = f(d, D_CONV), f(d)
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
+
+    def once():
         x = orc.conv_fwd(u, w, cb, True)
         orc.scan_fwd(x, delta, A, Bm, Cm, Dv, z, bias, True)
         orc.scan_bwd(x, delta, A, Bm, Cm, Dv, z, bias, g, True)
         orc.conv_bwd(u, w, cb, g, True)
-        reps += 1
-        el = time.perf_counter() - t0
-        if el > seconds_budget or reps >= 3:
+    once()
+    ts, t_start = [], time.perf_counter()
+    while len(ts) < min_reps or (time.perf_counter() - t_start < seconds_budget and len(ts) < 9):
+        t0 = time.perf_counter()
+        once()
+        ts.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > 2 * seconds_budget:
             break
-    tok_s = reps * sb * sl / el / 2.0  # the block runs two directions per token
-    return {"value": tok_s, "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"oracle C port (f32, OpenMP {cores} threads): conv fwd + scan fwd + scan bwd + conv bwd of one "
-                      f"direction on ({sb}, {sl}, {d}, {n}) x{reps}, halved for the block's two directions; "
-                      "projection GEMMs not included"}
+    t = statistics.median(ts)
+    return {"tokens_per_s_one_direction": sb * sl / t, "ms": t * 1e3, "reps": len(ts), "threads": cores,
+            "shape": [sb, sl, d, n], "what": "oracle C port (f32, OpenMP): conv fwd + scan fwd + scan bwd + conv bwd"}
+
+
+def cpu_baseline():
+    """cpu_baseline object of the bench line.  value = the reference's CPU path (its pure-PyTorch selective_scan_ref +
+    causal_conv1d_ref, forward + backward of one scan direction at configs[0]) halved for the block's two directions;
+    the C port follows as `c_port`.  The projection GEMMs are in neither (the GPU number includes them)."""
+    ref = cpu_baseline_reference_path()
+    port = cpu_baseline_c_port()
+    cores = ref["threads"]
+    return {
+        "value": ref["fwd_bwd_tokens_per_s"] / 2.0, "unit": "tokens/s", "cores": cores, "kind": "port",
+        "cpu": cpu_model(),
+        "sample": f"selective_scan_ref + causal_conv1d_ref (pure PyTorch, torch.set_num_threads({cores}), fp32) forward + "
+                  f"backward at BASELINE configs[0] (B,L,D,N)=(2,256,128,16): median of {ref['reps']} = "
+                  f"{ref['fwd_bwd_ms']:.1f} ms (forward only {ref['fwd_ms']:.1f} ms); one direction, halved for the "
+                  "block's two; projection GEMMs not included",
+        "reference_path": ref,
+        "c_port": dict(port, tokens_per_s_block=port["tokens_per_s_one_direction"] / 2.0),
+    }
 
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
@@ -99,7 +200,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
 def projection_mfma(block, hidden, iters=20):
     """The block's two large projections (library GEMMs on the matrix cores, mamba_ssm/ops/projections.py) timed on
     their own AFTER the timed region: forward + backward of in_proj and of out_proj, as TFLOP/s against the dense
-    bf16 MFMA peak (north_star: "MFMA utilisation for the projections")."""
+    bf16 MFMA peak (north_star: "MFMA utilisation for the projections"); the MFMA busy counters of the same GEMMs are
+    in profiles/ (tools/mfma_counters.sh)."""
     from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
     out = {}
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -107,8 +209,9 @@ def projection_mfma(block, hidden, iters=20):
             "in_proj": (lambda x: in_proj_fn(x, block.in_proj.weight, block.in_proj.bias),
                         hidden.detach().clone().requires_grad_(), block.in_proj.weight),
             "out_proj": (lambda y: out_proj_fn(y, block.out_proj.weight, block.out_proj.bias),
-                         torch.randn(hidden.shape[0], block.d_inner, hidden.shape[1], device=hidden.device,
-                                     dtype=torch.bfloat16, requires_grad=True), block.out_proj.weight),
+                         torch.randn(hidden.shape[0], block.out_proj.weight.shape[1], hidden.shape[1],
+                                     device=hidden.device, dtype=torch.bfloat16, requires_grad=True),
+                         block.out_proj.weight),
         }
         for name, (fn, x, w) in cases.items():
             y = fn(x)
@@ -135,106 +238,177 @@ def projection_mfma(block, hidden, iters=20):
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-projections", action="store_true", help="skip the separate projection GEMM timing (profiling runs)")
-    args = ap.parse_args()
+class _Stack(torch.nn.Module):
+    """configs[2]: n Blocks (Add -> RMSNorm -> ViM mixer, fused add+norm kernels, fp32 residual stream) closed by the
+    fused add + norm_f, the way the suite's ViViM / TimeMamba backbones run them."""
 
+    def __init__(self, d_model, n_layers, expand):
+        super().__init__()
+        from functools import partial
+        from mamba_ssm.modules.mamba_simple import Block, Mamba
+        from mamba_ssm.ops.triton.layernorm import RMSNorm
+        mixer = partial(Mamba, d_state=D_STATE, d_conv=D_CONV, expand=expand, bimamba_type="v2")
+        self.layers = torch.nn.ModuleList([Block(d_model, mixer, norm_cls=partial(RMSNorm, eps=1e-5), fused_add_norm=True,
+                                                 residual_in_fp32=True) for _ in range(n_layers)])
+        self.norm_f = RMSNorm(d_model, eps=1e-5)
+
+    def forward(self, h):
+        from mamba_ssm.ops.triton.layernorm import rms_norm_fn
+        res = None
+        for blk in self.layers:
+            h, res = blk(h, res)
+        return rms_norm_fn(h, self.norm_f.weight, self.norm_f.bias, eps=self.norm_f.eps, residual=res, prenorm=False,
+                           residual_in_fp32=True)
+
+
+def make_workload(config, device, dims=None):
+    """-> (module, per-GPU batch, seqlen, d_model).  dims = (batch, seqlen, d_model) overrides the sizes (CPU tests)."""
+    what, b, l, d_model, expand, layers = WORKLOADS[config]
+    if dims is not None:
+        b, l, d_model = dims
+    if config == "dbm":
+        from mamba_ssm.modules.mamba_new import Mamba as DBM
+        m = DBM(d_model, d_state=D_STATE, d_conv=D_CONV, expand=expand)
+    elif config == "stack":
+        m = _Stack(d_model, layers if dims is None else 2, expand)
+    else:
+        from mamba_ssm.modules.mamba_simple import Mamba
+        m = Mamba(d_model, d_state=D_STATE, d_conv=D_CONV, expand=expand, bimamba_type="v2")
+    return m.to(device), b, l, d_model
+
+
+def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=None, autocast=True,
+        cpu_base=True, projections=True):
+    """The timed loop.  device=None: cuda:LOCAL_RANK; a CPU device (tests: gloo + checker-backed fake extensions)
+    runs the same DDP / timing / reporting code on tiny sizes and skips the GPU-only instrumentation.
+    Returns the result dict on rank 0, None elsewhere."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
+    on_gpu = device is None or torch.device(device).type == "cuda"
+    if on_gpu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device(device)
+    if distributed and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        if on_gpu:
+            dist.init_process_group(backend=backend, device_id=dev)  # "nccl" = RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
 
     import vms_hip
-    from mamba_ssm.modules.mamba_simple import Mamba
 
     torch.manual_seed(0 + rank)
-    block = Mamba(D_MODEL, d_state=D_STATE, d_conv=D_CONV, expand=EXPAND, bimamba_type="v2").to(dev)
+    block, b, l, d_model = make_workload(config, dev, dims)
     model = block
     if distributed:
-        model = torch.nn.parallel.DistributedDataParallel(block, device_ids=[local_rank], bucket_cap_mb=32,
-                                                          gradient_as_bucket_view=True)
+        kw = dict(device_ids=[local_rank]) if on_gpu else {}
+        model = torch.nn.parallel.DistributedDataParallel(block, bucket_cap_mb=32, gradient_as_bucket_view=True, **kw)
+    act_dtype = torch.bfloat16 if autocast else torch.float32
     # the block sits inside a network: its input gradient is part of the backward
-    hidden = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    hidden = torch.randn(b, l, d_model, device=dev, dtype=act_dtype, requires_grad=True)
     # fixed upstream gradient: the step is exactly the block's forward + backward (no loss kernels)
-    gout = torch.randn(B, L, D_MODEL, device=dev, dtype=torch.bfloat16)
+    gout = torch.randn(b, l, d_model, device=dev, dtype=act_dtype)
 
     def step():
         model.zero_grad(set_to_none=True)
         hidden.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast(dev.type, dtype=torch.bfloat16, enabled=autocast):
             out = model(hidden)
         out.backward(gout)
 
     # the GPU's clocks need ~20 steps (0.1 s) to settle: with fewer the first timed steps run 1-2 % slow.  The extra
     # untimed steps below are reported as config.clock_ramp_steps; the timed region is exactly --steps steps.
-    ramp = max(0, 20 - args.warmup)
-    for _ in range(args.warmup + ramp):
+    ramp = max(0, 20 - warmup) if on_gpu else 0
+    for _ in range(warmup + ramp):
         step()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
-    vms_hip.start_timing()
+    sync()
+    if on_gpu:
+        vms_hip.start_timing()   # two event records per C-ABI launch, on the launch stream, same fast call path
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
-    torch.cuda.synchronize()
+    sync()
     if distributed:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = vms_hip.stop_timing()
+    kernel_ms = vms_hip.stop_timing() if on_gpu else {}
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
+    res = None
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        tokens = world * B * L * args.steps
-        ab = algorithmic_bytes()
+        what = WORKLOADS[config][0]
+        ms_per_step = elapsed / steps * 1e3
+        tokens = world * b * l * steps
+        d_inner = d_model * WORKLOADS[config][4]
+        ab = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l)
         kern = {}
         for name, ts in kernel_ms.items():
             avg = sum(ts) / len(ts)
-            kern[name] = {"calls_per_step": len(ts) / args.steps, "avg_ms": avg,
-                          "ms_per_step": sum(ts) / args.steps}
+            kern[name] = {"calls_per_step": len(ts) / steps, "avg_ms": avg, "ms_per_step": sum(ts) / steps}
             if name in ab:
                 kern[name]["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
-        dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["algorithmic_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": profiled_traffic(dom),
-                    "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+        comm = {"backend": backend if distributed else None, "world_size": dist.get_world_size() if distributed else 1}
+        if on_gpu:
+            try:
+                comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                comm["rccl_version"] = None
         res = {
             "metric": "Mamba-block fwd+bwd tokens/s at (B,L,D,d_state)=(8,8192,1024,16); % HBM roofline",
-            "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "configs[1]: single ViM (bimamba v2) Mamba block fwd+bwd, autocast bf16, "
-                                   "B=8 per GPU, L=8192, d_model=1024, expand=1 (d_inner=1024), d_state=16, d_conv=4",
-                       "step": "fwd+bwd" + (" + DDP RCCL all-reduce" if distributed else ""),
-                       "global_batch": world * B, "seq_len": L, "parallelism": f"dp{world}",
+            "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if autocast else "f32", "data": "synthetic",
+            "config": {"workload": f"{what}: fwd+bwd, autocast bf16, B={b} per GPU, L={l}, d_model={d_model}, "
+                                   f"expand={WORKLOADS[config][4]} (d_inner={d_inner}), d_state={D_STATE}, d_conv={D_CONV}",
+                       "name": config,
+                       "step": "fwd+bwd" + (" + DDP all-reduce" if distributed else ""),
+                       "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
-                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))},
-            "roofline": roofline,
+                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")), "comm": comm},
             "kernels": kern,
         }
-        if world == 1 and not args.no_projections:
+        if kern:
+            dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
+            traffic, src = profiled_traffic(dom) if config == "block" else (None, None)
+            res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["algorithmic_GBs"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
+                               "traffic_source": (f"{src}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel at this "
+                                                  "size, committed profile (not measured in this run)") if src else None,
+                               "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+        if on_gpu and world == 1 and projections and config == "block":
             res["projections"] = projection_mfma(block, hidden)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu_base:
             res["cpu_baseline"] = cpu_baseline()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="block")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-projections", action="store_true", help="skip the separate projection GEMM timing (profiling runs)")
+    args = ap.parse_args()
+    res = run(args.config, args.steps, args.warmup, cpu_base=not args.no_cpu_baseline,
+              projections=not args.no_projections)
+    if res is not None:
         print(json.dumps(res))
-    if distributed:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

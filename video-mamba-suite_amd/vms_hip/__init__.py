@@ -194,22 +194,27 @@ def _call(fn_name, params, ref_tensor):
     if not ref_tensor.is_cuda:
         raise RuntimeError(f"{fn_name}: tensors must be on a GPU (no CPU path in this library)")
     idx = ref_tensor.device.index
-    if _timing is None and idx == torch.cuda.current_device():
+    if idx == torch.cuda.current_device():
         # the common case without the device guard and stream object: ~20 us less host time per call, which is
-        # what small problems are bound by
-        rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx)))
-        if rc != 0:
-            raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
-        return
-    with torch.cuda.device(ref_tensor.device):
-        cur = torch.cuda.current_stream()
-        if _timing is not None:
+        # what small problems are bound by.  Timing (bench.py) only adds two event records on the same raw stream.
+        if _timing is None:
+            rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx)))
+        else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(cur)
-        rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(cur.cuda_stream))
-        if _timing is not None:
-            e1.record(cur)
+            e0.record()
+            rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx)))
+            e1.record()
             _timing.append((fn_name, e0, e1))
+    else:
+        with torch.cuda.device(ref_tensor.device):
+            cur = torch.cuda.current_stream()
+            if _timing is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+            rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(cur.cuda_stream))
+            if _timing is not None:
+                e1.record(cur)
+                _timing.append((fn_name, e0, e1))
     if rc != 0:
         raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
 
