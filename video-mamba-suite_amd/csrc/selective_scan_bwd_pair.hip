@@ -528,6 +528,407 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 }
 
 
+// =====================================================================================================================
+// Second generation for whole-vector rows (seqlen % 8 == 0; ragged rows stay on scan_bwd_pair_kernel above): the same
+// decomposition and arithmetic, reorganised around what the SQ counters of that kernel show
+// (profiles/r02a_sq_scan.md: 6.4 cycles per VALU issue unit against 4.5 for the forward kernel, a third of the wave
+// cycles parked in s_waitcnt / s_barrier).  The grid of the benchmark shape is 2,048 waves = 2 per SIMD whatever the
+// register count, so the lever is not occupancy but what the two waves of a SIMD wait for:
+//   * workgroups of W = 4 waves (16 rows) with 36 KB of LDS: the two waves of a SIMD belong to DIFFERENT workgroups,
+//     so a workgroup at its barrier (one per pair of states) or waiting for its chunk's loads leaves the SIMDs to
+//     its neighbour, and a barrier synchronises 4 waves instead of 8;
+//   * dB / dC: the 4 rows of a wave are summed IN the wave first -- v_permlane32_swap pairs dB[e] with dC[e]
+//     (lanes 0-31 then hold dB, lanes 32-63 dC, each summed over rows r and r+2), v_permlane16_swap pairs elements
+//     e and e+4 (DPP row rho then holds tensor rho >> 1, elements 4 (rho & 1) .. +3, summed over all 4 rows): 12
+//     swaps + 6 v_pk_add_f32, and ONE ds_write_b128 per lane and state.  The slab holds one wave partial per position
+//     instead of 4 rows (1 KB per wave and state), every thread sums the W partials of its (state, tensor,
+//     position)s with 8 ds_read_b32 per pair and issues the atomics;
+//   * no second B / C register set (the fp32 B / C of a state are read from LDS when the state starts), the
+//     softplus derivative is rebuilt in the chunk epilogue as 1 - exp(-delta) instead of being carried, u is
+//     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
+//     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
+template <int W> struct B4 {
+    static constexpr int kPair = 2 * W * 4 * kWave;   // floats of one pair of states: [par][wave][4 lane + k]
+    static constexpr int kRows = 4 * W;
+    static constexpr int kPPT = 8 / W;                 // B / C pieces and slab outputs per thread (512 per chunk / pair)
+    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kBN * 4);
+};
+
+template <typename T, bool HZ, bool REV, int W>
+__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
+    const vms_scan_fwd_params& p = q.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = kBK, N = kBN, CH = kCH;
+    constexpr int kB4Pair = B4<W>::kPair, PPT = B4<W>::kPPT, kRows4 = B4<W>::kRows;
+    lds_f4* const bc4 = (lds_f4*)smem;                                   // fp32 B / C of the chunk: [tensor][state][128]
+    lds_f4* const slab4 = (lds_f4*)(smem + kBcFloats);                   // [buf][par][wave][lane] float4
+    const lds_f32* const slab1 = (const lds_f32*)(smem + kBcFloats);
+    const int lane = threadIdx.x & 63;
+    const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, r = lane >> 4;
+    lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * kBN;
+    __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
+    const int wg_per_seg = gridDim.x / n_seg;
+    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
+    const int b = wg % p.batch;
+    const int d0 = (wg / p.batch) * kRows4;
+    const int d = d0 + quad * 4 + r;
+    const bool row_ok = d < p.dim;
+    const int dc = row_ok ? d : p.dim - 1;
+    const int g = d0 / (p.dim / p.n_groups);  // host guarantees one group per workgroup
+    const int L = p.seqlen;
+
+    const T* const u_b = static_cast<const T*>(p.u);
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    const T* const dout_b = static_cast<const T*>(q.dout);
+    T* const du_b = static_cast<T*>(q.du);
+    T* const ddelta_b = static_cast<T*>(q.ddelta);
+    const T* const z_b = static_cast<const T*>(p.z);
+    const T* const outp_b = static_cast<const T*>(p.out);
+    T* const dz_b = static_cast<T*>(q.dz);
+    T* const out_z_b = static_cast<T*>(p.out_z);
+#define VMS_OFF(bs, ds) static_cast<uint32_t>((int64_t)b * (bs) + (int64_t)dc * (ds))
+    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    float* const dBg = q.dB + (int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride;
+    float* const dCg = q.dC + (int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride;
+    const float* const x_b = static_cast<const float*>(p.x);
+    const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
+
+    float dAacc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
+
+    // B / C staging of the NEXT chunk: piece (tensor, state, j) = 8 values of one state; a thread owns PPT pieces
+    RawB<T, REV> stg[PPT];
+    bool st_ok = false;
+    auto piece_src = [&](int h) __attribute__((always_inline)) {
+        const int pid = (int)threadIdx.x + W * kWave * h, ten = pid >> 8, n = (pid >> 4) & 15;
+        return ten ? Cv + (int64_t)n * p.C_dstate_stride : Bv + (int64_t)n * p.B_dstate_stride;
+    };
+    auto stage_issue = [&](int cc) __attribute__((always_inline)) {
+        const int ll = cc * CH + j * K;
+        st_ok = cc >= 0 && ll < L;
+#pragma unroll
+        for (int h = 0; h < PPT; ++h) stg[h].load(piece_src(h), REV ? L - ll - K : ll, st_ok);
+    };
+    auto stage_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < PPT; ++h) {
+            f32x4 lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[i] = st_ok ? stg[h].at(i) : 0.f;
+                hi[i] = st_ok ? stg[h].at(4 + i) : 0.f;
+            }
+            const int pid = (int)threadIdx.x + W * kWave * h;
+            lds_f4* dst = bc4 + ((pid >> 4) * CH) / 4 + j;   // (tensor * N + state) * CH
+            dst[0] = lo;
+            dst[16] = hi;
+        }
+    };
+    // slab reduction: output (par, f) of a pair = float f of state par; a thread owns PPT outputs and sums their W wave
+    // partials.  Float f = 4 lane + k of a wave's 1 KB belongs to DPP row rho = lane >> 4: tensor rho >> 1, element
+    // 4 (rho & 1) + k of position group lane & 15 (see the swaps below).  W = 8: one output, half of its partials read
+    // during each state of the next pair; W = 4: two outputs (same f, par 0 / 1), one summed per state.
+    const int rd_f = threadIdx.x & 255, rd_par0 = (int)threadIdx.x >> 8;
+    const int rd_rho = rd_f >> 6, rd_ten = rd_rho >> 1;
+    const int rd_pos = 8 * ((rd_f >> 2) & 15) + 4 * (rd_rho & 1) + (rd_f & 3);
+    const lds_f32* const rd_src = slab1 + rd_f;
+    float* const rd_dst = rd_ten ? dCg : dBg;
+    const int64_t rd_stride = rd_ten ? q.dC_dstate_stride : q.dB_dstate_stride;
+    float racc = 0.f;
+    float* rd_ptr = nullptr;   // state (par 0 of the pair for W = 4) this thread's pending sums go to
+    bool rd_okp = false;
+
+    RawB<T, REV> pu, pdt, pdo, pz, pout;   // row data of the NEXT chunk: requested while the current one computes
+    float hck_next = 0.f;
+    const int n_c = (L + CH - 1) / CH;
+    const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
+    auto request_row = [&](int cc) __attribute__((always_inline)) {
+        const int ll = cc * CH + j * K;
+        const bool v = cc >= 0 && ll < L && row_ok;
+        const uint32_t pl = REV ? L - ll - K : ll;
+        pu.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl, v);
+        pdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl, v);
+        pdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
+        if (HZ) {
+            pz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
+            pout.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+        }
+        const int e128 = cc * (CH / 128) - 1;
+        const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
+        hck_next = x_b[xo];
+    };
+    const int cps = (n_c + n_seg - 1) / n_seg;
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
+    float g_in = 0.f, anx_in = 1.f;
+    if (seg < n_seg - 1) {
+        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_seg) * N + j;
+        for (int s2 = n_seg - 1; s2 > seg; --s2) {
+            const float2 pq = cp[(int64_t)s2 * N];
+            g_in = fmaf(pq.x, g_in, pq.y);
+        }
+        const int lr = c_hi * CH;
+        float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
+        if (p.delta_softplus) t = softplusf_(t);
+        anx_in = fast_exp2(t * A_mine * kLog2e);
+    }
+    request_row(c_hi - 1);
+    stage_issue(c_hi - 1);
+    stage_commit();
+    rec4[j] = f32x4{A_mine, c_hi > 1 ? hck_next : 0.f, anx_in, g_in};
+    lds_barrier_b();
+    f32x4 bc = rec4[0];
+    const bool is_first = j == 0, is_last = j == 15;
+    for (int c = c_hi - 1; c >= c_lo; --c) {
+        const int l0 = c * CH + j * K;
+        const bool ok = l0 < L && row_ok;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;
+        const int rd_lo = c * CH + rd_pos;
+        float* const rd_dst_c = rd_dst + (REV ? L - 1 - rd_lo : rd_lo);
+        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2];
+        float sdl = 0.f, dl_first = 0.f;
+        {
+            float dy[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                dy[i] = ok ? pdo.at(i) : 0.f;   // past the end: c = 0, a = 1 (identity for the suffix scan)
+                float t = pdt.at(i) + bias;
+                if (p.delta_softplus) t = softplusf_(t);
+                t = ok ? t : 0.f;
+                dl2[i / 2][i % 2] = t;
+                sdl += t;
+                if (i == 0) dl_first = t;
+            }
+            if (HZ) {
+                float ov[K], dzv[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float zv = pz.at(i);
+                    const float s = sigmoidf_(zv);
+                    const float silu = zv * s;
+                    ov[i] = pout.at(i);
+                    dzv[i] = dy[i] * ov[i] * s * (1.f + zv * (1.f - s));
+                    dy[i] *= silu;
+                    ov[i] *= silu;
+                }
+                if (ok) {
+                    if (q.dz_accumulate) {  // dz += (vms_hip.h)
+                        RawB<T, REV> od;
+                        od.load(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0, true);
+#pragma unroll
+                        for (int i = 0; i < K; ++i) dzv[i] += od.at(i);
+                    }
+                    store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
+                    if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float uv = pu.at(i);
+                dy2[i / 2][i % 2] = dy[i];
+                dlu2[i / 2][i % 2] = dl2[i / 2][i % 2] * uv;
+                dD_acc = fmaf(dy[i], uv, dD_acc);
+            }
+        }
+        f2 S1[K / 2], S2[K / 2];  // per element: sum_n g B  /  sum_n A g a x_{i-1}
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+            S1[k] = f2{0.f, 0.f};
+            S2[k] = f2{0.f, 0.f};
+        }
+        RawB<T, REV> ukeep = pu;   // u of this chunk in its raw form, for the epilogue
+        request_row(c - 1);        // in flight during the 16 states of this chunk
+        stage_issue(c - 1);
+#define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
+        auto do_state = [&](const int n, const int i4) __attribute__((always_inline)) {
+            const int par = i4 & 1, buf = (i4 >> 1) & 1;
+#ifdef VMS_BWD_ALTPRIO
+            // waves w and w + 4 share a SIMD, and between equal priorities the older wave wins every issue slot: it would
+            // reach each barrier first and wait while its partner runs alone at the single-wave issue rate.  Taking turns
+            // (one state each) brings both to the barrier together.
+            if (W == 8) {
+                if ((par ^ (quad >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+            // fp32 B / C of this state, shared by the workgroup's 32 rows
+            const lds_f4* bsrc = bc4 + (n * CH) / 4 + j;
+            const f32x4 b0 = bsrc[0], b1 = bsrc[16], c0 = bsrc[N * CH / 4], c1 = bsrc[N * CH / 4 + 16];
+            // 4 wave partials of the PREVIOUS pair (other slab buffer): W = 8: half of this thread's one output;
+            // W = 4: all of its output of state `par`
+            float rdv[4];
+            {
+                const lds_f32* src = rd_src + (buf ^ 1) * kB4Pair +
+                                     (W == 8 ? rd_par0 * (W * 4 * kWave) + par * 4 * (4 * kWave) : par * (W * 4 * kWave));
+#pragma unroll
+                for (int w = 0; w < 4; ++w) rdv[w] = src[w * (4 * kWave)];
+            }
+            const float Araw = bc.x, hin = bc.y, anx_n = bc.z, gin = bc.w;
+            // before the last state's fetch of state 0's record, lane j stores the state entering the NEXT chunk for state j
+            if (i4 == 3 && n == N - 1) rec1[4 * j + 1] = c > 1 ? hck_next : 0.f;
+            bc = rec4[(n + 1) & (N - 1)];
+            const float An = Araw * kLog2e;
+            const f2 An2 = f2{An, An}, Araw2 = f2{Araw, Araw};
+            f2 Bn2[K / 2], c2[K / 2], a2[K / 2], xs2[K / 2], ax2[K / 2];
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                Bn2[k] = k == 0 ? f2{b0.x, b0.y} : k == 1 ? f2{b0.z, b0.w} : k == 2 ? f2{b1.x, b1.y} : f2{b1.z, b1.w};
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
+                c2[k] = (k == 0 ? f2{c0.x, c0.y} : k == 1 ? f2{c0.z, c0.w} : k == 2 ? f2{c1.x, c1.y} : f2{c1.z, c1.w}) * dy2[k];
+            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
+            float pa = fast_exp2(sdl * An);
+            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);  // lane 15 of the row <- next chunk
+            float rg = 0.f;
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
+            float ra = fast_exp2((sdl - dl_first) * An) * a_right;
+            px = fmaf(pa, is_first ? hin : 0.f, px);
+            rg = fmaf(ra, is_last ? gin : 0.f, rg);
+            row_scan_pair_b(pa, px, ra, rg);
+            const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);
+            float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
+            if (is_first) *(lds_f2*)(rec1 + 4 * n + 2) = f2{a2[0].x, rg};
+            {
+                float xrun = xseed;
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float ax = VMS_EL(a2, i) * xrun;
+                    xrun = ax + VMS_EL(xs2, i);
+                    VMS_EL(ax2, i) = ax;
+                    VMS_EL(xs2, i) = xrun;
+                }
+            }
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) {
+                grun = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), grun, VMS_EL(c2, i));
+                VMS_EL(c2, i) = grun;
+            }
+            f2 dA2 = f2{0.f, 0.f};
+            float vb[K], vc[K];   // this row's dB / dC products of the lane's 8 elements
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 g2 = c2[k];
+                const f2 gax = g2 * ax2[k];  // g * a_i x_{i-1}
+                S1[k] = pk_fma_b(g2, Bn2[k], S1[k]);
+                S2[k] = pk_fma_b(Araw2, gax, S2[k]);
+                dA2 = pk_fma_b(dl2[k], gax, dA2);
+                const f2 dBv = g2 * dlu2[k], dCv = dy2[k] * xs2[k];
+                vb[2 * k] = dBv.x; vb[2 * k + 1] = dBv.y;
+                vc[2 * k] = dCv.x; vc[2 * k + 1] = dCv.y;
+            }
+            const float dA_tot = row_allsum_b(dA2.x + dA2.y);
+            if (j == n) dAacc += dA_tot;
+            // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
+            asm volatile("s_nop 1\n\t"
+                         "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
+                         "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
+                         "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+                         "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+                         : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]), "+v"(vb[7]),
+                           "+v"(vc[0]), "+v"(vc[1]), "+v"(vc[2]), "+v"(vc[3]), "+v"(vc[4]), "+v"(vc[5]), "+v"(vc[6]), "+v"(vc[7]));
+            f2 t2[K / 2];
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) t2[k] = f2{vb[2 * k], vb[2 * k + 1]} + f2{vc[2 * k], vc[2 * k + 1]};
+            // elements e and e + 4: DPP row rho then holds tensor rho >> 1, elements 4 (rho & 1) + k, all 4 rows summed
+            float t[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) t[i] = VMS_EL(t2, i);
+            asm volatile("s_nop 1\n\t"
+                         "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
+                         "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
+                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+            const f2 o0 = f2{t[0], t[1]} + f2{t[4], t[5]}, o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
+            slab4[(buf * kB4Pair + par * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
+                __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
+            {
+                const float tsum = (rdv[0] + rdv[1]) + (rdv[2] + rdv[3]);
+#ifdef VMS_ABL_NOATOM
+                racc += tsum;
+#else
+                if (W == 8) {
+                    racc = par == 0 ? tsum : racc + tsum;
+                    if (par == 1 && rd_okp) atomicAdd(rd_ptr + rd_par0 * rd_stride, racc);
+                } else if (rd_okp) {
+                    atomicAdd(rd_ptr + par * rd_stride, tsum);
+                }
+#endif
+            }
+            if (par == 1) {
+                // the pair just written is summed during the next one
+                rd_ptr = rd_dst_c + (int64_t)(n - 1) * rd_stride;
+                rd_okp = rd_lo < L;
+#ifndef VMS_ABL_NOBAR
+                lds_barrier_b();  // pair written by all waves; previous pair's buffer free again
+#endif
+            }
+        };
+#pragma unroll 1
+        for (int n = 0; n < N; n += 4) {
+            do_state(n, 0);
+            do_state(n + 1, 1);
+            do_state(n + 2, 2);
+            do_state(n + 3, 3);
+        }
+#undef VMS_EL
+        // u of this chunk before its registers are refilled; the next chunk's row data then travels during the
+        // epilogue, the staging commit and the barrier
+        // keep the compiler from carrying the prologue's widened u, D dy products and address arithmetic through the
+        // 16 states: what the epilogue needs is rebuilt from these (opaque) registers
+        asm volatile("" : "+v"(ukeep.v[0]));
+#pragma unroll
+        for (int k2 = 0; k2 < K / 2; ++k2) asm volatile("" : "+v"(dy2[k2]));
+        float uvv[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) uvv[i] = ukeep.at(i);
+        {
+            float duv[K], ddl[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float dl = dl2[i / 2][i % 2];
+                const float s1 = S1[i / 2][i % 2], s2 = S2[i / 2][i % 2];
+                // d softplus / d(delta + bias) = sigmoid = 1 - exp(-softplus); 1 above the reference's threshold, where
+                // exp(-delta) < 2^-28 anyway (selective_scan_bwd_kernel.cuh:439-452)
+                const float sg = p.delta_softplus ? 1.f - fast_exp2(-kLog2e * dl) : 1.f;
+                duv[i] = fmaf(dl, s1, Dd * dy2[i / 2][i % 2]);
+                ddl[i] = fmaf(uvv[i], s1, s2) * sg;
+                dbias_acc += ok ? ddl[i] : 0.f;
+            }
+            if (ok) {
+                store_b<T, REV>(du_b + (VMS_OFF(q.du_batch_stride, q.du_d_stride) + pl0), duv);
+                store_b<T, REV>(ddelta_b + (VMS_OFF(q.ddelta_batch_stride, q.ddelta_d_stride) + pl0), ddl);
+            }
+        }
+        stage_commit();   // every wave is past its last B / C read of this chunk (barrier of the last pair)
+        lds_barrier_b();
+    }
+#undef VMS_OFF
+    if (rd_okp) {   // the last pair (buffer 1) is still in the slab
+#pragma unroll
+        for (int h = 0; h < PPT; ++h) {
+            const int par = W == 8 ? rd_par0 : h;
+            const lds_f32* src = rd_src + kB4Pair + par * (W * 4 * kWave);
+            float tsum = src[0];
+#pragma unroll
+            for (int w = 1; w < W; ++w) tsum += src[w * (4 * kWave)];
+            atomicAdd(rd_ptr + par * rd_stride, tsum);
+        }
+    }
+    const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
+    if (row_ok) {
+        if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
+        if (q.ddelta_bias && j == 0) atomicAdd(q.ddelta_bias + d, db_tot);
+        atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)j * q.dA_dstate_stride, dAacc);
+    }
+}
+
+
 // ---- adjoint carries of a segmented backward --------------------------------------------------------------------
 // With few rows and long sequences (batch 1, 768 channels, 65,536 tokens: 24 workgroups for 256 CUs) the grid
 // above is repeated over n_seg ranges of chunks.  The adjoint entering a range from the right depends linearly on
@@ -745,9 +1146,19 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
 #undef VMS_C
         grid = dim3(p.batch * tiles * n_seg);
     }
+    // whole-vector rows run on the second generation (scan_bwd_pair4_kernel, W waves per workgroup)
+#ifndef VMS_BWD_W
+#define VMS_BWD_W 4
+#endif
+    constexpr int W4 = VMS_BWD_W;             // A/B builds: 0 = the first generation for every problem, 4 or 8
+    constexpr bool four = W4 != 0;
+    constexpr int WK = four ? W4 : 4;
+    const size_t smem4 = B4<WK>::kSmem;
+    const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q, 1, carry); \
+        else if (four) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK>), grid4, block4, smem4, stream, q, n_seg, carry); \
         else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q, n_seg, carry); \
     } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
