@@ -744,7 +744,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
 #define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
         auto do_state = [&](const int n, const int i4) __attribute__((always_inline)) {
             const int par = i4 & 1, buf = (i4 >> 1) & 1;
-#ifdef VMS_BWD_ALTPRIO
+#ifndef VMS_BWD_NO_ALTPRIO
             // waves w and w + 4 share a SIMD, and between equal priorities the older wave wins every issue slot: it would
             // reach each barrier first and wait while its partner runs alone at the single-wave issue rate.  Taking turns
             // (one state each) brings both to the barrier together.
@@ -780,6 +780,27 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
                 xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
                 c2[k] = (k == 0 ? f2{c0.x, c0.y} : k == 1 ? f2{c0.z, c0.w} : k == 2 ? f2{c1.x, c1.y} : f2{c1.z, c1.w}) * dy2[k];
             }
+#ifdef VMS_ABL_SEEDS
+            // ablation: forward seeds as if they came from memory (no lane-aggregate chain, no forward half of the row scan)
+            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);
+            float rg = 0.f;
+#pragma unroll
+            for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
+            float ra = fast_exp2((sdl - dl_first) * An) * a_right;
+            rg = fmaf(ra, is_last ? gin : 0.f, rg);
+            asm volatile("s_nop 1\n\t"
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                         "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1"
+                         : "+v"(rg), "+v"(ra));
+            const float xseed = hin * a_right;   // stands for a loaded value
+            float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
+#else
             float px = 0.f;
 #pragma unroll
             for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
@@ -794,6 +815,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             row_scan_pair_b(pa, px, ra, rg);
             const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);
             float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
+#endif
             if (is_first) *(lds_f2*)(rec1 + 4 * n + 2) = f2{a2[0].x, rg};
             {
                 float xrun = xseed;
@@ -1148,7 +1170,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     }
     // whole-vector rows run on the second generation (scan_bwd_pair4_kernel, W waves per workgroup)
 #ifndef VMS_BWD_W
-#define VMS_BWD_W 4
+#define VMS_BWD_W 8
 #endif
     constexpr int W4 = VMS_BWD_W;             // A/B builds: 0 = the first generation for every problem, 4 or 8
     constexpr bool four = W4 != 0;

@@ -288,6 +288,227 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 }
 
 
+// =====================================================================================================================
+// Same kernel with B / C shared by the workgroup as fp32 in LDS (whole-vector rows: seqlen % 16 == 0).
+//
+// The SQ counters of the kernel above (profiles/r02a_sq_scan.md) show a VALU-issue-bound loop: 125 VALU
+// instructions per state and wave, of which 32 only widen the bf16 B / C of the state -- the same 2 x 1024 values
+// in every wave of a batch.  Here a workgroup = 8 rows of one (batch, group); B / C travel global -> registers ->
+// fp32 -> LDS once per workgroup, four states at a time ([tensor][state % 4][1024] = 32 KB, two such buffers), one
+// group ahead of the compute; a lane then takes its 16 + 16 values of a state with eight ds_read_b128 (positions
+// stored as [i / 4][lane][i % 4], so consecutive lanes hit consecutive 16-byte slots).  Per state and wave: 4
+// widening ops + 1 ds_write_b128 instead of 32 widening ops; one workgroup barrier per four states.  64 KB of LDS
+// per workgroup: two workgroups = 16 waves per CU, the same 4 waves per SIMD as before.
+constexpr int kLW = 8;                       // waves (rows) per workgroup
+constexpr int kLG = 4;                       // states per staged group
+constexpr int kLGroupFloats = 2 * kLG * kWave * kPK;   // [tensor][state % 4][1024]
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f4 lds_f4p;
+
+template <typename T, bool REV>
+struct Raw8 {
+    static constexpr int EPV = 16 / sizeof(T);
+    vec_t<T, EPV> v[8 / EPV];
+    __device__ __forceinline__ void load(const T* __restrict__ base, uint32_t off, bool valid) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
+#pragma unroll
+        for (int i = 0; i < 8 / EPV; ++i) v[i] = vp[i];
+    }
+    __device__ __forceinline__ float at(int i) const {
+        const int e = REV ? 7 - i : i;
+        return static_cast<float>(v[e / EPV][e % EPV]);
+    }
+};
+
+template <typename T, bool HZ, bool REV>
+__global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
+                                                                        const float2* __restrict__ seg_carry) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = kPK, N = kPN, CS = kWave * K;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wg_per_seg = gridDim.x / n_seg;
+    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
+    const int b = wg % p.batch;
+    const int d0 = (wg / p.batch) * kLW;
+    const int d = d0 + wave;
+    const bool row_ok = d < p.dim;           // rows past the end still stage B / C and meet the barriers
+    const int dc = row_ok ? d : p.dim - 1;
+    const int g = d0 / (p.dim / p.n_groups); // host guarantees one group per workgroup
+    const int L = p.seqlen;
+
+    const T* const u_b = static_cast<const T*>(p.u);
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    T* const out_b = static_cast<T*>(p.out);
+    const T* const z_b = static_cast<const T*>(p.z);
+    T* const outz_b = static_cast<T*>(p.out_z);
+    const uint32_t o_u = static_cast<uint32_t>((int64_t)b * p.u_batch_stride + (int64_t)dc * p.u_d_stride);
+    const uint32_t o_dt = static_cast<uint32_t>((int64_t)b * p.delta_batch_stride + (int64_t)dc * p.delta_d_stride);
+    const uint32_t o_out = static_cast<uint32_t>((int64_t)b * p.out_batch_stride + (int64_t)dc * p.out_d_stride);
+    const uint32_t o_z = HZ ? static_cast<uint32_t>((int64_t)b * p.z_batch_stride + (int64_t)dc * p.z_d_stride) : 0u;
+    const uint32_t o_oz = HZ ? static_cast<uint32_t>((int64_t)b * p.out_z_batch_stride + (int64_t)dc * p.out_z_d_stride) : 0u;
+    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
+    float* const xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + dc) * p.n_chunks * xpitch;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)(lane & 15) * p.A_dstate_stride] * kLog2e;
+    float hreg = 0.f;
+
+    const int n_kchunks = (L + CS - 1) / CS;
+    const int cps = (n_kchunks + n_seg - 1) / n_seg;
+    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_kchunks) ? c_lo + cps : n_kchunks;
+    if (seg > 0 && lane < N) {
+        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_seg) * N + lane;
+        for (int s2 = 0; s2 < seg; ++s2) {
+            const float2 pq = cp[(int64_t)s2 * N];
+            hreg = fmaf(pq.x, hreg, pq.y);
+        }
+    }
+    // staging: a group = 4 states x 2 tensors x 1024 positions = 1024 pieces of 8 values; thread t owns pieces t and
+    // t + 512: tensor pid >> 9, state (pid >> 7) & 3, positions 8 (pid & 127) .. + 7 of the chunk
+    Raw8<T, REV> stg[2];
+    bool st_ok[2] = {false, false};
+    auto stage_issue = [&](int gi) __attribute__((always_inline)) {   // gi = 4 chunk + state group, global order
+        const int cc = gi >> 2, n0 = (gi & 3) * kLG;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pid = (int)threadIdx.x + kLW * kWave * h;
+            const int ten = pid >> 9, n = n0 + ((pid >> 7) & 3), l8 = cc * CS + (pid & 127) * 8;
+            st_ok[h] = cc < c_hi && l8 < L;
+            const T* src = ten ? Cv + (int64_t)n * p.C_dstate_stride : Bv + (int64_t)n * p.B_dstate_stride;
+            stg[h].load(src, REV ? L - l8 - 8 : l8, st_ok[h]);
+        }
+    };
+    auto stage_commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pid = (int)threadIdx.x + kLW * kWave * h;
+            const int p8 = pid & 127;       // positions 8 p8 .. + 7 = lane p8 / 2, elements 8 (p8 & 1) .. + 7
+            f4 lo, hi;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                lo[i] = st_ok[h] ? stg[h].at(i) : 0.f;
+                hi[i] = st_ok[h] ? stg[h].at(4 + i) : 0.f;
+            }
+            lds_f4p* dst = (lds_f4p*)(smem + buf * kLGroupFloats + (pid >> 7) * (kWave * K)) + (2 * (p8 & 1)) * kWave + (p8 >> 1);
+            dst[0] = lo;
+            dst[kWave] = hi;
+        }
+    };
+    int gi = c_lo * 4;
+    stage_issue(gi);
+    stage_commit(0);
+    __syncthreads();
+    for (int c = c_lo; c < c_hi; ++c) {
+        const int l0 = c * CS + lane * K;
+        const bool ok = l0 < L && row_ok;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;
+        f2 dl2[K / 2], du2[K / 2], y2[K / 2];
+        float sdl = 0.f;
+        {
+            RawP<T, REV> t0, t1;
+            t0.load(u_b, o_u + pl0, ok);
+            t1.load(dt_b, o_dt + pl0, ok);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                float t = t1.at(i) + bias;
+                if (p.delta_softplus) t = softplusf_(t);
+                t = ok ? t : 0.f;  // past the end: delta = 0 -> a = 1, b = 0 (identity)
+                const float uv = t0.at(i);
+                dl2[i / 2][i % 2] = t;
+                du2[i / 2][i % 2] = t * uv;
+                y2[i / 2][i % 2] = Dd * uv;
+                sdl += t;
+            }
+        }
+        auto do_state = [&](const int n, const int buf) __attribute__((always_inline)) {
+            const lds_f4p* bsrc = (const lds_f4p*)(smem + buf * kLGroupFloats + (n & 3) * (kWave * K)) + lane;
+            const lds_f4p* csrc = bsrc + kLG * (kWave * K) / 4;
+            const f4 b0 = bsrc[0], b1 = bsrc[kWave], b2 = bsrc[2 * kWave], b3 = bsrc[3 * kWave];
+            const float An = readlane_f(A_mine, n);
+            const float hin = readlane_f(hreg, n);
+            const f2 An2 = f2{An, An};
+            f2 a2[K / 2], bx2[K / 2];
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f4 bq = k < 2 ? b0 : k < 4 ? b1 : k < 6 ? b2 : b3;
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                bx2[k] = du2[k] * ((k & 1) ? f2{bq.z, bq.w} : f2{bq.x, bq.y});
+            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_ELP(a2, i), px, VMS_ELP(bx2, i));
+            float pa = fast_exp2(sdl * An);  // product of the lane's K a_i
+            wave_scan_fused_p(pa, px);
+            const f4 c0 = csrc[0], c1 = csrc[kWave], c2 = csrc[2 * kWave], c3 = csrc[3 * kWave];   // arrive during the second chain
+            const float ea = dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa);
+            const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
+            float xs = fmaf(ea, hin, ex);
+            const float hend = fmaf(pa, hin, px);  // state after this lane's last element
+            if (p.x_has_sub && ((lane + 1) * K) % 128 == 0 && row_ok) {  // 128-element sub-checkpoints for the backward kernel
+                const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
+                xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
+            }
+            const float hout = readlane_f(hend, 63);
+            if (lane == n) hreg = hout;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
+                VMS_ELP(bx2, i) = xs;  // x_i
+            }
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f4 cq = k < 2 ? c0 : k < 4 ? c1 : k < 6 ? c2 : c3;
+                y2[k] = pk_fma_p((k & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y}, bx2[k], y2[k]);
+            }
+        };
+#pragma unroll 1
+        for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
+            const int buf = gi & 1;
+            stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
+            do_state(4 * sg, buf);
+            do_state(4 * sg + 1, buf);
+            do_state(4 * sg + 2, buf);
+            do_state(4 * sg + 3, buf);
+            stage_commit(buf ^ 1);   // every wave left that buffer at the previous barrier
+            __syncthreads();
+        }
+        float y[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) y[i] = VMS_ELP(y2, i);
+        if (ok) store_p<T, REV>(out_b + (o_out + pl0), y);
+        if (HZ) {
+            RawP<T, REV> tz;
+            tz.load(z_b, o_z + pl0, ok);
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const float zv = tz.at(i);
+                y[i] *= zv * sigmoidf_(zv);
+            }
+            if (p.out_z_accumulate) {
+                RawP<T, REV> told;
+                told.load(outz_b, o_oz + pl0, ok);
+#pragma unroll
+                for (int i = 0; i < K; ++i) y[i] += told.at(i);
+            }
+            if (ok) store_p<T, REV>(outz_b + (o_oz + pl0), y);
+        }
+        const bool last = c == n_kchunks - 1;
+        const int pos = (c + 1) * CS;
+        if (lane < N && row_ok && (last || pos % 1024 == 0)) {
+            const int blk = last ? (L - 1) / 2048 : (pos - 1) / 2048;
+            const int r = (last ? L : pos) - blk * 2048;
+            float* xb = xck + (int64_t)blk * xpitch;
+            if (r <= 1024) xb[2 * lane] = hreg;
+            if (r == 2048 || last) xb[2 * lane + 1] = hreg;
+        }
+    }
+}
+
+
 // ---- state carries of a sequence-split forward --------------------------------------------------------------------
 // (P, q) per (row, state) and range of chunks: the state leaving the range is P x_in + q, P = exp2(A sum(delta)),
 // q = the recurrence run from x = 0.  The forward kernel without its C / y / z half (~60 % of its work).
@@ -432,9 +653,17 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
         else hipLaunchKernelGGL((scan_fwd_carry_kernel<T, false>), cgrid, block, 0, stream, p, n_seg, carry);
         grid = dim3(p.batch * tiles * n_seg);
     }
+#ifdef VMS_FWD_NO_LDS
+    constexpr bool lds_ok = false;            // A/B builds: the per-wave B / C kernel for every problem
+#else
+    const bool lds_ok = !rag && (p.dim / p.n_groups) % kLW == 0;   // a workgroup's rows share one B / C group
+#endif
+    const size_t smem_l = sizeof(float) * 2 * kLGroupFloats;        // 64 KB
+    const dim3 grid_l(p.batch * ((p.dim + kLW - 1) / kLW) * n_seg), block_l(kLW * kWave);
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p, 1, carry); \
+        else if (lds_ok) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_>), grid_l, block_l, smem_l, stream, p, n_seg, carry); \
         else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p, n_seg, carry); \
     } while (0)
     if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
@@ -442,6 +671,7 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
 #undef VMS_L
     VMS_LAUNCH_CHECK();
     set_last_kernel(n_seg > 1 ? "scan_fwd_pair+split" : (rag ? "scan_fwd_pair_ragged" : "scan_fwd_pair"));
+    (void)lds_ok;
     return VMS_OK;
 }
 
