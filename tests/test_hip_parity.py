@@ -630,6 +630,49 @@ def test_c_abi_is_reentrant_across_threads_and_streams(oracle):
             assert torch.equal(a, b_)
 
 
+def test_compiled_binding_equals_ctypes_binding(monkeypatch):
+    """The two host paths over the C ABI -- the compiled PyTorch extension (csrc/torch_binding, what the reference's
+    pybind11 modules are) and the ctypes binding -- fill the same parameter blocks: every deterministic result is
+    bit-identical, returned lists have the same structure, and errors surface as RuntimeError from both."""
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    import vms_hip
+    if vms_hip.ext() is None:
+        pytest.skip("compiled binding not built (python video-mamba-suite_amd/csrc/torch_binding/build.py)")
+    ext = vms_hip.ext()
+    g = _rows_problem((2, 64, 1569, 1), torch.bfloat16, True, seed=21)   # ragged length: pad_bc + bc_pad through both
+    f = lambda k, dt=torch.bfloat16: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                        f("z"), f("delta_bias", torch.float32), f("g"))
+    w = torch.randn(64, 4, device=DEV)
+
+    def run():
+        out, x, oz = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, True)
+        res = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, True, True)
+        y = causal_conv1d_cuda.causal_conv1d_fwd(u, w, bias, True)
+        cb = causal_conv1d_cuda.causal_conv1d_bwd(u, w, bias, dout, None, True)
+        return [out, x, oz] + list(res) + [y] + list(cb)
+    a = run()
+    assert vms_hip.last_kernel().startswith("conv_bwd")
+    monkeypatch.setattr(vms_hip, "_ext", None)
+    b_ = run()
+    monkeypatch.setattr(vms_hip, "_ext", ext)
+    assert len(a) == len(b_)
+    det = {0, 1, 2, 3, 4, 10, 11, 12, 13}   # out, x, out_z, du, ddelta, dz, recomputed out_z, conv out, conv dx
+    for i, (p_, q_) in enumerate(zip(a, b_)):
+        assert p_.shape == q_.shape and p_.dtype == q_.dtype and p_.stride() == q_.stride(), i
+        if i in det:
+            assert torch.equal(p_, q_), i
+        else:
+            check(p_, q_, 1e-3, f"result {i}")
+    for use_ext in (True, False):
+        monkeypatch.setattr(vms_hip, "_ext", ext if use_ext else None)
+        with pytest.raises(RuntimeError):
+            selective_scan_cuda.fwd(u, dl.float(), A, B, C, D, z, bias, True)
+        with pytest.raises(RuntimeError):
+            causal_conv1d_cuda.causal_conv1d_fwd(u, torch.randn(64, 5, device=DEV), None, True)
+
+
 # BASELINE.json configs at full size: [1] block shape, [2] TimeMamba-B tokens, [3] DBM feature sequence,
 # [4] long-video regime (per-GPU shard)
 FULL_SIZES = {"cfg2_8x1024x8192": (8, 1024, 8192), "cfg3_8x768x3136": (8, 768, 3136),

@@ -32,6 +32,9 @@ def _common(x, weight, bias_):
 
 def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
     """-> out   (causal_conv1d.cpp:130-189)"""
+    ext = _k.ext()
+    if ext is not None:   # compiled binding: same checks / allocations / launch in C++
+        return ext.conv_fwd(x, weight, bias_, bool(silu_activation), bool(reverse))
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
     _check(x.stride(2) == 1 or x.stride(1) == 1, "x.stride(2) == 1 || x.stride(1) == 1")
@@ -46,6 +49,9 @@ def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
 
 def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False, zeroed=None, accumulate_dx=False):
     """-> [dx, dweight, dbias]   (causal_conv1d.cpp:191-268)"""
+    ext = _k.ext()
+    if ext is not None:
+        return ext.conv_bwd(x, weight, bias_, dout, dx_, bool(silu_activation), bool(reverse), zeroed, bool(accumulate_dx))
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
     _check(dout.is_cuda, "dout.is_cuda()")
@@ -82,6 +88,9 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=Fals
 
 def causal_conv1d_update(x, conv_state, weight, bias_, silu_activation):
     """-> out; conv_state is updated in place   (causal_conv1d.cpp:270-327)"""
+    ext = _k.ext()
+    if ext is not None:
+        return ext.conv_update(x, conv_state, weight, bias_, bool(silu_activation))
     _check(x.dim() == 2, "x must be (batch, dim)")
     _common(x, weight, bias_)
     _check(conv_state.dtype == x.dtype, "conv_state.scalar_type() == input_type")

@@ -1,0 +1,422 @@
+// vms_torch.cpp -- compiled binding of the C ABI (include/vms_hip.h) for PyTorch: the module the Python mirrors
+// selective_scan_cuda.py / causal_conv1d_cuda.py forward to when it has been built.
+//
+// It plays the part of the reference's two pybind11 host files
+//   mamba/csrc/selective_scan/selective_scan.cpp:226-497        (fwd, bwd)
+//   causal-conv1d/csrc/causal_conv1d.cpp:130-333                 (causal_conv1d_fwd, _bwd, _update)
+// checks (TORCH_CHECK -> RuntimeError, same expressions), output allocation rules (out = empty_like(delta), fp32 dB /
+// dC cast on return, caller-owned dz / dx), parameter-block fill, device guard + current stream -- all in C++, so that
+// a launch costs microseconds of host time instead of the ~40-60 us of the ctypes path (what small problems such as
+// the DBM block at (2, 2304, 512) are bound by).  Nothing here computes: the kernels live in libvms_hip.so.
+#include <torch/extension.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../../include/vms_hip.h"
+
+namespace {
+
+using torch::Tensor;
+using OptT = c10::optional<Tensor>;
+
+int dtype_code(const Tensor& t) {
+    switch (t.scalar_type()) {
+        case at::kFloat: return VMS_F32;
+        case at::kHalf: return VMS_F16;
+        case at::kBFloat16: return VMS_BF16;
+        default: TORCH_CHECK(false, "unsupported dtype ", t.scalar_type(), ": expected float32, float16 or bfloat16");
+    }
+    return 0;
+}
+bool is_itype(const Tensor& t) {
+    return t.scalar_type() == at::kFloat || t.scalar_type() == at::kHalf || t.scalar_type() == at::kBFloat16;
+}
+const void* cptr(const OptT& t) { return t.has_value() ? t->data_ptr() : nullptr; }
+void* mptr(const OptT& t) { return t.has_value() ? t->data_ptr() : nullptr; }
+
+// ---- optional per-launch device timing (bench.py): two events per C-ABI call on the launch stream ---------------
+struct Timed { std::string name; hipEvent_t e0, e1; };
+bool g_timing = false;
+std::vector<Timed> g_timed;
+
+template <typename P>
+void call(const char* name, int (*fn)(const P*, void*), const P& p, const Tensor& ref) {
+    TORCH_CHECK(ref.is_cuda(), name, ": tensors must be on a GPU (no CPU path in this library)");
+    c10::DeviceGuard guard(ref.device());
+    hipStream_t s = c10::hip::getCurrentHIPStream(ref.device().index()).stream();
+    int rc;
+    if (g_timing) {
+        Timed t{name, nullptr, nullptr};
+        (void)hipEventCreate(&t.e0);
+        (void)hipEventCreate(&t.e1);
+        (void)hipEventRecord(t.e0, s);
+        rc = fn(&p, s);
+        (void)hipEventRecord(t.e1, s);
+        g_timed.push_back(t);
+    } else {
+        rc = fn(&p, s);
+    }
+    TORCH_CHECK(rc == 0, name, " failed (status ", rc, "): ", vms_last_error());
+}
+
+// ---- selective scan -------------------------------------------------------------------------------------------------
+struct ScanDims { int64_t batch, dim, seqlen, dstate; bool var_B, var_C; };
+
+ScanDims scan_checks(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
+                     const OptT& z_, const OptT& delta_bias_) {   // selective_scan.cpp:233-305
+    TORCH_CHECK(is_itype(u), "selective_scan: input dtype ", u.scalar_type(), " not supported");
+    TORCH_CHECK(!A.is_complex(), "selective_scan: complex A is not supported by the MI355X HIP path");
+    TORCH_CHECK(A.scalar_type() == at::kFloat, "selective_scan: A must be float32");
+    const bool var_B = B.dim() >= 3, var_C = C.dim() >= 3;
+    TORCH_CHECK(delta.scalar_type() == u.scalar_type(), "delta.scalar_type() == input_type");
+    TORCH_CHECK(B.scalar_type() == (var_B ? u.scalar_type() : A.scalar_type()), "B.scalar_type() == (!is_variable_B ? weight_type : input_type)");
+    TORCH_CHECK(C.scalar_type() == (var_C ? u.scalar_type() : A.scalar_type()), "C.scalar_type() == (!is_variable_C ? weight_type : input_type)");
+    TORCH_CHECK(u.is_cuda(), "u.is_cuda()");
+    TORCH_CHECK(delta.is_cuda(), "delta.is_cuda()");
+    TORCH_CHECK(A.is_cuda(), "A.is_cuda()");
+    TORCH_CHECK(B.is_cuda(), "B.is_cuda()");
+    TORCH_CHECK(C.is_cuda(), "C.is_cuda()");
+    TORCH_CHECK(u.dim() == 3, "u must be (batch, dim, seqlen)");
+    TORCH_CHECK(u.stride(-1) == 1, "u.stride(-1) == 1");
+    TORCH_CHECK(delta.stride(-1) == 1, "delta.stride(-1) == 1");
+    const int64_t batch = u.size(0), dim = u.size(1), seqlen = u.size(2), dstate = A.size(1);
+    const int64_t n_groups = var_B ? B.size(1) : 1;
+    TORCH_CHECK(dstate <= 256, "selective_scan only supports state dimension <= 256");
+    TORCH_CHECK(delta.dim() == 3 && delta.size(0) == batch && delta.size(1) == dim && delta.size(2) == seqlen, "delta must have shape (batch, dim, seqlen)");
+    TORCH_CHECK(A.dim() == 2 && A.size(0) == dim, "A must have shape (dim, dstate)");
+    if (!var_B) {
+        TORCH_CHECK(B.dim() == 2 && B.size(0) == dim && B.size(1) == dstate, "B must have shape (dim, dstate)");
+    } else {
+        TORCH_CHECK(B.dim() == 4 && B.size(0) == batch && B.size(2) == dstate && B.size(3) == seqlen, "B must have shape (batch, n_groups, dstate, seqlen)");
+        TORCH_CHECK(B.stride(-1) == 1, "B.stride(-1) == 1");
+    }
+    if (!var_C) {
+        TORCH_CHECK(C.dim() == 2 && C.size(0) == dim && C.size(1) == dstate, "C must have shape (dim, dstate)");
+    } else {
+        TORCH_CHECK(C.dim() == 4 && C.size(0) == batch && C.size(2) == dstate && C.size(3) == seqlen && (!var_B || C.size(1) == n_groups),
+                    "C must have shape (batch, n_groups, dstate, seqlen)");
+        TORCH_CHECK(C.stride(-1) == 1, "C.stride(-1) == 1");
+    }
+    auto vec_check = [&](const OptT& t, const char* name) {
+        if (!t.has_value()) return;
+        TORCH_CHECK(t->scalar_type() == at::kFloat, name, " must be float32");
+        TORCH_CHECK(t->is_cuda(), name, ".is_cuda()");
+        TORCH_CHECK(t->stride(-1) == 1, name, ".stride(-1) == 1");
+        TORCH_CHECK(t->dim() == 1 && t->size(0) == dim, name, " must have shape (dim,)");
+    };
+    vec_check(D_, "D");
+    vec_check(delta_bias_, "delta_bias");
+    if (z_.has_value()) {
+        TORCH_CHECK(z_->scalar_type() == u.scalar_type(), "z.scalar_type() == input_type");
+        TORCH_CHECK(z_->is_cuda(), "z.is_cuda()");
+        TORCH_CHECK(z_->stride(-1) == 1, "z.stride(-1) == 1");
+        TORCH_CHECK(z_->dim() == 3 && z_->size(0) == batch && z_->size(1) == dim && z_->size(2) == seqlen, "z must have shape (batch, dim, seqlen)");
+    }
+    return {batch, dim, seqlen, dstate, var_B, var_C};
+}
+
+void fill_scan(vms_scan_fwd_params& P, const ScanDims& s, const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B,
+               const Tensor& C, const OptT& D_, const OptT& z_, const OptT& delta_bias_, const OptT& out, const OptT& out_z,
+               const OptT& x, bool delta_softplus, bool reverse, int64_t impl, int64_t segments, int64_t bc_pad) {
+    P = vms_scan_fwd_params{};
+    P.batch = (int)s.batch; P.dim = (int)s.dim; P.seqlen = (int)s.seqlen; P.dstate = (int)s.dstate;
+    P.n_groups = s.var_B ? (int)B.size(1) : (s.var_C ? (int)C.size(1) : 1);
+    P.n_chunks = (int)((s.seqlen + 2047) / 2048);
+    P.dtype = dtype_code(u);
+    P.is_variable_B = s.var_B; P.is_variable_C = s.var_C; P.delta_softplus = delta_softplus;
+    P.reverse = reverse; P.impl = (int)impl; P.segments = (int)segments; P.bc_pad = (int)bc_pad;
+    P.u = u.data_ptr(); P.delta = delta.data_ptr(); P.A = A.data_ptr(); P.B = B.data_ptr(); P.C = C.data_ptr();
+    P.D = cptr(D_); P.z = cptr(z_); P.delta_bias = cptr(delta_bias_);
+    P.out = mptr(out); P.out_z = mptr(out_z); P.x = mptr(x);
+    if (x.has_value()) {
+        P.x_chunk_stride = x->stride(2);
+        P.x_has_sub = (x->stride(2) >= 18 * s.dstate && x->stride(3) == 1) ? 1 : 0;
+    }
+    P.u_batch_stride = u.stride(0); P.u_d_stride = u.stride(1);
+    P.delta_batch_stride = delta.stride(0); P.delta_d_stride = delta.stride(1);
+    if (z_.has_value()) { P.z_batch_stride = z_->stride(0); P.z_d_stride = z_->stride(1); }
+    if (out.has_value()) { P.out_batch_stride = out->stride(0); P.out_d_stride = out->stride(1); }
+    if (out_z.has_value()) { P.out_z_batch_stride = out_z->stride(0); P.out_z_d_stride = out_z->stride(1); }
+    P.A_d_stride = A.stride(0); P.A_dstate_stride = A.stride(1);
+    if (s.var_B) { P.B_batch_stride = B.stride(0); P.B_group_stride = B.stride(1); P.B_dstate_stride = B.stride(2); }
+    else { P.B_d_stride = B.stride(0); P.B_dstate_stride = B.stride(1); }
+    if (s.var_C) { P.C_batch_stride = C.stride(0); P.C_group_stride = C.stride(1); P.C_dstate_stride = C.stride(2); }
+    else { P.C_d_stride = C.stride(0); P.C_dstate_stride = C.stride(1); }
+}
+
+// -> [out, x, (out_z)]   (selective_scan.cpp:226-336).  B / C must already carry the padding bc_pad promises.
+std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
+                             const OptT& z_, const OptT& delta_bias_, bool delta_softplus, bool reverse, const OptT& out_z_into,
+                             int64_t bc_pad, int64_t impl, int64_t segments) {
+    const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
+    TORCH_CHECK(impl < VMS_IMPL_ROWS, "the row-major layout (VMS_SCAN_IMPL=rows) is served by the ctypes binding");
+    Tensor out = at::empty_like(delta);   // inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
+    OptT out_z;
+    if (z_.has_value()) out_z = at::empty_like(*z_);
+    if (out_z_into.has_value()) {
+        TORCH_CHECK(z_.has_value(), "out_z_into needs z");
+        TORCH_CHECK(out_z_into->scalar_type() == u.scalar_type() && out_z_into->is_cuda() && out_z_into->stride(-1) == 1 &&
+                        out_z_into->dim() == 3 && out_z_into->size(0) == s.batch && out_z_into->size(1) == s.dim && out_z_into->size(2) == s.seqlen,
+                    "out_z_into must be (batch, dim, seqlen), input dtype, unit last stride");
+        out_z = out_z_into;
+    }
+    const int64_t n_chunks = (s.seqlen + 2047) / 2048;
+    // the reference-shaped x is a view of a wider buffer whose tail carries 128-element sub-checkpoints for the
+    // backward kernel (include/vms_hip.h)
+    Tensor x = at::empty({s.batch, s.dim, n_chunks, s.dstate * 18}, u.options().dtype(at::kFloat)).narrow(3, 0, s.dstate * 2);
+    vms_scan_fwd_params P;
+    fill_scan(P, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, impl, segments, bc_pad);
+    P.x_has_sub = 1;
+    P.out_z_accumulate = out_z_into.has_value();
+    Tensor ws;
+    const int64_t nws = vms_scan_fwd_workspace_bytes(&P);   // state carries of a sequence-split forward
+    if (nws > 0) {
+        ws = at::empty({nws}, u.options().dtype(at::kByte));
+        P.workspace = ws.data_ptr(); P.workspace_bytes = nws;
+    }
+    call("vms_selective_scan_fwd", vms_selective_scan_fwd, P, u);
+    std::vector<Tensor> res{out, x};
+    if (z_.has_value()) res.push_back(*out_z);
+    return res;
+}
+
+// -> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492); B / C as for scan_fwd;
+// Bshape / Cshape: the caller's unpadded B / C, whose shapes and dtypes dB / dC take
+std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
+                           const OptT& z_, const OptT& delta_bias_, const Tensor& dout, const OptT& x_, const OptT& out_, const OptT& dz_,
+                           bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
+                           bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape) {
+    const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
+    auto bdl = [&](const Tensor& t) { return t.dim() == 3 && t.size(0) == s.batch && t.size(1) == s.dim && t.size(2) == s.seqlen; };
+    TORCH_CHECK(dout.scalar_type() == u.scalar_type(), "dout.scalar_type() == input_type");
+    TORCH_CHECK(dout.is_cuda(), "dout.is_cuda()");
+    TORCH_CHECK(dout.stride(-1) == 1, "dout.stride(-1) == 1");
+    TORCH_CHECK(bdl(dout), "dout must have shape (batch, dim, seqlen)");
+    OptT out, dz, out_z;
+    if (z_.has_value()) {
+        TORCH_CHECK(out_.has_value(), "out_.has_value()");
+        out = out_;
+        TORCH_CHECK(out->scalar_type() == u.scalar_type() && out->is_cuda() && out->stride(-1) == 1 && bdl(*out),
+                    "out must be (batch, dim, seqlen), input dtype, unit last stride");
+        TORCH_CHECK(!accumulate_dz || dz_.has_value(), "accumulate_dz needs the dz tensor to add to");
+        if (dz_.has_value()) {
+            dz = dz_;
+            TORCH_CHECK(dz->scalar_type() == u.scalar_type() && dz->is_cuda() && dz->stride(-1) == 1 && bdl(*dz),
+                        "dz must be (batch, dim, seqlen), input dtype, unit last stride");
+        } else {
+            dz = at::empty_like(*z_);
+        }
+        if (recompute_out_z) out_z = at::empty_like(*out);
+    }
+    const int64_t n_chunks = (s.seqlen + 2047) / 2048;
+    if (n_chunks > 1) TORCH_CHECK(x_.has_value(), "x_.has_value()");
+    if (x_.has_value()) {
+        TORCH_CHECK(x_->scalar_type() == at::kFloat && x_->is_cuda() && x_->dim() == 4 && x_->size(0) == s.batch && x_->size(1) == s.dim &&
+                        x_->size(2) == n_chunks && x_->size(3) == 2 * s.dstate && x_->stride(3) == 1 &&
+                        x_->stride(1) == n_chunks * x_->stride(2) && x_->stride(0) == s.dim * x_->stride(1),
+                    "x must be the (batch, dim, n_chunks, 2*dstate) checkpoint tensor returned by fwd");
+    } else {
+        TORCH_CHECK(s.seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024");
+    }
+    Tensor du = at::empty_like(u), ddelta = at::empty_like(delta);
+    Tensor dA, dB, dC;
+    OptT dD, dbias;
+    const auto f32 = u.options().dtype(at::kFloat);
+    if (zeroed.has_value()) {
+        int64_t need = A.numel() + Bshape.numel() + Cshape.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
+        TORCH_CHECK(zeroed->scalar_type() == at::kFloat && zeroed->is_cuda() && zeroed->dim() == 1 && zeroed->is_contiguous() && zeroed->numel() >= need,
+                    "zeroed must be a flat float32 tensor of at least bwd_accumulator_elems() elements");
+        int64_t o = 0;
+        auto carve = [&](const Tensor& like) { Tensor t = zeroed->narrow(0, o, like.numel()).view(like.sizes()); o += like.numel(); return t; };
+        dA = carve(A); dB = carve(Bshape); dC = carve(Cshape);
+        if (D_.has_value()) dD = carve(*D_);
+        if (delta_bias_.has_value()) dbias = carve(*delta_bias_);
+    } else {
+        dA = at::zeros_like(A);
+        dB = at::zeros(Bshape.sizes(), f32);
+        dC = at::zeros(Cshape.sizes(), f32);
+        if (D_.has_value()) dD = at::zeros_like(*D_);
+        if (delta_bias_.has_value()) dbias = at::zeros_like(*delta_bias_);
+    }
+    vms_scan_bwd_params Q{};
+    fill_scan(Q.f, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x_, delta_softplus, reverse, impl, segments, bc_pad);
+    Q.dout = dout.data_ptr(); Q.du = du.data_ptr(); Q.ddelta = ddelta.data_ptr(); Q.dz = mptr(dz);
+    Q.dA = dA.data_ptr<float>(); Q.dB = dB.data_ptr<float>(); Q.dC = dC.data_ptr<float>();
+    Q.dD = dD.has_value() ? dD->data_ptr<float>() : nullptr;
+    Q.ddelta_bias = dbias.has_value() ? dbias->data_ptr<float>() : nullptr;
+    Q.dout_batch_stride = dout.stride(0); Q.dout_d_stride = dout.stride(1);
+    Q.du_batch_stride = du.stride(0); Q.du_d_stride = du.stride(1);
+    Q.ddelta_batch_stride = ddelta.stride(0); Q.ddelta_d_stride = ddelta.stride(1);
+    if (dz.has_value()) { Q.dz_batch_stride = dz->stride(0); Q.dz_d_stride = dz->stride(1); }
+    Q.dA_d_stride = dA.stride(0); Q.dA_dstate_stride = dA.stride(1);
+    if (s.var_B) { Q.dB_batch_stride = dB.stride(0); Q.dB_group_stride = dB.stride(1); Q.dB_dstate_stride = dB.stride(2); }
+    else { Q.dB_d_stride = dB.stride(0); Q.dB_dstate_stride = dB.stride(1); }
+    if (s.var_C) { Q.dC_batch_stride = dC.stride(0); Q.dC_group_stride = dC.stride(1); Q.dC_dstate_stride = dC.stride(2); }
+    else { Q.dC_d_stride = dC.stride(0); Q.dC_dstate_stride = dC.stride(1); }
+    Q.dz_accumulate = accumulate_dz;
+    Tensor ws;
+    const int64_t nws = vms_scan_bwd_workspace_bytes(&Q);   // adjoint carries of a sequence-split backward
+    if (nws > 0) {
+        ws = at::empty({nws}, u.options().dtype(at::kByte));
+        Q.f.workspace = ws.data_ptr(); Q.f.workspace_bytes = nws;
+    }
+    call("vms_selective_scan_bwd", vms_selective_scan_bwd, Q, u);
+    if (!keep_fp32) { dB = dB.to(Bshape.scalar_type()); dC = dC.to(Cshape.scalar_type()); }
+    std::vector<OptT> res{du, ddelta, dA, dB, dC, dD, dbias};
+    if (z_.has_value()) res.push_back(dz);
+    if (recompute_out_z) res.push_back(out_z);
+    return res;
+}
+
+// ---- causal conv1d ----------------------------------------------------------------------------------------------------
+void conv_common(const Tensor& x, const Tensor& weight, const OptT& bias_) {   // causal_conv1d.cpp:136-170
+    TORCH_CHECK(is_itype(x), "causal_conv1d: input dtype ", x.scalar_type(), " not supported");
+    TORCH_CHECK(is_itype(weight), "causal_conv1d: weight dtype ", weight.scalar_type(), " not supported");
+    TORCH_CHECK(x.is_cuda(), "x.is_cuda()");
+    TORCH_CHECK(weight.is_cuda(), "weight.is_cuda()");
+    const int64_t width = weight.size(-1);
+    TORCH_CHECK(weight.dim() == 2 && weight.size(0) == x.size(1), "weight must have shape (dim, width)");
+    TORCH_CHECK(width >= 2 && width <= 4, "causal_conv1d only supports width between 2 and 4");
+    if (bias_.has_value()) {
+        TORCH_CHECK(bias_->scalar_type() == weight.scalar_type(), "bias.scalar_type() == weight_type");
+        TORCH_CHECK(bias_->is_cuda(), "bias.is_cuda()");
+        TORCH_CHECK(bias_->stride(-1) == 1, "bias.stride(-1) == 1");
+        TORCH_CHECK(bias_->dim() == 1 && bias_->size(0) == x.size(1), "bias must have shape (dim,)");
+    }
+}
+void fill_conv(vms_conv_fwd_params& P, const Tensor& x, const Tensor& weight, const OptT& bias, const OptT& out, bool silu, bool reverse) {
+    P = vms_conv_fwd_params{};
+    P.batch = (int)x.size(0); P.dim = (int)x.size(1); P.seqlen = (int)x.size(2); P.width = (int)weight.size(-1);
+    P.dtype = dtype_code(x); P.wdtype = dtype_code(weight);
+    P.silu_activation = silu; P.reverse = reverse;
+    P.x = x.data_ptr(); P.weight = weight.data_ptr(); P.bias = cptr(bias); P.out = mptr(out);
+    P.x_batch_stride = x.stride(0); P.x_c_stride = x.stride(1); P.x_l_stride = x.stride(2);
+    P.weight_c_stride = weight.stride(0); P.weight_width_stride = weight.stride(1);
+    if (out.has_value()) { P.out_batch_stride = out->stride(0); P.out_c_stride = out->stride(1); P.out_l_stride = out->stride(2); }
+}
+Tensor channel_last_like(const Tensor& x) {
+    return at::empty({x.size(0), x.size(2), x.size(1)}, x.options()).transpose(1, 2);
+}
+
+Tensor conv_fwd(const Tensor& x, const Tensor& weight, const OptT& bias_, bool silu, bool reverse) {   // causal_conv1d.cpp:130-189
+    TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
+    conv_common(x, weight, bias_);
+    TORCH_CHECK(x.stride(2) == 1 || x.stride(1) == 1, "x.stride(2) == 1 || x.stride(1) == 1");
+    const bool channel_last = x.stride(1) == 1 && x.stride(2) > 1;
+    if (channel_last) TORCH_CHECK(x.size(1) % 8 == 0, "causal_conv1d only supports channel dimension divisible by 8 for now");
+    Tensor out = at::empty_like(x);
+    if (channel_last && out.stride(1) != 1) out = channel_last_like(x);
+    vms_conv_fwd_params P;
+    fill_conv(P, x, weight, bias_, out, silu, reverse);
+    call("vms_causal_conv1d_fwd", vms_causal_conv1d_fwd, P, x);
+    return out;
+}
+
+std::vector<OptT> conv_bwd(const Tensor& x, const Tensor& weight, const OptT& bias_, Tensor dout, const OptT& dx_, bool silu,
+                           bool reverse, const OptT& zeroed, bool accumulate_dx) {   // causal_conv1d.cpp:191-268
+    TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
+    conv_common(x, weight, bias_);
+    TORCH_CHECK(dout.is_cuda(), "dout.is_cuda()");
+    TORCH_CHECK(dout.sizes() == x.sizes(), "dout must have the shape of x");
+    TORCH_CHECK(x.stride(2) == 1 || x.stride(1) == 1, "x.stride(2) == 1 || x.stride(1) == 1");
+    const bool channel_last = x.stride(1) == 1 && x.stride(2) > 1;
+    if (!channel_last && dout.stride(2) != 1) dout = dout.contiguous();
+    if (channel_last && dout.stride(1) != 1) dout = dout.transpose(-1, -2).contiguous().transpose(-1, -2);
+    Tensor dx;
+    if (dx_.has_value()) {
+        dx = *dx_;
+        TORCH_CHECK(dx.scalar_type() == x.scalar_type(), "dx.scalar_type() == input_type");
+        TORCH_CHECK(dx.is_cuda(), "dx.is_cuda()");
+        TORCH_CHECK(dx.sizes() == x.sizes(), "dx must have the shape of x");
+        TORCH_CHECK(channel_last ? dx.stride(1) == 1 : dx.stride(2) == 1, "dx must have x's unit-stride axis");
+    } else {
+        dx = at::empty_like(x);
+        if (channel_last && dx.stride(1) != 1) dx = channel_last_like(x);
+    }
+    Tensor dweight;
+    OptT dbias;
+    if (zeroed.has_value()) {
+        const int64_t nw = weight.numel(), nb = bias_.has_value() ? bias_->numel() : 0;
+        TORCH_CHECK(zeroed->scalar_type() == at::kFloat && zeroed->is_cuda() && zeroed->dim() == 1 && zeroed->is_contiguous() && zeroed->numel() >= nw + nb,
+                    "zeroed must be a flat float32 tensor of weight.numel() + bias.numel() elements");
+        dweight = zeroed->narrow(0, 0, nw).view(weight.sizes());
+        if (bias_.has_value()) dbias = zeroed->narrow(0, nw, nb);
+    } else {
+        dweight = at::zeros(weight.sizes(), weight.options().dtype(at::kFloat));
+        if (bias_.has_value()) dbias = at::zeros(bias_->sizes(), bias_->options().dtype(at::kFloat));
+    }
+    TORCH_CHECK(!accumulate_dx || dx_.has_value(), "accumulate_dx needs the dx tensor to add to");
+    vms_conv_bwd_params Q{};
+    fill_conv(Q.f, x, weight, bias_, c10::nullopt, silu, reverse);
+    Q.dout = dout.data_ptr(); Q.dx = dx.data_ptr(); Q.dweight = dweight.data_ptr<float>();
+    Q.dbias = dbias.has_value() ? dbias->data_ptr<float>() : nullptr;
+    Q.dout_batch_stride = dout.stride(0); Q.dout_c_stride = dout.stride(1); Q.dout_l_stride = dout.stride(2);
+    Q.dx_batch_stride = dx.stride(0); Q.dx_c_stride = dx.stride(1); Q.dx_l_stride = dx.stride(2);
+    Q.dweight_c_stride = dweight.stride(0); Q.dweight_width_stride = dweight.stride(1);
+    Q.dx_accumulate = accumulate_dx;
+    call("vms_causal_conv1d_bwd", vms_causal_conv1d_bwd, Q, x);
+    OptT db;
+    if (bias_.has_value()) db = dbias->to(bias_->scalar_type());
+    return {dx, dweight.to(weight.scalar_type()), db};
+}
+
+Tensor conv_update(const Tensor& x, const Tensor& conv_state, const Tensor& weight, const OptT& bias_, bool silu) {   // causal_conv1d.cpp:270-327
+    TORCH_CHECK(x.dim() == 2, "x must be (batch, dim)");
+    conv_common(x, weight, bias_);
+    TORCH_CHECK(conv_state.scalar_type() == x.scalar_type(), "conv_state.scalar_type() == input_type");
+    TORCH_CHECK(conv_state.is_cuda(), "conv_state.is_cuda()");
+    TORCH_CHECK(conv_state.dim() == 3 && conv_state.size(0) == x.size(0) && conv_state.size(1) == x.size(1) && conv_state.size(2) == weight.size(-1),
+                "conv_state must have shape (batch, dim, width)");
+    Tensor out = at::empty_like(x);
+    vms_conv_fwd_params P{};
+    P.batch = (int)x.size(0); P.dim = (int)x.size(1); P.seqlen = 1; P.width = (int)weight.size(-1);
+    P.dtype = dtype_code(x); P.wdtype = dtype_code(weight); P.silu_activation = silu;
+    P.x = x.data_ptr(); P.weight = weight.data_ptr(); P.bias = cptr(bias_); P.out = out.data_ptr();
+    P.x_batch_stride = x.stride(0); P.x_c_stride = x.stride(1); P.x_l_stride = 1;
+    P.weight_c_stride = weight.stride(0); P.weight_width_stride = weight.stride(1);
+    P.out_batch_stride = out.stride(0); P.out_c_stride = out.stride(1); P.out_l_stride = 1;
+    P.conv_state = conv_state.data_ptr();
+    P.conv_state_batch_stride = conv_state.stride(0); P.conv_state_c_stride = conv_state.stride(1); P.conv_state_l_stride = conv_state.stride(2);
+    call("vms_causal_conv1d_update", vms_causal_conv1d_update, P, x);
+    return out;
+}
+
+void timing_start() {
+    g_timed.clear();
+    g_timing = true;
+}
+// -> [(entry point, milliseconds)] in launch order; synchronises the device
+std::vector<std::tuple<std::string, double>> timing_stop() {
+    g_timing = false;
+    (void)hipDeviceSynchronize();
+    std::vector<std::tuple<std::string, double>> out;
+    for (auto& t : g_timed) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+        out.emplace_back(t.name, (double)ms);
+        (void)hipEventDestroy(t.e0);
+        (void)hipEventDestroy(t.e1);
+    }
+    g_timed.clear();
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "compiled PyTorch binding of libvms_hip.so (include/vms_hip.h)";
+    m.def("scan_fwd", &scan_fwd);
+    m.def("scan_bwd", &scan_bwd);
+    m.def("conv_fwd", &conv_fwd);
+    m.def("conv_bwd", &conv_bwd);
+    m.def("conv_update", &conv_update);
+    m.def("timing_start", &timing_start);
+    m.def("timing_stop", &timing_stop);
+    m.def("abi_version", []() { return vms_abi_version(); });
+    m.def("last_kernel", []() { return std::string(vms_last_kernel()); });
+}

@@ -92,6 +92,13 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
     out_z_into (extension): a (batch, dim, seqlen) tensor the gated output is ADDED to (and that is returned as
     out_z) -- the other direction's output of a bidirectional block.
     bc_pad (extension): None = pad B / C here when the length needs it (pad_bc); an int = the caller already did."""
+    ext = _k.ext()
+    impl = _k.scan_impl_from_env()
+    if ext is not None and impl < _k.IMPL_ROWS:   # compiled binding: same checks / allocations / launch in C++
+        if bc_pad is None:
+            B, C, bc_pad = pad_bc(B, C, reverse)
+        return ext.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, bool(delta_softplus), bool(reverse), out_z_into,
+                            bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"))
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
@@ -128,6 +135,16 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
     ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
     accumulate_dz: dz_ += instead of dz_ = (dz_ must be given)."""
+    ext = _k.ext()
+    impl = _k.scan_impl_from_env()
+    if ext is not None and impl < _k.IMPL_ROWS:
+        if bc_pad is None:
+            Bk, Ck, bc_pad = pad_bc(B, C, reverse)
+        else:
+            Bk, Ck = B, C
+        return ext.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out_, dz_, bool(delta_softplus),
+                            bool(recompute_out_z), bool(reverse), zeroed, bool(keep_fp32), bool(accumulate_dz), bc_pad, impl,
+                            _k.segments_from_env("VMS_BWD_SEGMENTS"), B, C)
     batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
     _check(dout.is_cuda, "dout.is_cuda()")

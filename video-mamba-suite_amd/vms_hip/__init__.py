@@ -138,7 +138,30 @@ def last_kernel():
     """Kernel family enqueued by this thread's last successful launch call (vms_hip.h vms_last_kernel)."""
     return lib().vms_last_kernel().decode()
 
+
+def segments_from_env(name):
+    return _segments_from_env(name)
+
 _lib = None
+_ext = False   # the compiled PyTorch binding (_vms_torch.so, csrc/torch_binding): False = not looked for yet, None = absent
+
+
+def ext():
+    """The compiled binding of the scan / conv entry points, or None when it has not been built (or VMS_NO_TORCH_EXT=1):
+    the ctypes path below then serves every call.  Both end in the same C ABI."""
+    global _ext
+    if _ext is False:
+        _ext = None
+        if os.environ.get("VMS_NO_TORCH_EXT") != "1" and "VMS_HIP_LIB" not in os.environ:   # A/B libraries: ctypes only
+            lib()
+            try:
+                import _vms_torch
+                if _vms_torch.abi_version() == 4:
+                    _ext = _vms_torch
+            except ImportError:
+                pass
+    return _ext
+
 
 # Optional per-call device timing (used by bench.py): when a list is installed here every C-ABI
 # call is bracketed by two events on the stream the kernel is launched on.
@@ -148,6 +171,8 @@ _timing = None
 def start_timing():
     global _timing
     _timing = []
+    if ext() is not None:
+        ext().timing_start()
 
 
 def stop_timing():
@@ -158,6 +183,9 @@ def stop_timing():
     out = {}
     for name, e0, e1 in rec or []:
         out.setdefault(name, []).append(e0.elapsed_time(e1))
+    if ext() is not None:
+        for name, ms in ext().timing_stop():
+            out.setdefault(name, []).append(ms)
     return out
 
 
