@@ -250,12 +250,13 @@ int vms_layer_norm_bwd_partials(const vms_norm_params *p);
 /* ---- single-token SSM step ------------------------------------------------------------------
  * replaces the Triton kernel behind selective_state_update
  * (mamba/mamba_ssm/ops/triton/selective_state_update.py:16-154).
- * state (batch, dim, dstate) in/out; x, dt, z, out (batch, dim) in x_dtype; A (dim, dstate), D, dt_bias
- * (dim) in w_dtype; B, C (batch, dstate) in bc_dtype; D, z, dt_bias may be NULL. */
+ * state (batch, dim, dstate) in/out; x, out (batch, dim) in x_dtype; dt, z (batch, dim) in dt_dtype / z_dtype;
+ * A (dim, dstate), D, dt_bias (dim) in w_dtype; B, C (batch, dstate) in bc_dtype; D, z, dt_bias may be NULL. */
 typedef struct {
     int32_t batch, dim, dstate;
     int32_t state_dtype, x_dtype, bc_dtype, w_dtype;
     int32_t dt_softplus;
+    int32_t dt_dtype, z_dtype;   /* ABI v4: dt and z in their own dtypes, as the reference's kernel loads them (:77-83) */
     void *state;
     const void *x, *dt, *A, *B, *C, *D, *z, *dt_bias;
     void *out;

@@ -279,3 +279,21 @@ def test_block_stack_host_logic(fake_extensions, name, fused_add_norm):
             rg = T(g["grad." + prefix + k])
             err = (p.grad - rg).abs().max().item()
             assert err <= 3e-3 * max(1.0, rg.abs().max().item()), (prefix + k, err, rg.abs().max().item())
+
+
+def test_complex_A_is_served_by_the_reference_statement():
+    """SURVEY.md 8a a-excl: complex A has no HIP kernel; selective_scan_fn routes it to selective_scan_ref with a
+    warning (any device, differentiable), the raw extension raises."""
+    torch.manual_seed(0)
+    b, d, n, L = 2, 4, 8, 24
+    u, delta = torch.randn(b, d, L, requires_grad=True), torch.rand(b, d, L)
+    A = torch.complex(-torch.rand(d, n), torch.randn(d, n))
+    B, C = torch.randn(b, n, 2 * L), torch.randn(b, n, 2 * L)   # interleaved (re, im) along L (SSI:100-104)
+    with pytest.warns(RuntimeWarning):
+        out = ssi.selective_scan_fn(u, delta, A, B, C, delta_softplus=True)
+    ref = ssi.selective_scan_ref(u, delta, A, B, C, delta_softplus=True)
+    assert torch.equal(out, ref) and out.dtype == u.dtype
+    out.sum().backward()
+    assert u.grad is not None and torch.isfinite(u.grad).all()
+    with pytest.raises(RuntimeError):
+        selective_scan_cuda.fwd(u.detach(), delta, A, B, C, None, None, None, True)

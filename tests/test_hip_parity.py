@@ -15,7 +15,29 @@ from conftest import golden_names, load_golden
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
+# ---- the one tolerance table of this file -------------------------------------------------------------------------
+# TOL = north_star's bar per I/O dtype (1e-3 fp32, 1e-2 bf16; fp16 in between), relative to the tensor's scale
+# (max |reference|).  Every comparison is TOL[dtype] x a factor from FACTOR, by what the tensor is and what it is
+# compared with:
+#   "oracle"  the f64 C oracle on the very (rounded) inputs the kernel saw        -- the tight one
+#   "golden"  the fixture the reference's own fp32 PyTorch path produced          -- carries that path's own rounding
+# Non-reduced tensors (one output element per input element) stay at 1x against the oracle for forward results, 2x for
+# gradients (two chained recurrences) and 2x against the fixtures; sums over rows (dB, dC) 2x; sums over batch x L
+# (dA, dD, ddelta_bias, dweight, dbias, norm dweight / dbias) 5x -- the reference's own tests allow those 10x
+# (test_selective_scan.py:137-149).
 TOL = {torch.float32: 1e-3, torch.bfloat16: 1e-2, torch.float16: 3e-3}
+FACTOR = {
+    "fwd": {"oracle": 1, "golden": 2},            # out, out_z, last_state, conv out, norm y
+    "grad": {"oracle": 2, "golden": 2},           # du, ddelta, dz, conv dx, norm dx
+    "row_sum": {"oracle": 2, "golden": 2},        # dB, dC
+    "batch_sum": {"oracle": 5, "golden": 5},      # dA, dD, ddelta_bias, dweight, dbias
+}
+KIND = {"out": "fwd", "last_state": "fwd", "du": "grad", "ddelta": "grad", "dz": "grad", "dB": "row_sum", "dC": "row_sum",
+        "dA": "batch_sum", "dD": "batch_sum", "ddelta_bias": "batch_sum"}
+
+
+def tol_for(name, itype, vs):
+    return TOL[itype] * FACTOR[KIND[name]][vs]
 
 
 def G(a, dtype=torch.float32, grad=False):
@@ -85,16 +107,10 @@ def test_scan_vs_oracle_and_golden(oracle, name):
     itype = itype_of(g)
     tol = TOL[itype]
     got, want = run_scan(g, itype, oracle)
-    L = g["u"].shape[-1]
-    wide = 5 if L * g["u"].shape[0] > 512 else 2  # sums over batch*L
-    for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
+    for k in KIND:
         if want.get(k) is not None:
-            check(got[k], want[k], tol * (2 if k != "out" else 1), f"{name}:{k} vs oracle")
-            check(got[k], g[k], tol * 3 if itype == torch.float32 else tol * 4, f"{name}:{k} vs golden")
-    for k in ("dA", "dD", "ddelta_bias"):
-        if want.get(k) is not None:
-            check(got[k], want[k], tol * wide, f"{name}:{k} vs oracle")
-            check(got[k], g[k], tol * wide * 2, f"{name}:{k} vs golden")
+            check(got[k], want[k], tol_for(k, itype, "oracle"), f"{name}:{k} vs oracle")
+            check(got[k], g[k], tol_for(k, itype, "golden"), f"{name}:{k} vs golden")
 
 
 @pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
@@ -809,26 +825,53 @@ def test_conv_update(oracle, name, itype):
         check(out, g["out"], 1e-3, "out vs golden")
 
 
+def test_scan_deterministic_outputs():
+    """The scan's non-atomic results -- out, out_z, the checkpoints x, du, ddelta, dz -- are bit-identical over 1,000
+    forward + backward repeats (what test_causal_conv1d_race_condition asks of the conv, asked of the scan); dA / dB /
+    dC / dD / ddelta_bias (fp32 atomics) agree to 1e-4 of their scale."""
+    import selective_scan_cuda
+    g = _rows_problem((2, 64, 2048, 1), torch.bfloat16, True, seed=17)
+    f = lambda k, dt=torch.bfloat16: G(g[k], dt)
+    u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
+                                        f("z"), f("delta_bias", torch.float32), f("g"))
+
+    def run():
+        out, x, oz = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True)
+        r = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, keep_fp32=True)
+        return [out, x, oz, r[0], r[1], r[7]], [r[2], r[3], r[4], r[5], r[6]]
+    det0, at0 = run()
+    for it in range(1000):
+        det, at = run()
+        for a, b_ in zip(det, det0):
+            assert torch.equal(a, b_), it
+        if it % 100 == 0:
+            for a, b_ in zip(at, at0):
+                assert (a - b_).abs().max() <= 1e-4 * b_.abs().max()
+
+
 def test_conv_deterministic_outputs():
-    """test_causal_conv1d_race_condition (test_causal_conv1d.py:117-173), shortened: out and dx are
-    bit-identical across repeats; dweight/dbias (fp32 atomics) agree to 1e-4 relative."""
+    """test_causal_conv1d_race_condition (test_causal_conv1d.py:117-173): out and dx are bit-identical across 1,000
+    repeats (the reference runs 10,000; same check, bounded run time); dweight/dbias (fp32 atomics) agree to 1e-4
+    relative."""
     from causal_conv1d import causal_conv1d_fn
     torch.manual_seed(0)
     x = torch.randn(2, 2048, 512 + 8, device=DEV, dtype=torch.bfloat16)[:, :, :512].transpose(1, 2).requires_grad_()
     w = torch.randn(512, 4, device=DEV, requires_grad=True)
     b = torch.randn(512, device=DEV, requires_grad=True)
     g = torch.randn(2, 512, 2048, device=DEV, dtype=torch.bfloat16)
-    outs = []
-    for _ in range(20):
+    first = None
+    for it in range(1000):
         for t in (x, w, b):
             t.grad = None
         out = causal_conv1d_fn(x, w, b, "silu")
         out.backward(g)
-        outs.append((out.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone()))
-    for o, dx, dw, db in outs[1:]:
-        assert torch.equal(o, outs[0][0]) and torch.equal(dx, outs[0][1])
-        assert (dw - outs[0][2]).abs().max() <= 1e-4 * outs[0][2].abs().max()
-        assert (db - outs[0][3]).abs().max() <= 1e-4 * outs[0][3].abs().max()
+        if first is None:
+            first = (out.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+            continue
+        assert torch.equal(out, first[0]) and torch.equal(x.grad, first[1]), it
+        if it % 100 == 0:
+            assert (w.grad - first[2]).abs().max() <= 1e-4 * first[2].abs().max()
+            assert (b.grad - first[3]).abs().max() <= 1e-4 * first[3].abs().max()
 
 
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16, torch.float32])
@@ -1151,11 +1194,11 @@ def test_norm_vs_oracle_and_golden(oracle, name):
     if got["pre"] is not None:
         check(got["pre"], g["pre"], tol * 2, "prenorm sum vs golden")
     check(got["dx"], ob["ds"].reshape(g["dx"].shape), tol * 2, "dx vs oracle")
-    check(got["dx"], g["dx"], tol * 4, "dx vs golden")
+    check(got["dx"], g["dx"], tol * FACTOR["grad"]["golden"], "dx vs golden")
     if got["dresidual"] is not None:
-        check(got["dresidual"], g["dresidual"], tol * 4, "dresidual vs golden")
+        check(got["dresidual"], g["dresidual"], tol * FACTOR["grad"]["golden"], "dresidual vs golden")
     check(got["dweight"], ob["dw"], tol * 5, "dweight vs oracle")
-    check(got["dweight"], g["dweight"], tol * 10, "dweight vs golden")
+    check(got["dweight"], g["dweight"], tol * FACTOR["batch_sum"]["golden"], "dweight vs golden")
     if got["dbias"] is not None:
         check(got["dbias"], ob["db"], tol * 5, "dbias vs oracle")
 
@@ -1229,6 +1272,28 @@ def test_state_update_vs_oracle_and_golden(oracle, name, itype):
     if itype == torch.float32:
         check(out, g["out"], 1e-4, "out vs golden")
         check(state, g["state_out"], 1e-5, "state vs golden")
+
+
+def test_state_update_keeps_dt_and_z_precision(oracle):
+    """bf16 x with fp32 dt / z (Mamba.step under bf16 activations keeps dt in fp32): dt and z are loaded in their own
+    dtypes (vms_hip.h dt_dtype / z_dtype), as the reference's kernel does -- the result matches the oracle fed the
+    unrounded dt at the fp32 bar for the state."""
+    from mamba_ssm.ops.triton.selective_state_update import selective_state_update
+    torch.manual_seed(3)
+    b, d, N = 2, 80, 16
+    x = torch.randn(b, d, device=DEV, dtype=torch.bfloat16)
+    dt = torch.rand(b, d, device=DEV) * 0.3 + 1e-3          # fp32: bf16 would lose 16 bits of it
+    z = torch.randn(b, d, device=DEV)
+    A = -torch.rand(d, N, device=DEV) - 0.5
+    Bm, Cm = torch.randn(b, N, device=DEV), torch.randn(b, N, device=DEV)
+    D, bias = torch.randn(d, device=DEV), torch.rand(d, device=DEV) * 0.1
+    state = torch.randn(b, d, N, device=DEV)
+    st0 = state.cpu().numpy()
+    out = selective_state_update(state, x, dt, A, Bm, Cm, D, z=z, dt_bias=bias, dt_softplus=True)
+    f = lambda a: a.detach().float().cpu().numpy()
+    o_out, o_st = oracle.state_update(st0, f(x), f(dt), f(A), f(Bm), f(Cm), f(D), f(z), f(bias), True, prec="f64")
+    check(state, o_st, 1e-5, "state (fp32 dt)")
+    check(out, o_out, 1e-2, "out (bf16)")
 
 
 def test_state_update_strided_and_low_precision_state(oracle):

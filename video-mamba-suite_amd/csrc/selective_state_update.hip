@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void state_update_kernel(const vms_state_updat
     const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);  // b * dim + d
     const bool ok = row < (int64_t)p.batch * p.dim;
     const int b = ok ? (int)(row / p.dim) : 0, d = ok ? (int)(row % p.dim) : 0;
-    float t = ld_any(p.dt, (int64_t)b * p.dt_batch_stride + (int64_t)d * p.dt_d_stride, p.x_dtype);
+    float t = ld_any(p.dt, (int64_t)b * p.dt_batch_stride + (int64_t)d * p.dt_d_stride, p.dt_dtype);
     if (p.dt_bias) t += ld_any(p.dt_bias, d, p.w_dtype);
     if (p.dt_softplus) t = softplusf_(t);
     const float xv = ld_any(p.x, (int64_t)b * p.x_batch_stride + (int64_t)d * p.x_d_stride, p.x_dtype);
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void state_update_kernel(const vms_state_updat
     acc += dpp_mov<0x128, 0xf>(0.f, acc);
     if (p.D) acc = fmaf(xv, ld_any(p.D, d, p.w_dtype), acc);
     if (p.z) {
-        const float zv = ld_any(p.z, (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride, p.x_dtype);
+        const float zv = ld_any(p.z, (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride, p.z_dtype);
         acc *= zv * sigmoidf_(zv);
     }
     if (ok && j == 0) st_any(p.out, (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride, p.x_dtype, acc);
@@ -66,7 +66,8 @@ extern "C" int vms_selective_state_update(const vms_state_update_params* pp, voi
     VMS_CHECK(pp != nullptr, "null params");
     const vms_state_update_params& p = *pp;
     auto dt_ok = [](int d) { return d == VMS_F32 || d == VMS_F16 || d == VMS_BF16; };
-    VMS_CHECK(dt_ok(p.state_dtype) && dt_ok(p.x_dtype) && dt_ok(p.bc_dtype) && dt_ok(p.w_dtype), "dtypes must be fp32/fp16/bf16");
+    VMS_CHECK(dt_ok(p.state_dtype) && dt_ok(p.x_dtype) && dt_ok(p.bc_dtype) && dt_ok(p.w_dtype) && dt_ok(p.dt_dtype) && (!p.z || dt_ok(p.z_dtype)),
+              "dtypes must be fp32/fp16/bf16");
     VMS_CHECK(p.batch > 0 && p.dim > 0 && p.dstate > 0, "empty problem");
     VMS_CHECK(p.state && p.x && p.dt && p.A && p.B && p.C && p.out, "state, x, dt, A, B, C, out are required");
     const int64_t rows = (int64_t)p.batch * p.dim;

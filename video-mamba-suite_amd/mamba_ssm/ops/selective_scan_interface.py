@@ -14,6 +14,8 @@ reference's recompute policy (checkpoint_lvl=1: conv output and delta are rebuil
 SSI:218-219, 238-241) and its layout contract (delta and the scan output are "d-slowest",
 dx/dz are written straight into the halves of one dxz buffer, SSI:244-248, 281-283).
 """
+import warnings
+
 import torch
 import torch.nn.functional as F
 
@@ -89,6 +91,13 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     last_state has shape (batch, dim, dstate). Note that the gradient of the last state is
     not considered in the backward pass.
     """
+    if A.is_complex():
+        # complex A (the reference's weight_t = complex<float> instantiations, selective_scan.cpp:282-287) has no HIP
+        # kernel here: no model of the suite uses it (SURVEY.md 8a a-excl).  The PyTorch statement of the op serves it,
+        # differentiable and on any device, with a warning; the raw extension (selective_scan_cuda.fwd) raises.
+        warnings.warn("selective_scan_fn: complex A runs on the pure-PyTorch selective_scan_ref path (no HIP kernel)",
+                      RuntimeWarning, stacklevel=2)
+        return selective_scan_ref(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
 
 

@@ -18,10 +18,7 @@ def selective_state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, 
     assert D is None or D.shape == (dim,)
     assert z is None or z.shape == x.shape
     assert dt_bias is None or dt_bias.shape == (dim,)
-    if dt.dtype != x.dtype:
-        dt = dt.to(x.dtype)
-    if z is not None and z.dtype != x.dtype:
-        z = z.to(x.dtype)
+    # dt and z keep their own dtypes (the reference's kernel loads every tensor in its dtype and widens to fp32)
     if C.dtype != B.dtype:
         C = C.to(B.dtype)
     wd = A.dtype

@@ -90,7 +90,8 @@ class NormBwdParams(ctypes.Structure):
 
 class StateUpdateParams(ctypes.Structure):
     _fields_ = (
-        [(n, _i32) for n in ("batch", "dim", "dstate", "state_dtype", "x_dtype", "bc_dtype", "w_dtype", "dt_softplus")]
+        [(n, _i32) for n in ("batch", "dim", "dstate", "state_dtype", "x_dtype", "bc_dtype", "w_dtype", "dt_softplus",
+                             "dt_dtype", "z_dtype")]
         + [(n, _vp) for n in ("state", "x", "dt", "A", "B", "C", "D", "z", "dt_bias", "out")]
         + [(n, _i64) for n in ("state_batch_stride", "state_d_stride", "state_n_stride", "x_batch_stride",
                                "x_d_stride", "dt_batch_stride", "dt_d_stride", "z_batch_stride", "z_d_stride",
@@ -470,6 +471,8 @@ def state_update(state, x, dt, A, B, C, D, z, dt_bias, out, dt_softplus):
     P = StateUpdateParams()
     P.batch, P.dim, P.dstate = state.shape
     P.state_dtype, P.x_dtype, P.bc_dtype, P.w_dtype = dtype_code(state), dtype_code(x), dtype_code(B), dtype_code(A)
+    P.dt_dtype = dtype_code(dt)
+    P.z_dtype = dtype_code(z) if z is not None else P.x_dtype
     P.dt_softplus = int(bool(dt_softplus))
     P.state, P.x, P.dt, P.A, P.B, P.C = _ptr(state), _ptr(x), _ptr(dt), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.dt_bias, P.out = _ptr(D), _ptr(z), _ptr(dt_bias), _ptr(out)
