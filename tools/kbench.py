@@ -7,9 +7,13 @@ import torch
 import selective_scan_cuda, causal_conv1d_cuda
 from bench import algorithmic_bytes
 
-def timeit(fn, n=10, warm=3):
-    for _ in range(warm): fn()
-    torch.cuda.synchronize()
+def timeit(fn, n=20, warm=3):
+    # clocks ramp over the first tens of milliseconds of load: run >= 60 ms before timing (a cold 13-launch sample reads 10-15 % slow)
+    t0 = time.time()
+    while True:
+        for _ in range(warm): fn()
+        torch.cuda.synchronize()
+        if time.time() - t0 > 0.06: break
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n): fn()

@@ -5,7 +5,7 @@ import collections
 import csv
 import sys
 
-KEYS = ("scan_fwd_pair_kernel", "scan_bwd_pair4_kernel", "scan_bwd_pair_kernel", "scan_fwd_lds_kernel", "conv_fwd_kernel", "conv_bwd_kernel")
+KEYS = ("scan_bwd_sp_kernel", "scan_fwd_pair_kernel", "scan_bwd_pair4_kernel", "scan_bwd_pair_kernel", "scan_fwd_lds_kernel", "conv_fwd_kernel", "conv_bwd_kernel")
 
 
 def main():
