@@ -576,8 +576,13 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 //     softplus derivative is rebuilt in the chunk epilogue as 1 - exp(-delta) instead of being carried, u is
 //     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
 //     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
+#ifndef VMS_BWD_SG
+#define VMS_BWD_SG 2
+#endif
 template <int W> struct B4 {
-    static constexpr int kPair = 2 * W * 4 * kWave;   // floats of one pair of states: [par][wave][4 lane + k]
+    // states between two workgroup barriers (= states per slab buffer): 2, or 4 for W = 8 in -DVMS_BWD_SG=4 builds
+    static constexpr int kSG = (W == 8 && VMS_BWD_SG == 4) ? 4 : 2;
+    static constexpr int kPair = kSG * W * 4 * kWave;   // floats of one group of states: [state][wave][4 lane + k]
     static constexpr int kRows = 4 * W;
     static constexpr int kPPT = 8 / W;                 // B / C pieces and slab outputs per thread (512 per chunk / pair)
     static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kBN * 4);
@@ -627,6 +632,12 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
 
     float dAacc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
+#ifdef VMS_BWD_PROF   // in-kernel phase timers (tools/prof_once.py): s_memtime around the phases of a state
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#define VMS_TICK2(i) do { unsigned long long tn_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); tacc[i] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define VMS_TICK2(i) do {} while (0)
+#endif
 
     // B / C staging of the NEXT chunk: piece (tensor, state, j) = 8 values of one state; a thread owns PPT pieces
     RawB<T, REV> stg[PPT];
@@ -785,14 +796,21 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
         stage_issue(c - 1);
 #define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
         auto do_state = [&](const int n, const int i4) __attribute__((always_inline)) {
-            const int par = i4 & 1, buf = (i4 >> 1) & 1;
+            constexpr int SG = B4<W>::kSG;
+            const int par = i4 & 1, buf = SG == 4 ? (n >> 2) & 1 : (i4 >> 1) & 1;
+            const int st = SG == 4 ? i4 : par;   // state inside its slab group
+            VMS_TICK2(0);   // since the previous tick: barrier exit / chunk prologue + epilogue
 #ifndef VMS_BWD_NO_ALTPRIO
             // waves w and w + 4 share a SIMD, and between equal priorities the older wave wins every issue slot: it would
             // reach each barrier first and wait while its partner runs alone at the single-wave issue rate.  Taking turns
             // (one state each) brings both to the barrier together.
             if (W == 8) {
+#if defined(VMS_BWD_PRIO_YOUNG)      // A/B: static priority for the second-dispatched half (waves 4-7)
+                if (i4 == 0 && n == 0) { if (quad >> 2) __builtin_amdgcn_s_setprio(VMS_BWD_PRIO_YOUNG); }
+#else
                 if ((par ^ (quad >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
+#endif
             }
 #endif
             // fp32 B / C of this state, shared by the workgroup's 32 rows
@@ -802,8 +820,11 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             // W = 4: all of its output of state `par`
             float rdv[4];
             {
+                // SG = 4: a thread owns the outputs of states rd_par0 and rd_par0 + 2 of the previous group; it reads
+                // waves 0-3 / 4-7 of the first during states 0 / 1 of this group, of the second during states 2 / 3
                 const lds_f32* src = rd_src + (buf ^ 1) * kB4Pair +
-                                     (W == 8 ? rd_par0 * (W * 4 * kWave) + par * 4 * (4 * kWave) : par * (W * 4 * kWave));
+                                     (SG == 4 ? (rd_par0 + 2 * (i4 >> 1)) * (W * 4 * kWave) + par * 4 * (4 * kWave)
+                                      : W == 8 ? rd_par0 * (W * 4 * kWave) + par * 4 * (4 * kWave) : par * (W * 4 * kWave));
 #pragma unroll
                 for (int w = 0; w < 4; ++w) rdv[w] = src[w * (4 * kWave)];
             }
@@ -854,7 +875,9 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             float ra = fast_exp2((sdl - dl_first) * An) * a_right;
             px = fmaf(pa, is_first ? hin : 0.f, px);
             rg = fmaf(ra, is_last ? gin : 0.f, rg);
+            VMS_TICK2(1);   // LDS reads, exps, aggregates
             row_scan_pair_b(pa, px, ra, rg);
+            VMS_TICK2(2);   // row scan
             const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);
             float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
 #endif
@@ -889,6 +912,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             }
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
+            VMS_TICK2(3);   // seeded chains, gradient core, dA
             // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
             asm volatile("s_nop 1\n\t"
                          "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
@@ -909,7 +933,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
                          "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
                          : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
             const f2 o0 = f2{t[0], t[1]} + f2{t[4], t[5]}, o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
-            slab4[(buf * kB4Pair + par * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
+            slab4[(buf * kB4Pair + st * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
                 __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
             {
                 const float tsum = (rdv[0] + rdv[1]) + (rdv[2] + rdv[3]);
@@ -918,19 +942,21 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
 #else
                 if (W == 8) {
                     racc = par == 0 ? tsum : racc + tsum;
-                    if (par == 1 && rd_okp) atomicAdd(rd_ptr + rd_par0 * rd_stride, racc);
+                    if (par == 1 && rd_okp) atomicAdd(rd_ptr + (rd_par0 + (SG == 4 ? 2 * (i4 >> 1) : 0)) * rd_stride, racc);
                 } else if (rd_okp) {
                     atomicAdd(rd_ptr + par * rd_stride, tsum);
                 }
 #endif
             }
-            if (par == 1) {
-                // the pair just written is summed during the next one
-                rd_ptr = rd_dst_c + (int64_t)(n - 1) * rd_stride;
+            VMS_TICK2(4);   // swaps, slab write, partial sums, atomic
+            if (st == SG - 1) {
+                // the group just written is summed during the next one
+                rd_ptr = rd_dst_c + (int64_t)(n - (SG - 1)) * rd_stride;
                 rd_okp = rd_lo < L;
 #ifndef VMS_ABL_NOBAR
                 lds_barrier_b();  // pair written by all waves; previous pair's buffer free again
 #endif
+                VMS_TICK2(5);   // barrier
             }
         };
 #pragma unroll 1
@@ -973,10 +999,11 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
         lds_barrier_b();
     }
 #undef VMS_OFF
-    if (rd_okp) {   // the last pair (buffer 1) is still in the slab
+    if (rd_okp) {   // the last group (buffer 1) is still in the slab
+        constexpr int SGt = B4<W>::kSG;
 #pragma unroll
-        for (int h = 0; h < PPT; ++h) {
-            const int par = W == 8 ? rd_par0 : h;
+        for (int h = 0; h < (SGt == 4 ? 2 : PPT); ++h) {
+            const int par = SGt == 4 ? rd_par0 + 2 * h : (W == 8 ? rd_par0 : h);
             const lds_f32* src = rd_src + kB4Pair + par * (W * 4 * kWave);
             float tsum = src[0];
 #pragma unroll
@@ -984,6 +1011,11 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             atomicAdd(rd_ptr + par * rd_stride, tsum);
         }
     }
+#ifdef VMS_BWD_PROF
+    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0)
+        printf("wg %d wave %d: lds+exp+aggr %llu  scan %llu  chains+core %llu  swaps+slab %llu  barrier %llu\n", (int)blockIdx.x, quad,
+               tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+#endif
     const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
     if (row_ok) {
         if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
@@ -1699,6 +1731,23 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     constexpr bool four = W4 != 0;
     constexpr int WK = four ? W4 : 4;
     const size_t smem4 = B4<WK>::kSmem;
+    if (four && smem4 > 64 * 1024) {   // 4-state slab groups: 88 KB
+        static PerDeviceOnce attr4_once;
+        const hipError_t arc4 = attr4_once.run([&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+#define VMS_A4(Z_, R_)                                                                                                   \
+            if (e == hipSuccess)                                                                                         \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_kernel<T, Z_, R_, WK>),             \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
+            VMS_A4(true, true); VMS_A4(true, false); VMS_A4(false, true); VMS_A4(false, false);
+#undef VMS_A4
+            return e;
+        });
+        if (arc4 != hipSuccess) {
+            set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", (int)smem4, hipGetErrorString(arc4));
+            return VMS_ERR_LAUNCH;
+        }
+    }
     const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
     // ... or, in -DVMS_BWD_GEN=3 builds, on the third (scan_bwd_sp_kernel: state pairs, 32 rows per workgroup)
     constexpr bool sp = VMS_BWD_GEN == 3;
