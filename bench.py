@@ -122,17 +122,18 @@ def _median_time(fn, reps=5, warm=1, budget_s=12.0):
     return statistics.median(ts), len(ts)
 
 
-def cpu_baseline_reference_path(reps=5, threads=None):
+def cpu_baseline_reference_path(reps=5, threads=None, shape=(2, 256, 128, 16), budget_s=8.0):
     """north_star / BASELINE.md section 3: the reference's pure-PyTorch CPU path -- selective_scan_ref
     (mamba/mamba_ssm/ops/selective_scan_interface.py:86-152) + causal_conv1d_ref
     (causal-conv1d/causal_conv1d/causal_conv1d_interface.py:49-65), as restated in this repo's mamba_ssm / causal_conv1d
-    packages and pinned to the reference by tests/golden -- on all host cores, at BASELINE configs[0]
-    (2, 256, 128, 16) fp32, input recipe of test_selective_scan.py:53-88; median of `reps` after one warm-up."""
+    packages and pinned to the reference by tests/golden -- on the host cores, fp32, input recipe of
+    test_selective_scan.py:53-88; median of `reps` after one warm-up.  shape = (B, L, D, N): BASELINE configs[0]
+    (2, 256, 128, 16) by default; the bench line's `value` uses a bounded sample of the headline rows instead."""
     from causal_conv1d.causal_conv1d_interface import causal_conv1d_ref
     from mamba_ssm.ops.selective_scan_interface import selective_scan_ref
     cores = usable_cores() if threads is None else threads
     torch.set_num_threads(cores)
-    b, l, d, n = 2, 256, 128, 16
+    b, l, d, n = shape
     g = torch.Generator().manual_seed(0)
     r = lambda *s: torch.randn(*s, generator=g)
     x0 = r(b, d, l).requires_grad_()
@@ -157,8 +158,8 @@ def cpu_baseline_reference_path(reps=5, threads=None):
         for t in leaves:
             t.grad = None
         fwd().backward(gout)
-    t_f, _ = _median_time(fwd_only, reps, budget_s=4.0)
-    t_fb, n_fb = _median_time(fwd_bwd, reps, budget_s=8.0)
+    t_f, _ = _median_time(fwd_only, reps, budget_s=budget_s / 2)
+    t_fb, n_fb = _median_time(fwd_bwd, reps, budget_s=budget_s)
     return {"fwd_ms": t_f * 1e3, "fwd_bwd_ms": t_fb * 1e3, "fwd_tokens_per_s": b * l / t_f,
             "fwd_bwd_tokens_per_s": b * l / t_fb, "shape": [b, l, d, n], "dtype": "f32", "reps": n_fb,
             "threads": cores}
@@ -202,23 +203,33 @@ def cpu_baseline_c_port(seconds_budget=25.0, min_reps=5):
             "shape": [sb, sl, d, n], "what": "oracle C port (f32, OpenMP): conv fwd + scan fwd + scan bwd + conv bwd"}
 
 
-def cpu_baseline():
-    """cpu_baseline object of the bench line.  value = the reference's CPU path (its pure-PyTorch selective_scan_ref +
-    causal_conv1d_ref, forward + backward of one scan direction at configs[0]) halved for the block's two directions;
-    the C port follows as `c_port`.  The projection GEMMs are in neither (the GPU number includes them)."""
+def cpu_baseline(threads_restore=None):
+    """cpu_baseline object of the bench line.  value = the reference's CPU path (pure-PyTorch selective_scan_ref +
+    causal_conv1d_ref, forward + backward of one scan direction) on a BOUNDED SAMPLE OF THE HEADLINE WORKLOAD -- one
+    sequence, the first 1024 of its 8192 tokens, all 1024 channels, d_state 16 (the recurrence is sequential in L, so
+    tokens/s does not depend on how many tokens are sampled) -- halved for the block's two directions.  The same path at
+    BASELINE configs[0] (2, 256, 128, 16) and the oracle's C port follow as labelled extras (`configs0_*`, `c_port`);
+    neither is meant to be divided into `value` of the bench line.  The projection GEMMs are in none of them."""
     port = cpu_baseline_c_port()            # first: libgomp reads OMP_NUM_THREADS when the library is loaded
-    ref = cpu_baseline_reference_path()     # all usable cores (BASELINE.md section 3)
+    hd = (1, 1024, D_MODEL * EXPAND, D_STATE)
+    head = cpu_baseline_reference_path(reps=3, shape=hd, budget_s=14.0)
+    head1 = cpu_baseline_reference_path(reps=3, threads=1, shape=hd, budget_s=14.0) if head["threads"] > 1 else head
+    best = max((head, head1), key=lambda r: r["fwd_bwd_tokens_per_s"])
+    ref = cpu_baseline_reference_path()     # configs[0], all usable cores (BASELINE.md section 3)
     ref1 = cpu_baseline_reference_path(threads=1) if ref["threads"] > 1 else ref
-    best = max((ref, ref1), key=lambda r: r["fwd_bwd_tokens_per_s"])   # a (2,256,128,16) problem rarely scales with threads
+    if threads_restore:
+        torch.set_num_threads(threads_restore)
     cores = best["threads"]
     return {
         "value": best["fwd_bwd_tokens_per_s"] / 2.0, "unit": "tokens/s", "cores": cores, "kind": "port",
         "cpu": cpu_model(), "host_cores_usable": usable_cores(), "host_cores_reported": os.cpu_count(),
         "sample": f"selective_scan_ref + causal_conv1d_ref (pure PyTorch, torch.set_num_threads({cores}), fp32) forward + "
-                  f"backward at BASELINE configs[0] (B,L,D,N)=(2,256,128,16): median of {best['reps']} = "
-                  f"{best['fwd_bwd_ms']:.1f} ms (forward only {best['fwd_ms']:.1f} ms); the better of {ref['threads']} "
+                  f"backward on a bounded sample of the headline workload: (B,L,D,N)=({hd[0]},{hd[1]},{hd[2]},{hd[3]}) = one "
+                  f"sequence's first {hd[1]} tokens at all {hd[2]} channels: median of {best['reps']} = "
+                  f"{best['fwd_bwd_ms']:.1f} ms (forward only {best['fwd_ms']:.1f} ms); the better of {head['threads']} "
                   "and 1 thread(s); one direction, halved for the block's two; projection GEMMs not included",
-        "reference_path_all_cores": ref, "reference_path_1_thread": ref1,
+        "headline_sample_all_cores": head, "headline_sample_1_thread": head1,
+        "configs0_reference_path_all_cores": ref, "configs0_reference_path_1_thread": ref1,
         "c_port": dict(port, tokens_per_s_block=port["tokens_per_s_one_direction"] / 2.0),
     }
 
