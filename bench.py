@@ -59,18 +59,38 @@ def profiled_traffic(kernel):
     return None, None
 
 
-def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, groups=1, w=D_CONV):
-    """SURVEY.md 8(d) / BASELINE.md section 2: algorithmic HBM bytes per launch of each kernel."""
+def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, groups=1, w=D_CONV, bwd_out_z=False):
+    """SURVEY.md 8(d) / BASELINE.md section 2: algorithmic HBM bytes per launch of each kernel.
+    bwd_out_z: the backward scan also rewrites the gated output (SURVEY's 9 B D L s: u, delta, dout, z, out read; du,
+    ddelta, dz, out_z written).  The blocks' fused nodes have no reader for it (no fused out_proj) and do not ask for
+    it since round 3 -- 8 B D L s; the roofline fraction is quoted on the bytes the launch really owes."""
     n_c = (seqlen + 2047) // 2048
     bdl = batch * dim * seqlen
     bc = 2 * batch * groups * n * seqlen
     x = batch * dim * n_c * 2 * n * 4
     return {
         "vms_selective_scan_fwd": 5 * bdl * s + bc * s + x + (dim * n + 2 * dim) * 4,
-        "vms_selective_scan_bwd": 9 * bdl * s + bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4,
+        "vms_selective_scan_bwd": (9 if bwd_out_z else 8) * bdl * s + bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4,
         "vms_causal_conv1d_fwd": 2 * bdl * s + dim * (w + 1) * 4,
         "vms_causal_conv1d_bwd": 3 * bdl * s + 2 * dim * (w + 1) * 4,
     }
+
+
+# The scans are bound by vector-ALU issue, not by HBM (DESIGN.md 4.0, profiles/r02_sq_scan_*.md).  Their VALU floor:
+# cycles one SIMD needs per 64 (element, state) pairs when every instruction issues at its standalone rate --
+# v_exp_f32 8.3 cycles (quarter rate), any other fp32 lane-operation 2.0 (packed or not: 32 lanes per clock) --
+#   forward : 1 exp + 5 lane-ops (delta*A, delta*u*B, local recurrence, seeded recurrence, y += C x)     = 18.3 cycles
+#   backward: 1.25 exp + 15 lane-ops (a, b, c, x re-scan + x chain, g chain, g*a*x, S1, S2, dA, dB, dC ..) = 40.4 cycles
+# on 1,024 SIMDs at the 2.4 GHz peak clock.  valu_frac = valu_floor_us / measured: the binding resource's own fraction.
+VALU_CYCLES_PER_64 = {"vms_selective_scan_fwd": 8.3 + 5 * 2.0, "vms_selective_scan_bwd": 1.25 * 8.3 + 15 * 2.0}
+N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
+
+
+def valu_floor_us(kernel, batch, dim, seqlen, n=D_STATE):
+    cyc = VALU_CYCLES_PER_64.get(kernel)
+    if cyc is None:
+        return None
+    return batch * dim * seqlen * n / 64.0 * cyc / N_SIMD / PEAK_CLOCK_HZ * 1e6
 
 
 def cpu_model():
@@ -105,6 +125,32 @@ def usable_cores():
         except (OSError, ValueError, IndexError):
             continue
     return max(1, n)
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """One process per GPU on ONE node: give each rank its own slice of the cores this job may use and size torch's
+    intra-op pool to it, so that N ranks do not each start a pool as wide as the machine (the GPU boxes report 256 cores,
+    a container may own 16: 8 ranks x 16 threads on 16 cores made the launch-bound configs host-bound).  Honours an
+    OMP_NUM_THREADS the launcher set.  Returns what it did (reported in the bench line)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = list(range(os.cpu_count() or 1))
+    usable = min(len(cores), usable_cores())
+    cores = cores[:usable] if usable < len(cores) else cores
+    per = max(1, len(cores) // max(1, local_world))
+    mine = cores[local_rank * per:(local_rank + 1) * per] if local_world > 1 and len(cores) >= local_world else cores
+    info = {"cores_visible": len(cores), "cores_this_rank": len(mine), "pinned": False}
+    if local_world > 1 and mine and os.environ.get("VMS_BENCH_NO_PIN") != "1":
+        try:
+            os.sched_setaffinity(0, mine)
+            info["pinned"] = True
+        except (AttributeError, OSError):
+            pass
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or max(1, min(len(mine), 8))
+    torch.set_num_threads(threads)
+    info["torch_threads"] = threads
+    return info
 
 
 def _median_time(fn, reps=5, warm=1, budget_s=12.0):
@@ -340,6 +386,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         else:
             dist.init_process_group(backend=backend)
     sync = torch.cuda.synchronize if on_gpu else (lambda: None)
+    host = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if on_gpu else None
 
     import vms_hip
 
@@ -371,7 +418,8 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         dist.barrier()
     sync()
     if on_gpu:
-        vms_hip.start_timing()   # two event records per C-ABI launch, on the launch stream, same fast call path
+        # two event records per C-ABI launch, on the launch stream, same fast call path; events pre-created here
+        vms_hip.start_timing(reserve=steps * 16 * WORKLOADS[config][5])
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -392,6 +440,8 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         ms_per_step = elapsed / steps * 1e3
         tokens = world * b * l * steps
         d_inner = d_model * WORKLOADS[config][4]
+        # the DBM block scans its two halves in separate launches of d_inner channels each; every other config's scans
+        # cover (b, d_inner, l) per launch
         ab = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l)
         kern = {}
         for name, ts in kernel_ms.items():
@@ -400,6 +450,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             if name in ab:
                 kern[name]["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
+            vf = valu_floor_us(name, b, d_inner, l)
+            if vf is not None:
+                kern[name]["valu_floor_us"] = vf
+                kern[name]["valu_frac"] = vf / (avg * 1e3)
         comm = {"backend": backend if distributed else None, "world_size": dist.get_world_size() if distributed else 1}
         if on_gpu:
             try:
@@ -407,7 +461,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             except Exception:  # noqa: BLE001
                 comm["rccl_version"] = None
         res = {
-            "metric": "Mamba-block fwd+bwd tokens/s at (B,L,D,d_state)=(8,8192,1024,16); % HBM roofline",
+            "metric": (f"Mamba-block fwd+bwd tokens/s at (B,L,D,d_state)=({b},{l},{d_model},{D_STATE}); % HBM roofline"
+                       if config != "stack" else
+                       f"{WORKLOADS[config][5]}-layer ViM stack fwd+bwd tokens/s at (B,L,D,d_state)=({b},{l},{d_model},{D_STATE}); % HBM roofline"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if autocast else "f32", "data": "synthetic",
@@ -417,13 +473,14 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                        "step": "fwd+bwd" + (" + DDP all-reduce" if distributed else ""),
                        "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
-                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")), "comm": comm},
+                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")), "comm": comm, "host": host},
             "kernels": kern,
         }
         if kern:
             dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
             traffic, src = profiled_traffic(dom) if config == "block" else (None, None)
-            res["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["algorithmic_GBs"],
+            res["roofline"] = {"kernel": dom, "bound": "hbm", "binding_resource": "valu" if "valu_frac" in kern[dom] else "hbm",
+                               "valu_frac": kern[dom].get("valu_frac"), "achieved": kern[dom]["algorithmic_GBs"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
                                "traffic_source": (f"{src}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel at this "
                                                   "size, committed profile (not measured in this run)") if src else None,
@@ -431,7 +488,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         if on_gpu and world == 1 and projections and config == "block":
             res["projections"] = projection_mfma(block, hidden)
         if world == 1 and cpu_base:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(threads_restore=host["torch_threads"] if host else None)
     return res
 
 

@@ -579,12 +579,16 @@ def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
     args = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32), f("z"),
             f("delta_bias", torch.float32), True)
     selective_scan_cuda.fwd(*args)
-    assert vms_hip.last_kernel() == "scan_fwd_pair+split"       # 64 rows: fewer waves than SIMDs -> ranges of chunks
+    assert vms_hip.last_kernel() == "scan_fwd_pair_lds+split"   # 64 rows: fewer waves than SIMDs -> ranges of chunks
     monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
     out, x, _ = selective_scan_cuda.fwd(*args)
-    assert vms_hip.last_kernel() == "scan_fwd_pair"
+    assert vms_hip.last_kernel() == "scan_fwd_pair_lds"         # the default kernel of whole-vector rows (B / C through LDS)
+    monkeypatch.setenv("VMS_BWD_SEGMENTS", "1")
     selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
-    assert vms_hip.last_kernel().startswith("scan_bwd_pair")
+    assert vms_hip.last_kernel() == "scan_bwd_pair4"            # ... and of the backward (4 rows per wave)
+    monkeypatch.delenv("VMS_BWD_SEGMENTS")
+    selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
+    assert vms_hip.last_kernel() == "scan_bwd_pair4+split"      # 2 workgroups for 256 CUs: the kernel's own choice is to split
     monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
     out, x, _ = selective_scan_cuda.fwd(*args)
     assert vms_hip.last_kernel() == "scan_fwd_generic"
@@ -596,6 +600,74 @@ def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
     B8 = torch.randn(1, 1, 8, 16384, device=DEV, dtype=torch.bfloat16)
     selective_scan_cuda.fwd(args[0], args[1], A8, B8, B8, None, None, None, True)
     assert vms_hip.last_kernel() == "scan_fwd_generic"
+
+
+@pytest.mark.parametrize("shape,fwd_name,bwd_name", [
+    ((8, 8192, 1024), "scan_fwd_pair_lds", "scan_bwd_pair4"),          # BASELINE configs[1] (bench.py default)
+    ((8, 3136, 768), "scan_fwd_pair_lds", "scan_bwd_pair4"),           # configs[2]
+    ((2, 2304, 512), "scan_fwd_pair_lds", "scan_bwd_pair4"),           # configs[3], one direction of the DBM block
+    ((8, 1569, 768), "scan_fwd_pair_ragged", "scan_bwd_pair_ragged"),  # 8 x 196 patches + class token
+    # 12 channels per group: a forward workgroup's 8 rows would straddle groups -> the per-wave B / C kernel; the
+    # backward's 32-row workgroups cannot share a group either -> generic
+    ((2, 2048, 24, 2), "scan_fwd_pair", "scan_bwd_generic"),
+    # 32 channels per group, not a multiple of 8 x ... : forward LDS kernel, paired backward
+    ((2, 2048, 64, 2), "scan_fwd_pair_lds", "scan_bwd_pair4"),
+])
+def test_kernel_choice_per_shape(shape, fwd_name, bwd_name):
+    """Which kernel a shape runs on is part of the contract the parity tests rely on: every BASELINE shape must land on
+    the tuned kernels, and a shape that falls off them must say so through vms_last_kernel()."""
+    import selective_scan_cuda
+    import vms_hip
+    b, L, d = shape[:3]
+    groups = shape[3] if len(shape) > 3 else 1
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    u = torch.randn(b, d, L, device=DEV, dtype=dt)
+    delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(dt)
+    A = -torch.rand(d, 16, device=DEV)
+    Bm = torch.randn(b, groups, 16, L, device=DEV, dtype=dt)
+    Cm = torch.randn(b, groups, 16, L, device=DEV, dtype=dt)
+    D = torch.randn(d, device=DEV)
+    z = torch.randn(b, d, L, device=DEV, dtype=dt)
+    bias = torch.rand(d, device=DEV)
+    out, x, _ = selective_scan_cuda.fwd(u, delta, A, Bm, Cm, D, z, bias, True)
+    assert vms_hip.last_kernel().split("+")[0] == fwd_name, vms_hip.last_kernel()
+    selective_scan_cuda.bwd(u, delta, A, Bm, Cm, D, z, bias, torch.randn_like(u), x, out, None, True, False)
+    assert vms_hip.last_kernel().split("+")[0] == bwd_name, vms_hip.last_kernel()
+    torch.cuda.synchronize()
+
+
+def test_tensors_beyond_31_bit_offsets_take_the_generic_kernels(oracle):
+    """The paired kernels address with 32-bit element offsets; a problem whose tensors span >= 2^31 elements must not
+    fail or wrap: it runs on the generic kernels (64-bit strides) and vms_last_kernel() says so.  Rows sampled against
+    the oracle (rows are independent given B, C).  8.6 GB of bf16 activations: fine on a 288 GB part."""
+    import selective_scan_cuda
+    import vms_hip
+    b, d, L, N = 1, 1024 + 32, 2 * 1024 * 1024, 16     # d * L = 2.2e9 elements per tensor
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    u = torch.empty(b, d, L, device=DEV, dtype=dt).normal_()
+    delta = torch.empty(b, d, L, device=DEV, dtype=dt).uniform_(0.0, 0.3)
+    A = -torch.rand(d, N, device=DEV) - 0.5
+    Bm = torch.randn(b, 1, N, L, device=DEV, dtype=dt)
+    Cm = torch.randn(b, 1, N, L, device=DEV, dtype=dt)
+    out, x = selective_scan_cuda.fwd(u, delta, A, Bm, Cm, None, None, None, False)
+    assert vms_hip.last_kernel() == "scan_fwd_generic", vms_hip.last_kernel()
+    torch.cuda.synchronize()
+    # the last rows sit beyond the 2^31-element mark: a wrapped offset would read / write another row
+    rows = [0, 1023, d - 1]
+    Lc = 4096      # the scan is causal: the first Lc outputs depend on the first Lc inputs only
+    f = lambda t: t.float().cpu().numpy()
+    ref = oracle.scan_fwd(f(u[:, rows, :Lc]), f(delta[:, rows, :Lc]), f(A[rows]), f(Bm[..., :Lc]), f(Cm[..., :Lc]),
+                          None, None, None, False, prec="f64")["out"]
+    got = f(out[:, rows, :Lc])
+    scale = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-2 * scale
+    # and the far end of the last row was written (not left to a wrapped store)
+    tail = out[0, d - 1, -4096:].float()
+    assert torch.isfinite(tail).all() and tail.abs().max() > 0
+    del out, x
+    torch.cuda.empty_cache()
 
 
 def test_c_abi_is_reentrant_across_threads_and_streams(oracle):
@@ -1060,34 +1132,41 @@ def test_block_L8192_fp32_vs_torch_reference():
         check(a, b_.cpu().numpy(), 1e-3 if k == "dh" else 5e-3, "grad " + k)
 
 
-def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
-    """configs[1] exactly as bench.py runs it: Mamba(1024, expand=1, "v2") at (8, 8192) under autocast(bf16), forward +
-    backward.  (a) the one-node reverse-kernel path == the reference's form (flipped copies through the causal ops,
-    conv_out / delta recomputed in backward: VMS_NO_REVERSE=1, VMS_CHECKPOINT_LVL=1); (b) the stages of the path, run
-    with the public ops on the block's own tensors, against the oracle on sampled rows: conv (both directions) and the
-    scan given (delta, B, C) (both directions); (c) the composition of those ops == the fused block output."""
+def _vim_full_size(oracle, monkeypatch, d_model, b, L, wrap_block=False, batches=None):
+    """A ViM ("v2") mixer at full size under autocast(bf16), forward + backward, checked three ways:
+    (a) the one-node reverse-kernel path == the reference's form (flipped copies through the causal ops, conv_out /
+    delta recomputed in backward: VMS_NO_REVERSE=1, VMS_CHECKPOINT_LVL=1); (b) the stages of the path, run with the
+    public ops on the block's own tensors, against the oracle on sampled rows: conv (both directions) and the scan given
+    (delta, B, C) (both directions); (c) the composition of those ops == the fused block output.
+    wrap_block: the mixer sits in a Block(Add -> RMSNorm -> mixer) with the fused add+norm kernel and an fp32 residual
+    stream, as the suite's backbones run it (configs[2])."""
+    from functools import partial
     import mamba_ssm.modules._core as core
-    from causal_conv1d import causal_conv1d_fn
-    from mamba_ssm.modules.mamba_simple import Mamba
-    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    from mamba_ssm.modules.mamba_simple import Block, Mamba
+    from mamba_ssm.ops.triton.layernorm import RMSNorm, rms_norm_fn
     import causal_conv1d_cuda
     import selective_scan_cuda
     torch.manual_seed(0)
-    m = Mamba(1024, expand=1, bimamba_type="v2").to(DEV)
+    if wrap_block:
+        top = Block(d_model, partial(Mamba, expand=1, bimamba_type="v2"), norm_cls=partial(RMSNorm, eps=1e-5),
+                    fused_add_norm=True, residual_in_fp32=True).to(DEV)
+        m = top.mixer
+    else:
+        top = m = Mamba(d_model, expand=1, bimamba_type="v2").to(DEV)
     with torch.no_grad():  # move A / D off their deterministic init
         for k, p in m.named_parameters():
             if k.endswith("_log"):
                 p.add_(0.3 * torch.randn_like(p))
             elif k in ("D", "D_b"):
                 p.add_(0.5 * torch.randn_like(p))
-    h = torch.randn(8, 8192, 1024, device=DEV, dtype=torch.bfloat16, requires_grad=True)
-    gout = torch.randn(8, 8192, 1024, device=DEV, dtype=torch.bfloat16)
-    params = list(m.parameters())
-    names = ["dh"] + [k for k, _ in m.named_parameters()]
+    h = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    gout = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16)
+    params = list(top.parameters())
+    names = ["dh"] + [k for k, _ in top.named_parameters()]
 
     def run():
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            y = m(h)
+            y = top(h)[0] if wrap_block else top(h)
         return y, torch.autograd.grad(y, [h] + params, gout)
     assert core._USE_REVERSE_KERNELS and core._CHECKPOINT_LVL == 0
     y1, g1 = run()
@@ -1101,10 +1180,15 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
 
     # (b) stage by stage against the oracle, on the tensors of this very block
     f = lambda t: t.detach().float().cpu().numpy()
-    rows = [0, 1, 511, 512, 1022, 1023]
-    d, R, N, L = m.d_inner, m.dt_rank, m.d_state, 8192
+    d, R, N = m.d_inner, m.dt_rank, m.d_state
+    rows = sorted({0, 1, d // 2 - 1, d // 2, d - 2, d - 1})
+    batches = batches if batches is not None else sorted({0, b - 1})
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        xz = m._in_projection(h)
+        hin = h
+        if wrap_block:
+            hin, _ = rms_norm_fn(h, top.norm.weight, top.norm.bias, residual=None, prenorm=True, residual_in_fp32=True,
+                                 eps=top.norm.eps)
+        xz = m._in_projection(hin)
         x, z = xz[:, :d], xz[:, d:]
         ys = []
         for sfx, rev in (("", False), ("_b", True)):
@@ -1112,7 +1196,7 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
             conv, xp, dtp = getattr(m, "conv1d" + sfx), getattr(m, "x_proj" + sfx), getattr(m, "dt_proj" + sfx)
             cw, cb = conv.weight.squeeze(1).float(), conv.bias.float()
             xc = causal_conv1d_cuda.causal_conv1d_fwd(x, cw, cb, True, rev)
-            for bi in (0, 7):
+            for bi in batches:
                 o = oracle.conv_fwd(fl(f(x[bi:bi + 1, rows])), f(cw[rows]), f(cb[rows]), True, prec="f64")
                 check(xc[bi:bi + 1, rows], fl(o), 1e-2, f"conv{sfx} rows batch {bi}")
             x_dbl = torch.nn.functional.linear(xc.transpose(1, 2), xp.weight.to(torch.bfloat16))     # (b, l, R + 2N)
@@ -1122,7 +1206,7 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
             A = -torch.exp(getattr(m, "A" + sfx + "_log").float())
             Dv, bias = getattr(m, "D" + sfx).float(), dtp.bias.float()
             out, _, out_z = selective_scan_cuda.fwd(xc, delta, A, Bm, Cm, Dv, z, bias, True, rev)
-            for bi in (0, 7):
+            for bi in batches:
                 sl = (slice(bi, bi + 1), rows)
                 o = oracle.scan_fwd(fl(f(xc[sl])), fl(f(delta[sl])), f(A[rows]), fl(f(Bm[bi:bi + 1])), fl(f(Cm[bi:bi + 1])),
                                     f(Dv[rows]), fl(f(z[sl])), f(bias[rows]), True, prec="f64")
@@ -1131,6 +1215,96 @@ def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
         yc = torch.nn.functional.linear((ys[0].float() + ys[1].float()).to(torch.bfloat16).transpose(1, 2),
                                         m.out_proj.weight.to(torch.bfloat16))
     check(y1, yc, 1e-2, "fused block vs composition of the checked stages")
+
+
+def test_block_full_size_bf16_bench_shape(oracle, monkeypatch):
+    """configs[1] exactly as bench.py runs it: Mamba(1024, expand=1, "v2") at (8, 8192) under autocast(bf16)."""
+    _vim_full_size(oracle, monkeypatch, 1024, 8, 8192)
+
+
+def test_block_full_size_configs2_block(oracle, monkeypatch):
+    """configs[2]: one Block(Add -> RMSNorm -> ViM 768) of the 12-layer stack at (8, 3136): fused add+norm kernel in
+    front, 192 backward-scan workgroups for 256 CUs."""
+    _vim_full_size(oracle, monkeypatch, 768, 8, 3136, wrap_block=True)
+
+
+def test_block_full_size_configs4_long_video(oracle, monkeypatch):
+    """configs[4]: the ViM block at (1, 65536, 768): both scans split into ranges of chunks INSIDE the block (24
+    workgroups otherwise), conv rows of 65,536 elements."""
+    import vms_hip
+    _vim_full_size(oracle, monkeypatch, 768, 1, 65536)
+    import selective_scan_cuda
+    # the forward scan of this shape really is the split one (the check above covered its values)
+    u = torch.randn(1, 768, 65536, device=DEV, dtype=torch.bfloat16)
+    dl = torch.rand(1, 768, 65536, device=DEV).to(torch.bfloat16)
+    Bm = torch.randn(1, 1, 16, 65536, device=DEV, dtype=torch.bfloat16)
+    selective_scan_cuda.fwd(u, dl, -torch.rand(768, 16, device=DEV), Bm, Bm, None, None, None, True)
+    assert vms_hip.last_kernel() == "scan_fwd_pair_lds+split"
+
+
+def test_block_full_size_configs3_dbm(oracle, monkeypatch):
+    """configs[3]: the DBM block (shared weights, second half of the channels scanned right-to-left, mamba_new.py:168-229)
+    at (2, 2304, 512) under autocast(bf16), forward + backward: (a) reverse-kernel path == the reference's form (the
+    flipped half stacked on the batch axis, recompute in backward); (b) conv + scan stages of both halves against the
+    oracle on sampled rows; (c) the composition of the checked stages == the block output."""
+    import mamba_ssm.modules._core as core
+    from mamba_ssm.modules.mamba_new import Mamba as DBM
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    torch.manual_seed(0)
+    d_model, b, L = 512, 2, 2304
+    m = DBM(d_model, expand=1).to(DEV)
+    with torch.no_grad():
+        m.A_log.add_(0.3 * torch.randn_like(m.A_log))
+        m.D.add_(0.5 * torch.randn_like(m.D))
+    h = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    gout = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16)
+    params = list(m.parameters())
+    names = ["dh"] + [k for k, _ in m.named_parameters()]
+
+    def run():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(h)
+        return y, torch.autograd.grad(y, [h] + params, gout)
+    y1, g1 = run()
+    monkeypatch.setattr(core, "_USE_REVERSE_KERNELS", False)
+    monkeypatch.setattr(core, "_CHECKPOINT_LVL", 1)
+    y2, g2 = run()
+    monkeypatch.undo()
+    check(y1, y2, 1e-2, "y: reverse kernels vs stacked flipped copies")
+    for k, a, b_ in zip(names, g1, g2):
+        check(a, b_, 1e-2 if k == "dh" else 2e-2, f"grad {k}: reverse kernels vs stacked flipped copies")
+
+    f = lambda t: t.detach().float().cpu().numpy()
+    d, R, N = m.d_inner, m.dt_rank, m.d_state
+    rows = sorted({0, 1, d // 2, d - 1})
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        xz4 = m._in_projection(h)                       # (b, 4 d, L): (x, z) forward half, (x, z) reversed half
+        cw, cb = m.conv1d.weight.squeeze(1).float(), m.conv1d.bias.float()
+        A = -torch.exp(m.A_log.float())
+        Dv, bias = m.D.float(), m.dt_proj.bias.float()
+        ys = []
+        for half, rev in ((0, False), (1, True)):
+            fl = (lambda a: np.ascontiguousarray(a[..., ::-1])) if rev else (lambda a: a)
+            xz = xz4[:, 2 * d * half:2 * d * (half + 1)]
+            x, z = xz[:, :d], xz[:, d:]
+            xc = causal_conv1d_cuda.causal_conv1d_fwd(x, cw, cb, True, rev)
+            for bi in range(b):
+                o = oracle.conv_fwd(fl(f(x[bi:bi + 1, rows])), f(cw[rows]), f(cb[rows]), True, prec="f64")
+                check(xc[bi:bi + 1, rows], fl(o), 1e-2, f"conv half {half} batch {bi}")
+            x_dbl = torch.nn.functional.linear(xc.transpose(1, 2), m.x_proj.weight.to(torch.bfloat16))
+            delta = torch.nn.functional.linear(x_dbl[..., :R], m.dt_proj.weight.to(torch.bfloat16)).transpose(1, 2).contiguous()
+            Bm = x_dbl[..., R:R + N].transpose(1, 2).contiguous()[:, None]
+            Cm = x_dbl[..., R + N:].transpose(1, 2).contiguous()[:, None]
+            out, _, out_z = selective_scan_cuda.fwd(xc, delta, A, Bm, Cm, Dv, z, bias, True, rev)
+            for bi in range(b):
+                sl = (slice(bi, bi + 1), rows)
+                o = oracle.scan_fwd(fl(f(xc[sl])), fl(f(delta[sl])), f(A[rows]), fl(f(Bm[bi:bi + 1])), fl(f(Cm[bi:bi + 1])),
+                                    f(Dv[rows]), fl(f(z[sl])), f(bias[rows]), True, prec="f64")
+                check(out_z[sl], fl(o["out_z"]), 1e-2, f"scan half {half} batch {bi}")
+            ys.append(out_z)
+        yc = torch.nn.functional.linear(torch.cat(ys, dim=1).transpose(1, 2), m.out_proj.weight.to(torch.bfloat16))
+    check(y1, yc, 1e-2, "DBM block vs composition of the checked stages")
 
 
 def test_block_bf16_autocast_runs_and_matches_fp32():

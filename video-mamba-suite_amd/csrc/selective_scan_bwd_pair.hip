@@ -54,16 +54,12 @@ struct RawB {
         for (int i = 0; i < kBK / EPV; ++i) v[i] = vp[i];
     }
     // the same for data this launch touches once (u, delta, dout, z, out): `nt` loads leave the L2 lines of the dB / dC
-    // atomics, which 32 workgroups per batch revisit, in place (VMS_BWD_NO_NT: plain loads, for A/B measurements)
+    // atomics, which 32 workgroups per batch revisit, in place
     __device__ __forceinline__ void load_stream(const T* __restrict__ base, uint32_t off, bool valid) {
         const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
 #pragma unroll
         for (int i = 0; i < kBK / EPV; ++i) {
-#ifdef VMS_BWD_NO_NT
-            v[i] = vp[i];
-#else
             v[i] = __builtin_nontemporal_load(&vp[i]);
-#endif
         }
     }
     // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad
@@ -112,11 +108,7 @@ __device__ __forceinline__ void store_stream_b(T* __restrict__ ptr, const float 
         V t;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[REV ? kBK - 1 - (v * EPV + e) : v * EPV + e]);
-#ifdef VMS_BWD_NO_NT
-        reinterpret_cast<V*>(ptr)[v] = t;
-#else
         __builtin_nontemporal_store(t, reinterpret_cast<V*>(ptr) + v);
-#endif
     }
 }
 
@@ -1025,486 +1017,9 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
 }
 
 
-// =====================================================================================================================
-// Third generation -- an experiment, NOT the default (build with -DVMS_BWD_GEN=3; profiles/r02_bwd_state_pairs.md):
-// correct (every parity case passes) but 1,372 us against the second generation's 949 us at (8, 8192, 1024, 16) bf16.
-#ifndef VMS_BWD_GEN
-#define VMS_BWD_GEN 2
-#endif
-#if VMS_BWD_GEN == 3
-// Third generation for whole-vector rows: STATE PAIRS in packed registers.
-//
-// What the counters of the second generation say (profiles/r02h_sq_scan.md, r02i_occupancy.txt): the kernel is bound by
-// the VALU pipe, not by latency -- forcing 4 waves per SIMD (two ranges of chunks) leaves the main kernel's time
-// unchanged, a second launch on a second stream does not overlap -- and every VALU instruction, packed or not, costs
-// about the same ~4.6 cycles of it.  Of the 153 VALU instructions per state, 40 are the four scalar recurrences along the
-// lane's 8 elements (forward aggregate, adjoint aggregate, seeded forward, seeded adjoint), which element pairing cannot
-// pack.  Here a lane works on the states (n, n+1) together: every quantity of the inner loop is a register pair
-// (state n, state n+1) of ONE element, so the recurrences are v_pk_fma_f32 chains too (20 per state instead of 40), the
-// per-element operands (delta, delta u, dy) stay element pairs and enter through op_sel broadcasts, B / C are staged in
-// LDS as [pair][position][2] so that one ds_read_b128 delivers two elements of both states, the du / ddelta sums are
-// kept as (even states, odd states) partials and added once per chunk, and dA accumulates in one register pair per
-// state pair over the whole row (the 8 pairs are unrolled), reduced across the row's 16 lanes once per kernel instead
-// of once per state.  The grid still gives 2 waves per SIMD, so the 60 extra VGPRs this costs are free.
-constexpr int kSpW = 8;                         // waves per workgroup (32 rows)
-constexpr int kSpSlab = kSpW * 4 * 2 * kWave;   // floats of one slab buffer: [wave][q2][lane] float4 (one state pair)
-constexpr size_t kSpSmem = sizeof(float) * (kBcFloats + 2 * kSpSlab + 4 * kSpW * kBN * 4);
-
-template <typename T, bool REV>
-struct Raw4 {   // 4 consecutive logical elements (8 bytes of bf16 / fp16, 16 of fp32)
-    vec_t<T, 4> v;
-    __device__ __forceinline__ void load(const T* __restrict__ base, uint32_t off, bool valid) {
-        v = *reinterpret_cast<const vec_t<T, 4>*>(base + (valid ? off : 0u));
-    }
-    __device__ __forceinline__ float at(int i) const { return static_cast<float>(v[REV ? 3 - i : i]); }
-};
-
-// D = S0 * S1 with one half of S0 (an element pair) on both result halves
-template <int H>
-__device__ __forceinline__ f2 pk_mul_bc(f2 e2, f2 s) {
-    f2 r;
-    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(r) : "v"(e2), "v"(s));
-    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(e2), "v"(s));
-    return r;
-}
-// D = S0 * S1 + S2 with one half of S0 on both result halves
-template <int H>
-__device__ __forceinline__ f2 pk_fma_bc(f2 e2, f2 s, f2 acc) {
-    f2 r;
-    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(e2), "v"(s), "v"(acc));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(e2), "v"(s), "v"(acc));
-    return r;
-}
-__device__ __forceinline__ f2 pk_mul_sp(f2 a, f2 b) {
-    f2 r;
-    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-// Forward inclusive scan of (pa, px) and suffix inclusive scan of (ra, rg) inside each 16-lane row for the two states
-// of a pair: 8 DPP-fused VOP2 per step; a result is read again 8 instructions later (>= the 2 wait states a DPP read
-// needs after a VALU write of its source).
-__device__ __forceinline__ void row_scan_sp(f2& pa, f2& px, f2& ra, f2& rg) {
-    float pax = pa.x, pay = pa.y, pxx = px.x, pxy = px.y, rax = ra.x, ray = ra.y, rgx = rg.x, rgy = rg.y;
-#define VMS_STEP(S)                                                                   \
-    "v_fmac_f32_dpp %0, %0, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_fmac_f32_dpp %2, %2, %3 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_fmac_f32_dpp %4, %4, %5 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_fmac_f32_dpp %6, %6, %7 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_mul_f32_dpp %1, %1, %1 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"           \
-    "v_mul_f32_dpp %3, %3, %3 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"           \
-    "v_mul_f32_dpp %5, %5, %5 row_shr:" #S " row_mask:0xf bank_mask:0xf\n\t"           \
-    "v_mul_f32_dpp %7, %7, %7 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"
-    asm volatile("s_nop 1\n\t" VMS_STEP(1) VMS_STEP(2) VMS_STEP(4) VMS_STEP(8) "s_nop 1"
-                 : "+v"(pxx), "+v"(pax), "+v"(rgx), "+v"(rax), "+v"(pxy), "+v"(pay), "+v"(rgy), "+v"(ray));
-#undef VMS_STEP
-    pa = f2{pax, pay}; px = f2{pxx, pxy}; ra = f2{rax, ray}; rg = f2{rgx, rgy};
-}
-
-template <typename T, bool HZ, bool REV>
-__global__ __launch_bounds__(kSpW* kWave) void scan_bwd_sp_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
-    const vms_scan_fwd_params& p = q.f;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = kBK, N = kBN, CH = kCH, W = kSpW, NP = kBN / 2;
-    lds_f4* const bc4 = (lds_f4*)smem;                       // fp32 B / C of the chunk: [tensor][pair][q][16] float4
-    lds_f4* const slab4 = (lds_f4*)(smem + kBcFloats);       // [buf][wave][q2][lane] float4
-    const lds_f32* const slab1 = (const lds_f32*)(smem + kBcFloats);
-    const int lane = threadIdx.x & 63;
-    const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 15, r = lane >> 4;
-    // per (row, pair): float4 {A_n, A_n+1, h_n, h_n+1} (h = state entering the chunk), float4 {a_n, a_n+1, g_n, g_n+1}
-    // (a of the first element to the right, adjoint from the right)
-    lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kSpSlab) + (quad * 4 + r) * (2 * NP);
-    __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
-    const int wg_per_seg = gridDim.x / n_seg;
-    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
-    const int b = wg % p.batch;
-    const int d0 = (wg / p.batch) * (4 * W);
-    const int d = d0 + quad * 4 + r;
-    const bool row_ok = d < p.dim;
-    const int dc = row_ok ? d : p.dim - 1;
-    const int g = d0 / (p.dim / p.n_groups);  // host guarantees one group per workgroup
-    const int L = p.seqlen;
-
-    const T* const u_b = static_cast<const T*>(p.u);
-    const T* const dt_b = static_cast<const T*>(p.delta);
-    const T* const dout_b = static_cast<const T*>(q.dout);
-    T* const du_b = static_cast<T*>(q.du);
-    T* const ddelta_b = static_cast<T*>(q.ddelta);
-    const T* const z_b = static_cast<const T*>(p.z);
-    const T* const outp_b = static_cast<const T*>(p.out);
-    T* const dz_b = static_cast<T*>(q.dz);
-    T* const out_z_b = static_cast<T*>(p.out_z);
-#define VMS_OFF(bs, ds) static_cast<uint32_t>((int64_t)b * (bs) + (int64_t)dc * (ds))
-    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
-    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
-    float* const dBg = q.dB + (int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride;
-    float* const dCg = q.dC + (int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride;
-    const float* const x_b = static_cast<const float*>(p.x);
-    const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
-    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
-    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
-
-    float dD_acc = 0.f, dbias_acc = 0.f;
-#ifdef VMS_SP_PROF
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
-#define VMS_TICK(i) do { unsigned long long tn_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); tacc[i] += tn_ - tprev; tprev = tn_; } while (0)
-#else
-#define VMS_TICK(i) do {} while (0)
-#endif
-#ifndef VMS_SP_UNROLL
-#define VMS_SP_UNROLL 2
-#endif
-    constexpr bool kFull = VMS_SP_UNROLL == 8;   // all 8 pairs unrolled: dA stays in one register pair per state pair
-    f2 dAacc[kFull ? NP : 1];
-    float dAlane = 0.f;                          // otherwise: reduced over the row after every pair, lane j keeps state j
-#pragma unroll
-    for (int pp = 0; pp < (kFull ? NP : 1); ++pp) dAacc[pp] = f2{0.f, 0.f};
-
-    // B / C staging of the NEXT chunk: thread = (tensor, pair, position group jj, half): 4 elements of both states
-    const int st_ten = (int)threadIdx.x >> 8, st_pp = ((int)threadIdx.x >> 5) & 7, st_jj = ((int)threadIdx.x >> 1) & 15,
-              st_h = (int)threadIdx.x & 1;
-    const T* const st_src0 = st_ten ? Cv + (int64_t)(2 * st_pp) * p.C_dstate_stride : Bv + (int64_t)(2 * st_pp) * p.B_dstate_stride;
-    const T* const st_src1 = st_src0 + (st_ten ? p.C_dstate_stride : p.B_dstate_stride);
-    lds_f4* const st_dst = bc4 + ((st_ten * NP + st_pp) * 4 + 2 * st_h) * 16 + st_jj;
-    Raw4<T, REV> stg0, stg1;
-    bool st_ok = false;
-    auto stage_issue = [&](int cc) __attribute__((always_inline)) {
-        const int ll = cc * CH + st_jj * K + 4 * st_h;
-        st_ok = cc >= 0 && ll < L;
-        const uint32_t po = REV ? L - ll - 4 : ll;
-        stg0.load(st_src0, po, st_ok);
-        stg1.load(st_src1, po, st_ok);
-    };
-    auto stage_commit = [&]() __attribute__((always_inline)) {
-        f32x4 lo, hi;
-        lo[0] = st_ok ? stg0.at(0) : 0.f; lo[1] = st_ok ? stg1.at(0) : 0.f;
-        lo[2] = st_ok ? stg0.at(1) : 0.f; lo[3] = st_ok ? stg1.at(1) : 0.f;
-        hi[0] = st_ok ? stg0.at(2) : 0.f; hi[1] = st_ok ? stg1.at(2) : 0.f;
-        hi[2] = st_ok ? stg0.at(3) : 0.f; hi[3] = st_ok ? stg1.at(3) : 0.f;
-        st_dst[0] = lo;
-        st_dst[16] = hi;
-    };
-    // slab reduction: thread t sums the W wave partials of float t of the pair's 512: q2 = t >> 8, lane' = (t >> 2) & 63,
-    // k = t & 3: DPP row rho = lane' >> 4 holds tensor rho >> 1, elements 4 (rho & 1) + e, e = 2 q2 + (k >> 1), state
-    // parity k & 1, position group lane' & 15 (see the swaps below)
-    const int rd_t = (int)threadIdx.x;
-    const int rd_rho = (rd_t >> 6) & 3, rd_ten = rd_rho >> 1, rd_s = rd_t & 1;
-    const int rd_pos = 8 * ((rd_t >> 2) & 15) + 4 * (rd_rho & 1) + 2 * (rd_t >> 8) + ((rd_t >> 1) & 1);
-    const lds_f32* const rd_src = slab1 + rd_t;
-    const int64_t rd_stride = rd_ten ? q.dC_dstate_stride : q.dB_dstate_stride;
-    float* const rd_dst = (rd_ten ? dCg : dBg) + rd_s * rd_stride;
-    float* rd_ptr = nullptr;
-    bool rd_okp = false;
-
-    RawB<T, REV> pu, pdt, pdo, pz, pout;   // row data of the NEXT chunk: requested while the current one computes
-    float hck_next = 0.f;
-    const int n_c = (L + CH - 1) / CH;
-    const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
-    auto request_row = [&](int cc) __attribute__((always_inline)) {
-        const int ll = cc * CH + j * K;
-        const bool v = cc >= 0 && ll < L && row_ok;
-        const uint32_t pl = REV ? L - ll - K : ll;
-        pu.load(u_b, VMS_OFF(p.u_batch_stride, p.u_d_stride) + pl, v);
-        pdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl, v);
-        pdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
-        if (HZ) {
-            pz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
-            pout.load(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
-        }
-        const int e128 = cc * (CH / 128) - 1;
-        const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
-        hck_next = x_b[xo];
-    };
-    const int cps = (n_c + n_seg - 1) / n_seg;
-    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
-    float g_in = 0.f, anx_in = 1.f;
-    if (seg < n_seg - 1) {
-        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_seg) * N + j;
-        for (int s2 = n_seg - 1; s2 > seg; --s2) {
-            const float2 pq = cp[(int64_t)s2 * N];
-            g_in = fmaf(pq.x, g_in, pq.y);
-        }
-        const int lr = c_hi * CH;
-        float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
-        if (p.delta_softplus) t = softplusf_(t);
-        anx_in = fast_exp2(t * A_mine * kLog2e);
-    }
-    request_row(c_hi - 1);
-    stage_issue(c_hi - 1);
-    stage_commit();
-    {   // lane j owns the record fields of state j
-        __attribute__((address_space(3))) float* rj = rec1 + (j >> 1) * 8 + (j & 1);
-        rj[0] = A_mine;
-        rj[2] = c_hi > 1 ? hck_next : 0.f;
-        rj[4] = anx_in;
-        rj[6] = g_in;
-    }
-    lds_barrier_b();
-    f32x4 rc0 = rec4[0], rc1 = rec4[1];
-    const f2 FL = f2{j == 0 ? 1.f : 0.f, j == 15 ? 1.f : 0.f};
-    const bool is_first = j == 0;
-    for (int c = c_hi - 1; c >= c_lo; --c) {
-        const int l0 = c * CH + j * K;
-        const bool ok = l0 < L && row_ok;
-        const uint32_t pl0 = REV ? L - l0 - K : l0;
-        const int rd_lo = c * CH + rd_pos;
-        float* const rd_dst_c = rd_dst + (REV ? L - 1 - rd_lo : rd_lo);
-        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2];
-        float sdl = 0.f, dl_first = 0.f;
-        {
-            float dy[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                dy[i] = ok ? pdo.at(i) : 0.f;   // past the end: c = 0, a = 1 (identity for the suffix scan)
-                float t = pdt.at(i) + bias;
-                if (p.delta_softplus) t = softplusf_(t);
-                t = ok ? t : 0.f;
-                dl2[i / 2][i % 2] = t;
-                sdl += t;
-                if (i == 0) dl_first = t;
-            }
-            if (HZ) {
-                float ov[K], dzv[K];
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    const float zv = pz.at(i);
-                    const float s = sigmoidf_(zv);
-                    const float silu = zv * s;
-                    ov[i] = pout.at(i);
-                    dzv[i] = dy[i] * ov[i] * s * (1.f + zv * (1.f - s));
-                    dy[i] *= silu;
-                    ov[i] *= silu;
-                }
-                if (ok) {
-                    if (q.dz_accumulate) {  // dz += (vms_hip.h)
-                        RawB<T, REV> od;
-                        od.load(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0, true);
-#pragma unroll
-                        for (int i = 0; i < K; ++i) dzv[i] += od.at(i);
-                    }
-                    store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
-                    if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const float uv = pu.at(i);
-                dy2[i / 2][i % 2] = dy[i];
-                dlu2[i / 2][i % 2] = dl2[i / 2][i % 2] * uv;
-                dD_acc = fmaf(dy[i], uv, dD_acc);
-            }
-        }
-        const float sdl_m = sdl - dl_first;
-        f2 S1[K], S2[K];  // per element, (even states, odd states): sum_n g B  /  sum_n A g a x_{i-1}
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-            S1[i] = f2{0.f, 0.f};
-            S2[i] = f2{0.f, 0.f};
-        }
-        RawB<T, REV> ukeep = pu;   // u of this chunk in its raw form, for the epilogue
-        request_row(c - 1);        // in flight during the 16 states of this chunk
-        stage_issue(c - 1);
-#define VMS_BC(FN, e2arr, i, ...) ((i) % 2 == 0 ? FN<0>(e2arr[(i) / 2], __VA_ARGS__) : FN<1>(e2arr[(i) / 2], __VA_ARGS__))
-#pragma unroll VMS_SP_UNROLL
-        for (int pp = 0; pp < NP; ++pp) {
-            const int buf = pp & 1;
-            VMS_TICK(0);   // since the last tick of the previous pair (barrier exit) or the chunk prologue
-#ifndef VMS_SP_NO_ALTPRIO
-            // waves w and w + 4 share a SIMD; taking turns at priority (one pair each) brings both to the barrier together
-            if ((pp ^ (quad >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-#endif
-            // fp32 B / C of the two states, shared by the workgroup's 32 rows
-            const lds_f4* bsrc = bc4 + pp * 64 + j;
-            const f32x4 bq0 = bsrc[0], bq1 = bsrc[16], bq2 = bsrc[32], bq3 = bsrc[48];
-            const lds_f4* csrc = bsrc + NP * 64;
-            const f32x4 cq0 = csrc[0], cq1 = csrc[16], cq2 = csrc[32], cq3 = csrc[48];
-            // the W wave partials of the PREVIOUS pair (other slab buffer)
-            float rdv[W];
-            {
-                const lds_f32* src = rd_src + (buf ^ 1) * kSpSlab;
-#pragma unroll
-                for (int w = 0; w < W; ++w) rdv[w] = src[w * (4 * 2 * kWave)];
-            }
-            const f2 Araw2 = f2{rc0.x, rc0.y}, hin2 = f2{rc0.z, rc0.w}, anx2 = f2{rc1.x, rc1.y}, gin2 = f2{rc1.z, rc1.w};
-            // before the fetch of pair 0's record for the next chunk, lane j stores the state entering it for state j
-            if (pp == NP - 1) rec1[(j >> 1) * 8 + 2 + (j & 1)] = c > 1 ? hck_next : 0.f;
-            rc0 = rec4[2 * ((pp + 1) & (NP - 1))];
-            rc1 = rec4[2 * ((pp + 1) & (NP - 1)) + 1];
-            const f2 An2 = Araw2 * f2{kLog2e, kLog2e};
-            f2 Bp[K], a2[K], xs2[K], c2[K], ax2[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const f32x4 bq = i < 2 ? bq0 : i < 4 ? bq1 : i < 6 ? bq2 : bq3;
-                const f32x4 cq = i < 2 ? cq0 : i < 4 ? cq1 : i < 6 ? cq2 : cq3;
-                Bp[i] = (i & 1) ? f2{bq.z, bq.w} : f2{bq.x, bq.y};
-                const f2 Cp = (i & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y};
-                const f2 t = VMS_BC(pk_mul_bc, dl2, i, An2);
-                a2[i] = f2{fast_exp2(t.x), fast_exp2(t.y)};
-                xs2[i] = VMS_BC(pk_mul_bc, dlu2, i, Bp[i]);   // b_i for now
-                c2[i] = VMS_BC(pk_mul_bc, dy2, i, Cp);
-            }
-            // lane aggregates: forward from 0, adjoint from 0 (a_{i+1} multiplies g_{i+1}; a_8 = a of the lane to the right)
-            const f2 pat = f2{sdl, sdl} * An2, rat = f2{sdl_m, sdl_m} * An2;
-            f2 pa = f2{fast_exp2(pat.x), fast_exp2(pat.y)};
-            const f2 a_right = f2{bdpp<DPP_ROW_SHL1>(anx2.x, a2[0].x), bdpp<DPP_ROW_SHL1>(anx2.y, a2[0].y)};
-            f2 ra = f2{fast_exp2(rat.x), fast_exp2(rat.y)} * a_right;
-            f2 px = xs2[0], rg = c2[K - 1];
-#pragma unroll
-            for (int i = 1; i < K; ++i) {
-                px = __builtin_elementwise_fma(a2[i], px, xs2[i]);
-                rg = __builtin_elementwise_fma(a2[K - i], rg, c2[K - 1 - i]);
-            }
-            px = __builtin_elementwise_fma(pa, pk_mul_bc<0>(FL, hin2), px);   // lane 0: the state entering the chunk
-            rg = __builtin_elementwise_fma(ra, pk_mul_bc<1>(FL, gin2), rg);   // lane 15: the adjoint from the right
-            VMS_TICK(1);   // LDS reads, exps, aggregates
-            row_scan_sp(pa, px, ra, rg);
-            VMS_TICK(2);   // row scan
-            f2 xrun = f2{bdpp<DPP_ROW_SHR1>(hin2.x, px.x), bdpp<DPP_ROW_SHR1>(hin2.y, px.y)};
-            f2 grun = f2{bdpp<DPP_ROW_SHL1>(gin2.x, rg.x), bdpp<DPP_ROW_SHL1>(gin2.y, rg.y)};
-            if (is_first) rec4[2 * pp + 1] = f32x4{a2[0].x, a2[0].y, rg.x, rg.y};
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                ax2[i] = a2[i] * xrun;                                   // a_i x_{i-1} (off the chain)
-                xrun = __builtin_elementwise_fma(a2[i], xrun, xs2[i]);
-                xs2[i] = xrun;                                           // x_i
-            }
-#pragma unroll
-            for (int i = K - 1; i >= 0; --i) {
-                grun = __builtin_elementwise_fma(i == K - 1 ? a_right : a2[i + 1], grun, c2[i]);
-                c2[i] = grun;                                            // g_i
-            }
-            f2 dA2 = kFull ? dAacc[kFull ? pp : 0] : f2{0.f, 0.f};
-            f2 vb[K], vc[K];   // this row's dB / dC products: (state n, state n+1) of the lane's 8 elements
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const f2 g2 = c2[i];
-                const f2 gax = g2 * ax2[i];  // g * a_i x_{i-1}
-                S1[i] = pk_fma_b(g2, Bp[i], S1[i]);
-                S2[i] = pk_fma_b(Araw2, gax, S2[i]);
-                dA2 = VMS_BC(pk_fma_bc, dl2, i, gax, dA2);
-                vb[i] = VMS_BC(pk_mul_bc, dlu2, i, g2);
-                vc[i] = VMS_BC(pk_mul_bc, dy2, i, xs2[i]);
-            }
-            if (kFull) {
-                dAacc[kFull ? pp : 0] = dA2;
-            } else {
-                const float s0 = row_allsum_b(dA2.x), s1 = row_allsum_b(dA2.y);
-                dAlane += j == 2 * pp ? s0 : (j == 2 * pp + 1 ? s1 : 0.f);
-            }
-            // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
-            float fb[2 * K], fc[2 * K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                fb[2 * i] = vb[i].x; fb[2 * i + 1] = vb[i].y;
-                fc[2 * i] = vc[i].x; fc[2 * i + 1] = vc[i].y;
-            }
-#define VMS_SW32(o)                                                                                                    \
-            asm volatile("s_nop 1\n\t"                                                                                  \
-                         "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"                              \
-                         "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"                            \
-                         "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"                            \
-                         "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"                                \
-                         : "+v"(fb[o + 0]), "+v"(fb[o + 1]), "+v"(fb[o + 2]), "+v"(fb[o + 3]), "+v"(fb[o + 4]),           \
-                           "+v"(fb[o + 5]), "+v"(fb[o + 6]), "+v"(fb[o + 7]), "+v"(fc[o + 0]), "+v"(fc[o + 1]),           \
-                           "+v"(fc[o + 2]), "+v"(fc[o + 3]), "+v"(fc[o + 4]), "+v"(fc[o + 5]), "+v"(fc[o + 6]), "+v"(fc[o + 7]))
-            VMS_TICK(3);   // seeded chains + gradient core
-            VMS_SW32(0);
-            VMS_SW32(8);
-#undef VMS_SW32
-            f2 t2[K];   // element i, both states; lanes 0-31: dB, lanes 32-63: dC, rows r and r + 2 summed
-#pragma unroll
-            for (int i = 0; i < K; ++i) t2[i] = f2{fb[2 * i], fb[2 * i + 1]} + f2{fc[2 * i], fc[2 * i + 1]};
-            // elements i and i + 4: DPP row rho then holds tensor rho >> 1, elements 4 (rho & 1) + e, all 4 rows summed
-            float tt[2 * K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) { tt[2 * i] = t2[i].x; tt[2 * i + 1] = t2[i].y; }
-            asm volatile("s_nop 1\n\t"
-                         "v_permlane16_swap_b32 %0, %8\n\tv_permlane16_swap_b32 %1, %9\n\t"
-                         "v_permlane16_swap_b32 %2, %10\n\tv_permlane16_swap_b32 %3, %11\n\t"
-                         "v_permlane16_swap_b32 %4, %12\n\tv_permlane16_swap_b32 %5, %13\n\t"
-                         "v_permlane16_swap_b32 %6, %14\n\tv_permlane16_swap_b32 %7, %15"
-                         : "+v"(tt[0]), "+v"(tt[1]), "+v"(tt[2]), "+v"(tt[3]), "+v"(tt[4]), "+v"(tt[5]), "+v"(tt[6]), "+v"(tt[7]),
-                           "+v"(tt[8]), "+v"(tt[9]), "+v"(tt[10]), "+v"(tt[11]), "+v"(tt[12]), "+v"(tt[13]), "+v"(tt[14]), "+v"(tt[15]));
-            const f2 o0 = f2{tt[0], tt[1]} + f2{tt[8], tt[9]}, o1 = f2{tt[2], tt[3]} + f2{tt[10], tt[11]};
-            const f2 o2 = f2{tt[4], tt[5]} + f2{tt[12], tt[13]}, o3 = f2{tt[6], tt[7]} + f2{tt[14], tt[15]};
-            lds_f4* sdst = slab4 + (buf * W + quad) * (2 * kWave) + lane;
-            sdst[0] = __builtin_shufflevector(o0, o1, 0, 1, 2, 3);      // elements e = 0, 1
-            sdst[kWave] = __builtin_shufflevector(o2, o3, 0, 1, 2, 3);  // elements e = 2, 3
-            {
-                const float tsum = ((rdv[0] + rdv[1]) + (rdv[2] + rdv[3])) + ((rdv[4] + rdv[5]) + (rdv[6] + rdv[7]));
-#ifdef VMS_SP_ABL_NOATOM
-                dD_acc += tsum;
-#else
-                if (rd_okp) atomicAdd(rd_ptr, tsum);
-#endif
-            }
-            // the pair just written is summed during the next one
-            rd_ptr = rd_dst_c + (int64_t)(2 * pp) * rd_stride;
-            rd_okp = rd_lo < L;
-            VMS_TICK(4);   // swaps, slab write, partial sums, atomic
-#ifndef VMS_SP_ABL_NOBAR
-            lds_barrier_b();  // pair written by all waves; previous pair's buffer free again
-#endif
-            VMS_TICK(5);   // barrier
-        }
-#undef VMS_BC
-        // u of this chunk before its registers are refilled; the next chunk's row data then travels during the
-        // epilogue, the staging commit and the barrier
-        asm volatile("" : "+v"(ukeep.v[0]));
-#pragma unroll
-        for (int k2 = 0; k2 < K / 2; ++k2) asm volatile("" : "+v"(dy2[k2]));
-        {
-            float duv[K], ddl[K];
-#pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const float dl = dl2[i / 2][i % 2];
-                const float s1 = S1[i].x + S1[i].y, s2 = S2[i].x + S2[i].y;
-                // d softplus / d(delta + bias) = sigmoid = 1 - exp(-softplus); 1 above the reference's threshold, where
-                // exp(-delta) < 2^-28 anyway (selective_scan_bwd_kernel.cuh:439-452)
-                const float sg = p.delta_softplus ? 1.f - fast_exp2(-kLog2e * dl) : 1.f;
-                duv[i] = fmaf(dl, s1, Dd * dy2[i / 2][i % 2]);
-                ddl[i] = fmaf(ukeep.at(i), s1, s2) * sg;
-                dbias_acc += ok ? ddl[i] : 0.f;
-            }
-            if (ok) {
-                store_b<T, REV>(du_b + (VMS_OFF(q.du_batch_stride, q.du_d_stride) + pl0), duv);
-                store_b<T, REV>(ddelta_b + (VMS_OFF(q.ddelta_batch_stride, q.ddelta_d_stride) + pl0), ddl);
-            }
-        }
-        stage_commit();   // every wave is past its last B / C read of this chunk (barrier of the last pair)
-        lds_barrier_b();
-    }
-#undef VMS_OFF
-    if (rd_okp) {   // the last pair (buffer 1) is still in the slab
-        const lds_f32* src = rd_src + kSpSlab;
-        float tsum = src[0];
-#pragma unroll
-        for (int w = 1; w < W; ++w) tsum += src[w * (4 * 2 * kWave)];
-        atomicAdd(rd_ptr, tsum);
-    }
-#ifdef VMS_SP_PROF
-    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0)
-        printf("wg %d wave %d: other %llu  lds+exp+aggr %llu  scan %llu  chains+core %llu  swaps+slab %llu  barrier %llu\n", (int)blockIdx.x, quad,
-               tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
-#endif
-    const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
-    float dA_mine = dAlane;
-    if (kFull) {
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-            const float s0 = row_allsum_b(dAacc[kFull ? pp : 0].x), s1 = row_allsum_b(dAacc[kFull ? pp : 0].y);
-            dA_mine = j == 2 * pp ? s0 : (j == 2 * pp + 1 ? s1 : dA_mine);
-        }
-    }
-    if (row_ok) {
-        if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
-        if (q.ddelta_bias && j == 0) atomicAdd(q.ddelta_bias + d, db_tot);
-        atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)j * q.dA_dstate_stride, dA_mine);
-    }
-}
-#endif  // VMS_BWD_GEN == 3
+// (A third generation -- state pairs in packed registers, 1,372 us against this kernel's 949 us -- was measured in round 2,
+// profiles/r02_bwd_state_pairs.md, and removed from the tree in round 3; its source is csrc/selective_scan_bwd_pair.hip
+// :1028-1507 of commit 64fcaa4.)
 
 // ---- adjoint carries of a segmented backward --------------------------------------------------------------------
 // With few rows and long sequences (batch 1, 768 channels, 65,536 tokens: 24 workgroups for 256 CUs) the grid
@@ -1749,18 +1264,9 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         }
     }
     const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
-    // ... or, in -DVMS_BWD_GEN=3 builds, on the third (scan_bwd_sp_kernel: state pairs, 32 rows per workgroup)
-    constexpr bool sp = VMS_BWD_GEN == 3;
-#if VMS_BWD_GEN == 3
-    const dim3 grid_sp(p.batch * ((p.dim + 4 * kSpW - 1) / (4 * kSpW)) * (grid.x / (p.batch * tiles))), block_sp(kSpW * kWave);
-#define VMS_LAUNCH_SP(Z_, R_) hipLaunchKernelGGL((scan_bwd_sp_kernel<T, Z_, R_>), grid_sp, block_sp, kSpSmem, stream, q, n_seg, carry)
-#else
-#define VMS_LAUNCH_SP(Z_, R_) (void)0
-#endif
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q, 1, carry); \
-        else if (sp) VMS_LAUNCH_SP(Z_, R_);                                                                        \
         else if (four) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK>), grid4, block4, smem4, stream, q, n_seg, carry); \
         else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q, n_seg, carry); \
     } while (0)
@@ -1768,7 +1274,9 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
-    set_last_kernel(n_seg > 1 ? "scan_bwd_pair+split" : (rag ? "scan_bwd_pair_ragged" : "scan_bwd_pair"));
+    set_last_kernel(rag ? "scan_bwd_pair_ragged"
+                        : four ? (n_seg > 1 ? "scan_bwd_pair4+split" : "scan_bwd_pair4")
+                               : (n_seg > 1 ? "scan_bwd_pair+split" : "scan_bwd_pair"));
     return VMS_OK;
 }
 

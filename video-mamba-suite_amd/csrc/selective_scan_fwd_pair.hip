@@ -670,8 +670,10 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
-    set_last_kernel(n_seg > 1 ? "scan_fwd_pair+split" : (rag ? "scan_fwd_pair_ragged" : "scan_fwd_pair"));
-    (void)lds_ok;
+    // distinct names per kernel: a shape that silently falls off the LDS kernel must be visible to callers and tests
+    set_last_kernel(rag ? "scan_fwd_pair_ragged"
+                        : lds_ok ? (n_seg > 1 ? "scan_fwd_pair_lds+split" : "scan_fwd_pair_lds")
+                                 : (n_seg > 1 ? "scan_fwd_pair+split" : "scan_fwd_pair"));
     return VMS_OK;
 }
 

@@ -14,8 +14,27 @@ HDR = os.path.join(os.path.dirname(PKG), "include", "vms_hip.h")
 LIB = os.path.join(PKG, "vms_hip", "libvms_hip.so")
 
 
+STAMP = OUT + ".stamp"
+
+
+def stamp():
+    """What a built binding depends on besides its sources: the torch build and the Python ABI it was compiled against
+    (a binding from another torch / interpreter fails to import and would silently leave every call on ctypes)."""
+    import torch
+    return f"torch {torch.__version__} | python {sysconfig.get_config_var('SOABI')} | hip {getattr(torch.version, 'hip', None)}"
+
+
+def up_to_date():
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
+        return False
+    if not all(os.path.getmtime(OUT) >= os.path.getmtime(f) for f in (SRC, HDR, __file__)):
+        return False
+    with open(STAMP) as f:
+        return f.read().strip() == stamp()
+
+
 def main(force=False):
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(f) for f in (SRC, HDR, __file__)):
+    if not force and up_to_date():
         return OUT
     import torch
     from torch.utils import cpp_extension as ce
@@ -29,6 +48,8 @@ def main(force=False):
            + ["-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python", "-lamdhip64", "-lvms_hip",
               "-Wl,-rpath,$ORIGIN/vms_hip"] + [f"-Wl,-rpath,{p}" for p in ce.library_paths() + [os.path.join(rocm, "lib")]])
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(stamp() + "\n")
     return OUT
 
 

@@ -13,6 +13,8 @@
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -40,9 +42,24 @@ const void* cptr(const OptT& t) { return t.has_value() ? t->data_ptr() : nullptr
 void* mptr(const OptT& t) { return t.has_value() ? t->data_ptr() : nullptr; }
 
 // ---- optional per-launch device timing (bench.py): two events per C-ABI call on the launch stream ---------------
-struct Timed { std::string name; hipEvent_t e0, e1; };
-bool g_timing = false;
+// Calls arrive from the Python thread AND from autograd's backward threads: the flag is atomic, the record list and the
+// pool of pre-created events are guarded by one mutex (held only around list / pool operations, never around a launch).
+struct Timed { const char* name; hipEvent_t e0, e1; };
+std::atomic<bool> g_timing{false};
+std::mutex g_timing_mu;
 std::vector<Timed> g_timed;
+std::vector<hipEvent_t> g_event_pool;
+
+hipEvent_t take_event_locked() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 
 template <typename P>
 void call(const char* name, int (*fn)(const P*, void*), const P& p, const Tensor& ref) {
@@ -50,13 +67,17 @@ void call(const char* name, int (*fn)(const P*, void*), const P& p, const Tensor
     c10::DeviceGuard guard(ref.device());
     hipStream_t s = c10::hip::getCurrentHIPStream(ref.device().index()).stream();
     int rc;
-    if (g_timing) {
+    if (g_timing.load(std::memory_order_acquire)) {
         Timed t{name, nullptr, nullptr};
-        (void)hipEventCreate(&t.e0);
-        (void)hipEventCreate(&t.e1);
+        {
+            std::lock_guard<std::mutex> lk(g_timing_mu);
+            t.e0 = take_event_locked();
+            t.e1 = take_event_locked();
+        }
         (void)hipEventRecord(t.e0, s);
         rc = fn(&p, s);
         (void)hipEventRecord(t.e1, s);
+        std::lock_guard<std::mutex> lk(g_timing_mu);
         g_timed.push_back(t);
     } else {
         rc = fn(&p, s);
@@ -154,6 +175,8 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
                              const OptT& z_, const OptT& delta_bias_, bool delta_softplus, bool reverse, const OptT& out_z_into,
                              int64_t bc_pad, int64_t impl, int64_t segments) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
+    // before the workspace query and the allocations: the split decision reads the CU count of the CURRENT device
+    c10::DeviceGuard guard(u.device());
     TORCH_CHECK(impl < VMS_IMPL_ROWS, "the row-major layout (VMS_SCAN_IMPL=rows) is served by the ctypes binding");
     Tensor out = at::empty_like(delta);   // inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
     OptT out_z;
@@ -192,6 +215,7 @@ std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A
                            bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
                            bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
+    c10::DeviceGuard guard(u.device());   // covers the workspace query (CU count of the tensors' device) and the allocations
     auto bdl = [&](const Tensor& t) { return t.dim() == 3 && t.size(0) == s.batch && t.size(1) == s.dim && t.size(2) == s.seqlen; };
     TORCH_CHECK(dout.scalar_type() == u.scalar_type(), "dout.scalar_type() == input_type");
     TORCH_CHECK(dout.is_cuda(), "dout.is_cuda()");
@@ -386,21 +410,31 @@ Tensor conv_update(const Tensor& x, const Tensor& conv_state, const Tensor& weig
     return out;
 }
 
-void timing_start() {
+// reserve: event pairs created now, outside the timed region (the pool grows on demand if a run needs more)
+void timing_start(int64_t reserve) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (auto& t : g_timed) { g_event_pool.push_back(t.e0); g_event_pool.push_back(t.e1); }
     g_timed.clear();
-    g_timing = true;
+    g_timed.reserve((size_t)reserve);
+    while ((int64_t)g_event_pool.size() < 2 * reserve) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        g_event_pool.push_back(e);
+    }
+    g_timing.store(true, std::memory_order_release);
 }
-// -> [(entry point, milliseconds)] in launch order; synchronises the device
+// -> [(entry point, milliseconds)] in launch order; synchronises the device.  The events go back to the pool.
 std::vector<std::tuple<std::string, double>> timing_stop() {
-    g_timing = false;
+    g_timing.store(false, std::memory_order_release);
     (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_timing_mu);
     std::vector<std::tuple<std::string, double>> out;
     for (auto& t : g_timed) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, t.e0, t.e1);
-        out.emplace_back(t.name, (double)ms);
-        (void)hipEventDestroy(t.e0);
-        (void)hipEventDestroy(t.e1);
+        out.emplace_back(std::string(t.name), (double)ms);
+        g_event_pool.push_back(t.e0);
+        g_event_pool.push_back(t.e1);
     }
     g_timed.clear();
     return out;
@@ -415,7 +449,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_fwd", &conv_fwd);
     m.def("conv_bwd", &conv_bwd);
     m.def("conv_update", &conv_update);
-    m.def("timing_start", &timing_start);
+    m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0);
     m.def("timing_stop", &timing_stop);
     m.def("abi_version", []() { return vms_abi_version(); });
     m.def("last_kernel", []() { return std::string(vms_last_kernel()); });

@@ -319,14 +319,18 @@ def _inner_backward(ctx, dout, dxz_into=None):
     n_scan = selective_scan_cuda.bwd_accumulator_elems(A, B, C, D, delta_bias)
     n_conv = conv_w.numel() + (conv_b.numel() if conv_b is not None else 0)
     zeros = torch.zeros(n_scan * (2 if ctx.bidirectional else 1) + n_conv, dtype=torch.float32, device=xz.device)
-    dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, out_z = selective_scan_cuda.bwd(
-        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, True, ctx.reverse,
+    # out_z is rebuilt only where something reads it: the fused out_proj's weight gradient.  (The reference asks for it
+    # in every node, SSI:247-251, and drops it in the ..NoOutProj ones: one full-tensor store per scan for nothing.)
+    want_out_z = ctx.has_out_proj
+    dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, *out_z = selective_scan_cuda.bwd(
+        conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, want_out_z, ctx.reverse,
         zeroed=zeros[:n_scan], keep_fp32=True, accumulate_dz=acc)
+    out_z = out_z[0] if out_z else None
     dA_b = None
     if ctx.bidirectional:
-        dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, out_z_b = selective_scan_cuda.bwd(
+        dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, *out_z_b = selective_scan_cuda.bwd(
             conv_out, delta, A_b, B, C, D, z, delta_bias, dy,
-            ckpt_b, out_b, dz, ctx.delta_softplus, True, not ctx.reverse,
+            ckpt_b, out_b, dz, ctx.delta_softplus, want_out_z, not ctx.reverse,
             zeroed=zeros[n_scan:2 * n_scan], keep_fp32=True, accumulate_dz=True)
         dconv_out = dconv_out + dconv_b
         ddelta = ddelta + ddelta_b
@@ -336,7 +340,8 @@ def _inner_backward(ctx, dout, dxz_into=None):
             dD = dD + dD_b
         if ddelta_bias is not None:
             ddelta_bias = ddelta_bias + ddelta_bias_b
-        out_z = out_z + out_z_b
+        if want_out_z:
+            out_z = out_z + out_z_b[0]
 
     dout_proj_weight = dout_proj_bias = None
     if ctx.has_out_proj:

@@ -159,8 +159,14 @@ def ext():
                 import _vms_torch
                 if _vms_torch.abi_version() == 4:
                     _ext = _vms_torch
-            except ImportError:
-                pass
+            except ImportError as e:
+                # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
+                # see csrc/torch_binding/build.py's stamp -- must not go unnoticed: every launch pays ~40 us more.
+                so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "_vms_torch.so")
+                if os.path.exists(so):
+                    import warnings
+                    warnings.warn(f"_vms_torch.so exists but does not import ({e}); rebuild it with "
+                                  "csrc/torch_binding/build.py --force.  Falling back to the ctypes binding.")
     return _ext
 
 
@@ -169,11 +175,13 @@ def ext():
 _timing = None
 
 
-def start_timing():
+def start_timing(reserve=0):
+    """reserve: launches expected until stop_timing() -- the compiled binding creates that many event pairs now, outside
+    the timed region (it grows the pool on demand if more arrive)."""
     global _timing
     _timing = []
     if ext() is not None:
-        ext().timing_start()
+        ext().timing_start(int(reserve))
 
 
 def stop_timing():
@@ -314,6 +322,15 @@ def is_rows_x(x, n_elems):
             and x.untyped_storage().nbytes() == (X_HEADER + n_elems) * 4)
 
 
+def _ws_bytes(fn_name, params, ref_tensor):
+    """Workspace query ON THE TENSORS' DEVICE: the split decision behind it reads the current device's CU count."""
+    fn = getattr(lib(), fn_name)
+    if not ref_tensor.is_cuda or ref_tensor.device.index == torch.cuda.current_device():
+        return fn(ctypes.byref(params))
+    with torch.cuda.device(ref_tensor.device):
+        return fn(ctypes.byref(params))
+
+
 def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False,
              out_z_accumulate=False, bc_pad=0):
     """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
@@ -330,7 +347,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
             ref = batch * dim * n_chunks * 2 * dstate
             x = torch.empty(X_HEADER + ne, device=u.device, dtype=torch.float32)[X_HEADER:X_HEADER + ref]
             x = x.view(batch, dim, n_chunks, 2 * dstate)
-            ws = torch.empty(lib().vms_scan_fwd_workspace_bytes(ctypes.byref(P)), device=u.device, dtype=torch.uint8)
+            ws = torch.empty(_ws_bytes("vms_scan_fwd_workspace_bytes", P, u), device=u.device, dtype=torch.uint8)
             P.x, P.x_chunk_stride, P.x_has_sub = _ptr(x), 2 * dstate, 2
             P.workspace, P.workspace_bytes = _ptr(ws), ws.numel()
         else:
@@ -340,7 +357,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
             P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
             P.x_has_sub = 1
     if not P.workspace:
-        nws = lib().vms_scan_fwd_workspace_bytes(ctypes.byref(P))   # state carries of a sequence-split forward
+        nws = _ws_bytes("vms_scan_fwd_workspace_bytes", P, u)   # state carries of a sequence-split forward
         if nws > 0:
             ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
             P.workspace, P.workspace_bytes = _ptr(ws), nws
@@ -373,7 +390,7 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
     Q.dz_accumulate = int(bool(dz_accumulate))
     Q.f.bc_pad = int(bc_pad)
     Q.f.segments = _segments_from_env("VMS_BWD_SEGMENTS")
-    nws = lib().vms_scan_bwd_workspace_bytes(ctypes.byref(Q))   # adjoint carries of a sequence-split backward
+    nws = _ws_bytes("vms_scan_bwd_workspace_bytes", Q, u)   # adjoint carries of a sequence-split backward
     if nws > 0:
         ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
         Q.f.workspace, Q.f.workspace_bytes = _ptr(ws), nws
