@@ -417,9 +417,13 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     if distributed:
         dist.barrier()
     sync()
-    if on_gpu:
-        # two event records per C-ABI launch, on the launch stream, same fast call path; events pre-created here
-        vms_hip.start_timing(reserve=steps * 16 * WORKLOADS[config][5])
+    # Per-kernel durations: two event records per C-ABI launch on the launch stream.  The headline block is GPU-bound, the
+    # records ride inside its timed region (as the contract asks).  The other configs are launch-bound on the host
+    # (configs[3]: ~50 launches in < 1 ms), where two extra records per launch would be measured as step time: their
+    # kernels are timed in `kt_steps` extra steps AFTER the timed region instead (reported as config.kernel_timing).
+    inline_timing = on_gpu and config == "block"
+    if inline_timing:
+        vms_hip.start_timing(reserve=steps * 16 * WORKLOADS[config][5])   # events pre-created here
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -428,7 +432,14 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = vms_hip.stop_timing() if on_gpu else {}
+    kernel_ms = vms_hip.stop_timing() if inline_timing else {}
+    kt_steps = steps
+    if on_gpu and not inline_timing:
+        kt_steps = min(steps, 10)
+        vms_hip.start_timing(reserve=kt_steps * 16 * WORKLOADS[config][5])
+        for _ in range(kt_steps):
+            step()
+        kernel_ms = vms_hip.stop_timing()
     if distributed:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -446,7 +457,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         kern = {}
         for name, ts in kernel_ms.items():
             avg = sum(ts) / len(ts)
-            kern[name] = {"calls_per_step": len(ts) / steps, "avg_ms": avg, "ms_per_step": sum(ts) / steps}
+            kern[name] = {"calls_per_step": len(ts) / kt_steps, "avg_ms": avg, "ms_per_step": sum(ts) / kt_steps}
             if name in ab:
                 kern[name]["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
@@ -473,6 +484,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                        "step": "fwd+bwd" + (" + DDP all-reduce" if distributed else ""),
                        "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
+                       "kernel_timing": "inside the timed region" if inline_timing else f"{kt_steps} extra steps after the timed region",
                        "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")), "comm": comm, "host": host},
             "kernels": kern,
         }

@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 4
+#define VMS_ABI_VERSION 5
 
 typedef enum {
     VMS_OK = 0,
@@ -134,6 +134,13 @@ typedef struct {
      * (from the device's CU count); n >= 1 forces n ranges (1 = never split) -- tests and profiling. */
     int32_t impl;
     int32_t segments;
+    /* ABI v5 (an extension): reverse_from > 0 makes the direction a property of the BATCH ENTRY -- entries
+     * [0, reverse_from) run left-to-right, entries [reverse_from, batch) right-to-left; `reverse` must then be 0.  One call
+     * serves both directions of a block whose directions share their weights (the DBM block, mamba_new.py:192-213, which
+     * stacks the flipped half on the batch axis: here the second half of the batch is simply scanned the other way, no
+     * copies).  Results per entry are exactly those of two calls on the two sub-batches.  0 = `reverse` decides. */
+    int32_t reverse_from;
+    int32_t reserved1;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).
@@ -192,6 +199,10 @@ typedef struct {
     /* update only */
     void *conv_state;
     int64_t conv_state_batch_stride, conv_state_c_stride, conv_state_l_stride;
+    /* ABI v5: as vms_scan_fwd_params.reverse_from -- batch entries >= reverse_from are filtered anti-causally
+     * (seqlen-contiguous layout only; `reverse` must be 0 when this is set) */
+    int32_t reverse_from;
+    int32_t reserved1;
 } vms_conv_fwd_params;
 
 typedef struct {

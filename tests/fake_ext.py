@@ -18,7 +18,26 @@ def make_fakes(oracle):
     def un(a, rev):
         return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
 
-    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None):
+    sl = lambda t, a, b: None if t is None else t[a:b]
+
+    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, reverse_from=0):
+        if reverse_from:   # by definition (vms_hip.h ABI v5): the two sub-batches, the second one right-to-left
+            k, n = reverse_from, u.shape[0]
+            lo = fwd(u[:k], delta[:k], A, sl(B, 0, k) if B.dim() >= 3 else B, sl(C, 0, k) if C.dim() >= 3 else C, D_, sl(z_, 0, k),
+                     delta_bias_, delta_softplus, False, sl(out_z_into, 0, k))
+            hi = fwd(u[k:], delta[k:], A, sl(B, k, n) if B.dim() >= 3 else B, sl(C, k, n) if C.dim() >= 3 else C, D_, sl(z_, k, n),
+                     delta_bias_, delta_softplus, True, sl(out_z_into, k, n))
+            out = torch.empty_like(delta)
+            out[:k], out[k:] = lo[0], hi[0]
+            res = [out, torch.cat([lo[1], hi[1]], dim=0)]
+            if z_ is not None:
+                if out_z_into is not None:
+                    res.append(out_z_into)
+                else:
+                    oz = torch.empty_like(z_)
+                    oz[:k], oz[k:] = lo[2], hi[2]
+                    res.append(oz)
+            return res
         rv = reverse
         r = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
                             np_(delta_bias_), delta_softplus, prec="f64")
@@ -30,7 +49,27 @@ def make_fakes(oracle):
         return res
 
     def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
-            reverse=False, zeroed=None, keep_fp32=False, accumulate_dz=False):  # the scratch is the real shim's business
+            reverse=False, zeroed=None, keep_fp32=False, accumulate_dz=False, reverse_from=0):  # the scratch is the real shim's business
+        if reverse_from:
+            k, n = reverse_from, u.shape[0]
+            vb, vc = B.dim() >= 3, C.dim() >= 3
+            dz = dz_ if (dz_ is not None or z_ is None) else torch.empty_like(z_)
+            parts = []
+            for a, b, rv2 in ((0, k, False), (k, n, True)):
+                parts.append(bwd(u[a:b], delta[a:b], A, B[a:b] if vb else B, C[a:b] if vc else C, D_, sl(z_, a, b), delta_bias_,
+                                 dout[a:b], sl(x_, a, b), sl(out_, a, b), sl(dz, a, b), delta_softplus, recompute_out_z, rv2,
+                                 None, keep_fp32, accumulate_dz))
+            lo, hi = parts
+            cat = lambda i: torch.cat([lo[i], hi[i]], dim=0)
+            add = lambda i: None if lo[i] is None else lo[i] + hi[i]
+            ddelta = torch.empty_like(delta)
+            ddelta[:k], ddelta[k:] = lo[1], hi[1]
+            res = [cat(0), ddelta, add(2), cat(3) if vb else add(3), cat(4) if vc else add(4), add(5), add(6)]
+            if z_ is not None:
+                res.append(dz)
+            if recompute_out_z:
+                res.append(cat(len(lo) - 1))
+            return res
         rv = reverse
         r = oracle.scan_bwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
                             np_(delta_bias_), np_(dout, rv), delta_softplus, prec="f64")
@@ -53,10 +92,19 @@ def make_fakes(oracle):
             res.append(torch.from_numpy(un(f["out_z"], rv)).to(u.dtype))
         return res
 
-    def cfwd(x, w, b, silu, reverse=False):
+    def cfwd(x, w, b, silu, reverse=False, reverse_from=0):
+        if reverse_from:
+            k = reverse_from
+            return torch.cat([cfwd(x[:k], w, b, silu, False), cfwd(x[k:], w, b, silu, True)], dim=0)
         return torch.from_numpy(un(oracle.conv_fwd(np_(x, reverse), np_(w), np_(b), silu, prec="f64"), reverse)).to(x.dtype)
 
-    def cbwd(x, w, b, dout, dx_, silu, reverse=False, zeroed=None, accumulate_dx=False):
+    def cbwd(x, w, b, dout, dx_, silu, reverse=False, zeroed=None, accumulate_dx=False, reverse_from=0):
+        if reverse_from:
+            k = reverse_from
+            dx = dx_ if dx_ is not None else torch.empty_like(x)
+            lo = cbwd(x[:k], w, b, dout[:k], dx[:k], silu, False, None, accumulate_dx)
+            hi = cbwd(x[k:], w, b, dout[k:], dx[k:], silu, True, None, accumulate_dx)
+            return [dx, lo[1] + hi[1], lo[2] + hi[2] if b is not None else None]
         r = oracle.conv_bwd(np_(x, reverse), np_(w), np_(b), np_(dout, reverse), silu, prec="f64")
         dx = dx_ if dx_ is not None else torch.empty_like(x)
         if accumulate_dx:

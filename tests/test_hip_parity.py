@@ -767,6 +767,114 @@ FULL_SIZES = {"cfg2_8x1024x8192": (8, 1024, 8192), "cfg3_8x768x3136": (8, 768, 3
               "cfg4_2x512x2304": (2, 512, 2304), "cfg5_1x768x65536": (1, 768, 65536)}
 
 
+@pytest.mark.parametrize("seqlen", [2304, 1569])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
+def test_reverse_from_equals_two_calls(seqlen, itype):
+    """vms_hip.h ABI v5 `reverse_from`: batch entries >= reverse_from run right-to-left.  Scan forward / backward and conv
+    forward / backward on a batch of 4 with reverse_from = 2 (and 1: uneven halves) equal the two calls on the two
+    sub-batches -- bit for bit where the kernels are deterministic (out, out_z, x, du, ddelta, dz, conv out / dx), to
+    atomics noise for the reduced gradients."""
+    import causal_conv1d_cuda
+    import selective_scan_cuda
+    b, d, N, L = 4, 64, 16, seqlen
+    torch.manual_seed(0)
+    xz = torch.randn(b, 2 * d, L, device=DEV, dtype=itype)
+    u, z = xz[:, :d], xz[:, d:]
+    delta = (0.5 * torch.rand(d, b, L, device=DEV)).to(itype).permute(1, 0, 2)
+    A = -torch.rand(d, N, device=DEV) - 0.2
+    Bm, Cm = torch.randn(b, 1, N, L, device=DEV, dtype=itype), torch.randn(b, 1, N, L, device=DEV, dtype=itype)
+    D, bias = torch.randn(d, device=DEV), torch.rand(d, device=DEV)
+    dout = torch.randn(b, d, L, device=DEV, dtype=itype)
+    w, cb = torch.randn(d, 4, device=DEV), torch.randn(d, device=DEV)
+    for k in (2, 1):
+        out, x, out_z = selective_scan_cuda.fwd(u, delta, A, Bm, Cm, D, z, bias, True, reverse_from=k)
+        parts = [selective_scan_cuda.fwd(u[a:e], delta[a:e], A, Bm[a:e], Cm[a:e], D, z[a:e], bias, True, rv)
+                 for a, e, rv in ((0, k, False), (k, b, True))]
+        for i, name in enumerate(("out", "x", "out_z")):
+            ref = torch.cat([parts[0][i], parts[1][i]], dim=0)
+            got = (out, x, out_z)[i]
+            assert torch.equal(got, ref), f"scan fwd {name} reverse_from={k}"
+        dz = torch.empty_like(xz)[:, d:]
+        g = selective_scan_cuda.bwd(u, delta, A, Bm, Cm, D, z, bias, dout, x, out, dz, True, False, reverse_from=k)
+        gp = []
+        for a, e, rv in ((0, k, False), (k, b, True)):
+            dzp = torch.empty_like(xz[a:e])[:, d:]
+            gp.append(selective_scan_cuda.bwd(u[a:e], delta[a:e], A, Bm[a:e], Cm[a:e], D, z[a:e], bias, dout[a:e], parts[0 if a == 0 else 1][1],
+                                              parts[0 if a == 0 else 1][0], dzp, True, False, rv))
+        for i, name in ((0, "du"), (1, "ddelta"), (7, "dz")):
+            assert torch.equal(g[i], torch.cat([gp[0][i], gp[1][i]], dim=0)), f"scan bwd {name} reverse_from={k}"
+        for i, name in ((3, "dB"), (4, "dC")):
+            check(g[i], torch.cat([gp[0][i], gp[1][i]], dim=0), 1e-2 if itype == torch.bfloat16 else 1e-4, f"scan bwd {name} reverse_from={k}")
+        for i, name in ((2, "dA"), (5, "dD"), (6, "ddelta_bias")):
+            check(g[i], gp[0][i] + gp[1][i], 1e-4, f"scan bwd {name} reverse_from={k}")
+        y = causal_conv1d_cuda.causal_conv1d_fwd(u, w, cb, True, reverse_from=k)
+        yp = torch.cat([causal_conv1d_cuda.causal_conv1d_fwd(u[:k], w, cb, True, False), causal_conv1d_cuda.causal_conv1d_fwd(u[k:], w, cb, True, True)])
+        assert torch.equal(y, yp), f"conv fwd reverse_from={k}"
+        dx, dw, db = causal_conv1d_cuda.causal_conv1d_bwd(u, w, cb, dout, None, True, reverse_from=k)
+        lo = causal_conv1d_cuda.causal_conv1d_bwd(u[:k], w, cb, dout[:k], None, True, False)
+        hi = causal_conv1d_cuda.causal_conv1d_bwd(u[k:], w, cb, dout[k:], None, True, True)
+        assert torch.equal(dx, torch.cat([lo[0], hi[0]])), f"conv bwd dx reverse_from={k}"
+        check(dw, lo[1] + hi[1], 1e-4, "conv dweight")
+        check(db, lo[2] + hi[2], 1e-4, "conv dbias")
+
+
+def test_dbm_stacked_node_equals_two_nodes(monkeypatch):
+    """The DBM block as one node on a batch of 2 B (reverse_from = B, stacking folded into the projections' weight layouts)
+    against one node per direction + torch.cat (VMS_DBM_TWO_NODES): same output, same gradients."""
+    import mamba_ssm.modules._core as core
+    from mamba_ssm.modules.mamba_new import Mamba as DBM
+    torch.manual_seed(0)
+    for (b, L, dm) in ((2, 2304, 512), (3, 777, 64)):
+        m = DBM(dm, expand=1, bias=(dm == 64)).to(DEV)
+        h = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+        gout = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16)
+        params = list(m.parameters())
+
+        def run():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(h)
+            return y, torch.autograd.grad(y, [h] + params, gout)
+        assert core._DBM_STACKED
+        y1, g1 = run()
+        monkeypatch.setattr(core, "_DBM_STACKED", False)
+        y2, g2 = run()
+        monkeypatch.undo()
+        check(y1, y2, 1e-2, "DBM y: stacked node vs two nodes")
+        for (k, _), a, c in zip([("dh", None)] + list(m.named_parameters()), g1, g2):
+            check(a, c, 2e-2, f"DBM grad {k}: stacked node vs two nodes")
+
+
+@pytest.mark.parametrize("variant", ["vim", "dbm"])
+@pytest.mark.parametrize("shape", [(2, 1569, 128), (2, 2048, 256)])
+def test_compiled_inner_node_equals_python_node(variant, shape, monkeypatch):
+    """csrc/torch_binding/vms_torch.cpp inner_fwd / inner_bwd (the fused node as ONE host call) against the Python statement
+    of the same node (VMS_NO_INNER_EXT=1): same ATen / C-ABI calls in the same order, so the outputs are identical and the
+    gradients agree to the run-to-run noise of the fp32 atomics (dA, dB, dC)."""
+    import vms_hip
+    if vms_hip.ext() is None or not hasattr(vms_hip.ext(), "inner_fwd"):
+        pytest.skip("compiled binding not built")
+    from mamba_ssm.modules.mamba_new import Mamba as DBM
+    from mamba_ssm.modules.mamba_simple import Mamba
+    b, L, dm = shape
+    torch.manual_seed(0)
+    m = (Mamba(dm, expand=1, bimamba_type="v2") if variant == "vim" else DBM(dm, expand=1)).to(DEV)
+    h = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    gout = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16)
+    params = list(m.parameters())
+
+    def run():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(h)
+        return y, torch.autograd.grad(y, [h] + params, gout)
+    y1, g1 = run()
+    monkeypatch.setenv("VMS_NO_INNER_EXT", "1")
+    y2, g2 = run()
+    monkeypatch.delenv("VMS_NO_INNER_EXT")
+    assert torch.equal(y1, y2)
+    for (k, _), a, c in zip([("dh", None)] + list(m.named_parameters()), g1, g2):
+        check(a, c, 1e-2, f"grad {k}: compiled node vs Python node")   # bf16: one ulp of the fp32-atomics noise
+
+
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("cfg", list(FULL_SIZES))
 def test_scan_full_size_rows_vs_oracle(oracle, itype, cfg):

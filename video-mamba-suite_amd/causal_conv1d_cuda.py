@@ -30,11 +30,12 @@ def _common(x, weight, bias_):
         _check(tuple(bias_.shape) == (x.shape[1],), "bias must have shape (dim,)")
 
 
-def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
-    """-> out   (causal_conv1d.cpp:130-189)"""
+def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False, reverse_from=0):
+    """-> out   (causal_conv1d.cpp:130-189)
+    reverse / reverse_from (extensions, vms_hip.h): anti-causal for every batch entry / for the entries >= reverse_from."""
     ext = _k.ext()
     if ext is not None:   # compiled binding: same checks / allocations / launch in C++
-        return ext.conv_fwd(x, weight, bias_, bool(silu_activation), bool(reverse))
+        return ext.conv_fwd(x, weight, bias_, bool(silu_activation), bool(reverse), int(reverse_from))
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
     _check(x.stride(2) == 1 or x.stride(1) == 1, "x.stride(2) == 1 || x.stride(1) == 1")
@@ -43,15 +44,17 @@ def causal_conv1d_fwd(x, weight, bias_, silu_activation, reverse=False):
     out = torch.empty_like(x)  # preserve_format keeps the unit-stride axis of x
     if (x.stride(1) == 1 and x.stride(2) > 1) and out.stride(1) != 1:
         out = torch.empty(x.shape[0], x.shape[2], x.shape[1], dtype=x.dtype, device=x.device).transpose(1, 2)
-    _k.conv_fwd(x, weight, bias_, out, silu_activation, reverse)
+    _k.conv_fwd(x, weight, bias_, out, silu_activation, reverse, reverse_from)
     return out
 
 
-def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False, zeroed=None, accumulate_dx=False):
+def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=False, zeroed=None, accumulate_dx=False,
+                      reverse_from=0):
     """-> [dx, dweight, dbias]   (causal_conv1d.cpp:191-268)"""
     ext = _k.ext()
     if ext is not None:
-        return ext.conv_bwd(x, weight, bias_, dout, dx_, bool(silu_activation), bool(reverse), zeroed, bool(accumulate_dx))
+        return ext.conv_bwd(x, weight, bias_, dout, dx_, bool(silu_activation), bool(reverse), zeroed, bool(accumulate_dx),
+                            int(reverse_from))
     _check(x.dim() == 3, "x must be (batch, dim, seqlen)")
     _common(x, weight, bias_)
     _check(dout.is_cuda, "dout.is_cuda()")
@@ -82,7 +85,7 @@ def causal_conv1d_bwd(x, weight, bias_, dout, dx_, silu_activation, reverse=Fals
         dweight = torch.zeros_like(weight, dtype=torch.float32)
         dbias = torch.zeros_like(bias_, dtype=torch.float32) if bias_ is not None else None
     _check(not accumulate_dx or dx_ is not None, "accumulate_dx needs the dx tensor to add to")
-    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation, reverse, bool(accumulate_dx))
+    _k.conv_bwd(x, weight, bias_, dout, dx, dweight, dbias, silu_activation, reverse, bool(accumulate_dx), reverse_from)
     return [dx, dweight.to(weight.dtype), dbias.to(bias_.dtype) if bias_ is not None else None]
 
 

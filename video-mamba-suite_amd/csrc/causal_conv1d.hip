@@ -480,6 +480,8 @@ static int validate_conv(const vms_conv_fwd_params& p) {
     VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
     VMS_CHECK(p.x && p.weight, "x and weight are required");
     VMS_CHECK(!p.reverse || (p.x_l_stride == 1 && !p.conv_state), "reverse (anti-causal) conv1d needs the seqlen-contiguous layout");
+    VMS_CHECK(p.reverse_from == 0 || (p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0 && p.x_l_stride == 1 && !p.conv_state),
+              "reverse_from must be in (0, batch] with reverse == 0, seqlen-contiguous layout");
     return VMS_OK;
 }
 
@@ -582,6 +584,16 @@ extern "C" int vms_causal_conv1d_fwd(const vms_conv_fwd_params* pp, void* stream
     VMS_CHECK(pp != nullptr, "null params");
     if (int rc = validate_conv(*pp)) return rc;
     VMS_CHECK(pp->out != nullptr, "out must be provided by the caller");
+    if (pp->reverse_from > 0 && pp->reverse_from < pp->batch) {   // ABI v5: the two sub-batches as two launches
+        const int rf = pp->reverse_from, es = pp->dtype == VMS_F32 ? 4 : 2;
+        vms_conv_fwd_params lo = *pp, hi = *pp;
+        lo.batch = rf; lo.reverse_from = 0;
+        hi.batch = pp->batch - rf; hi.reverse_from = 0; hi.reverse = 1;
+        hi.x = static_cast<const char*>(pp->x) + (int64_t)rf * pp->x_batch_stride * es;
+        hi.out = static_cast<char*>(pp->out) + (int64_t)rf * pp->out_batch_stride * es;
+        if (int rc = vms_causal_conv1d_fwd(&lo, stream)) return rc;
+        return vms_causal_conv1d_fwd(&hi, stream);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (pp->dtype) {
         case VMS_F32: return conv_fwd_dispatch<float>(*pp, s);
@@ -595,6 +607,17 @@ extern "C" int vms_causal_conv1d_bwd(const vms_conv_bwd_params* qq, void* stream
     if (int rc = validate_conv(qq->f)) return rc;
     VMS_CHECK(qq->dout && qq->dx && qq->dweight, "dout, dx and dweight are required");
     VMS_CHECK((qq->f.bias == nullptr) == (qq->dbias == nullptr), "dbias must be given iff bias is given");
+    if (qq->f.reverse_from > 0 && qq->f.reverse_from < qq->f.batch) {   // ABI v5: two launches, shared dweight / dbias accumulators
+        const int rf = qq->f.reverse_from, es = qq->f.dtype == VMS_F32 ? 4 : 2;
+        vms_conv_bwd_params lo = *qq, hi = *qq;
+        lo.f.batch = rf; lo.f.reverse_from = 0;
+        hi.f.batch = qq->f.batch - rf; hi.f.reverse_from = 0; hi.f.reverse = 1;
+        hi.f.x = static_cast<const char*>(qq->f.x) + (int64_t)rf * qq->f.x_batch_stride * es;
+        hi.dout = static_cast<const char*>(qq->dout) + (int64_t)rf * qq->dout_batch_stride * es;
+        hi.dx = static_cast<char*>(qq->dx) + (int64_t)rf * qq->dx_batch_stride * es;
+        if (int rc = vms_causal_conv1d_bwd(&lo, stream)) return rc;
+        return vms_causal_conv1d_bwd(&hi, stream);
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (qq->f.dtype) {
         case VMS_F32: return conv_bwd_dispatch<float>(*qq, s);

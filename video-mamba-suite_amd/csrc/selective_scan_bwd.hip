@@ -333,7 +333,30 @@ using namespace vms;
 
 // scratch the paired kernel wants when it splits the sequence into ranges (few rows, long sequences): the (P, q)
 // adjoint carries of selective_scan_bwd_pair.hip; 0 = no scratch needed for this problem
+static inline int64_t round256b(int64_t n) { return (n + 255) & ~(int64_t)255; }
+// reverse_from (ABI v5): the two sub-batches as two problems (dA, dD, ddelta_bias are shared accumulators)
+static void scan_bwd_sub_batches(const vms_scan_bwd_params& q, vms_scan_bwd_params& lo, vms_scan_bwd_params& hi) {
+    const vms_scan_fwd_params& p = q.f;
+    const int rf = p.reverse_from, es = p.dtype == VMS_F32 ? 4 : 2;
+    lo = q; hi = q;
+    scan_fwd_sub_batches(p, lo.f, hi.f);
+    auto offc = [](const void* ptr, int64_t bytes) -> const void* { return ptr ? static_cast<const char*>(ptr) + bytes : nullptr; };
+    auto offm = [](void* ptr, int64_t bytes) -> void* { return ptr ? static_cast<char*>(ptr) + bytes : nullptr; };
+    hi.dout = offc(q.dout, rf * q.dout_batch_stride * es);
+    hi.du = offm(q.du, rf * q.du_batch_stride * es);
+    hi.ddelta = offm(q.ddelta, rf * q.ddelta_batch_stride * es);
+    hi.dz = offm(q.dz, rf * q.dz_batch_stride * es);
+    if (p.is_variable_B) hi.dB = q.dB + rf * q.dB_batch_stride;
+    if (p.is_variable_C) hi.dC = q.dC + rf * q.dC_batch_stride;
+}
+
 extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
+    if (q != nullptr && q->f.reverse_from > 0 && q->f.reverse_from < q->f.batch) {
+        vms_scan_bwd_params lo, hi;
+        scan_bwd_sub_batches(*q, lo, hi);
+        const int64_t wl = vms_scan_bwd_workspace_bytes(&lo), wh = vms_scan_bwd_workspace_bytes(&hi);
+        return wl + wh > 0 ? round256b(wl) + wh : 0;
+    }
     if (q == nullptr || scan_impl_level(q->f) < VMS_IMPL_PAIR || !scan_bwd_pair_eligible(*q, true)) return 0;
     return scan_bwd_pair_segments(*q) > 1 ? scan_bwd_pair_ws_bytes(*q) : 0;
 }
@@ -344,6 +367,20 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     const vms_scan_fwd_params& p = q.f;
     if (int rc = validate_scan_common(p)) return rc;
     VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
+    if (p.reverse_from != 0) {
+        VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
+        if (p.reverse_from < p.batch) {
+            vms_scan_bwd_params lo, hi;
+            scan_bwd_sub_batches(q, lo, hi);
+            const int64_t wl = round256b(vms_scan_bwd_workspace_bytes(&lo)), wh = vms_scan_bwd_workspace_bytes(&hi);
+            if (p.workspace != nullptr && p.workspace_bytes >= wl + wh) {
+                if (wl > 0) { lo.f.workspace = p.workspace; lo.f.workspace_bytes = wl; }
+                if (wh > 0) { hi.f.workspace = static_cast<char*>(p.workspace) + wl; hi.f.workspace_bytes = wh; }
+            }
+            if (int rc = vms_selective_scan_bwd(&lo, stream)) return rc;
+            return vms_selective_scan_bwd(&hi, stream);
+        }
+    }
     VMS_CHECK(p.x != nullptr || p.seqlen <= 1024, "x (scan checkpoints) is required when seqlen > 1024");
     if (p.z) {
         VMS_CHECK(p.out != nullptr, "out is required when z is given");

@@ -210,10 +210,51 @@ bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
 
 using namespace vms;
 
+extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p);
+// reverse_from (ABI v5): the two sub-batches as two problems.  Every kernel generation serves it this way; the results are
+// by construction those of two calls.  The workspace is split in the same proportion vms_scan_fwd_workspace_bytes reports.
+static inline const void* off_c(const void* ptr, int64_t elems, int es) { return ptr ? static_cast<const char*>(ptr) + elems * es : nullptr; }
+static inline void* off_m(void* ptr, int64_t elems, int es) { return ptr ? static_cast<char*>(ptr) + elems * es : nullptr; }
+static inline int64_t round256(int64_t n) { return (n + 255) & ~(int64_t)255; }
+
+void vms::scan_fwd_sub_batches(const vms_scan_fwd_params& p, vms_scan_fwd_params& lo, vms_scan_fwd_params& hi) {
+    const int rf = p.reverse_from, es = p.dtype == VMS_F32 ? 4 : 2;
+    lo = p; lo.batch = rf; lo.reverse_from = 0; lo.reverse = 0;
+    hi = p; hi.batch = p.batch - rf; hi.reverse_from = 0; hi.reverse = 1;
+    hi.u = off_c(p.u, rf * p.u_batch_stride, es);
+    hi.delta = off_c(p.delta, rf * p.delta_batch_stride, es);
+    hi.z = off_c(p.z, rf * p.z_batch_stride, es);
+    hi.out = off_m(p.out, rf * p.out_batch_stride, es);
+    hi.out_z = off_m(p.out_z, rf * p.out_z_batch_stride, es);
+    if (p.is_variable_B) hi.B = off_c(p.B, rf * p.B_batch_stride, es);
+    if (p.is_variable_C) hi.C = off_c(p.C, rf * p.C_batch_stride, es);
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * p.dstate;
+    hi.x = off_m(p.x, (int64_t)rf * p.dim * p.n_chunks * xpitch, 4);
+    lo.workspace = hi.workspace = nullptr;
+    lo.workspace_bytes = hi.workspace_bytes = 0;
+}
+
+static int scan_fwd_mixed(const vms_scan_fwd_params& p, void* stream) {
+    vms_scan_fwd_params lo, hi;
+    scan_fwd_sub_batches(p, lo, hi);
+    const int64_t wl = round256(vms_scan_fwd_workspace_bytes(&lo)), wh = vms_scan_fwd_workspace_bytes(&hi);
+    if (p.workspace != nullptr && p.workspace_bytes >= wl + wh) {
+        if (wl > 0) { lo.workspace = p.workspace; lo.workspace_bytes = wl; }
+        if (wh > 0) { hi.workspace = static_cast<char*>(p.workspace) + wl; hi.workspace_bytes = wh; }
+    }
+    if (int rc = vms_selective_scan_fwd(&lo, stream)) return rc;
+    return vms_selective_scan_fwd(&hi, stream);
+}
+
 extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* stream) {
     VMS_CHECK(pp != nullptr, "null params");
     const vms_scan_fwd_params& p = *pp;
     if (int rc = validate_scan_common(p)) return rc;
+    if (p.reverse_from != 0) {
+        VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
+        VMS_CHECK(p.x_has_sub != 2, "reverse_from is not available with the rows layout");
+        if (p.reverse_from < p.batch) return scan_fwd_mixed(p, stream);
+    }
     VMS_CHECK(p.out && p.x, "out and x must be provided by the caller");
     VMS_CHECK((p.z == nullptr) == (p.out_z == nullptr), "out_z must be given iff z is given");
     VMS_CHECK(!p.out_z_accumulate || p.z != nullptr, "out_z_accumulate needs z / out_z");
@@ -251,6 +292,12 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
+    if (p->reverse_from > 0 && p->reverse_from < p->batch) {
+        vms_scan_fwd_params lo, hi;
+        scan_fwd_sub_batches(*p, lo, hi);
+        const int64_t wl = vms_scan_fwd_workspace_bytes(&lo), wh = vms_scan_fwd_workspace_bytes(&hi);
+        return wl + wh > 0 ? round256(wl) + wh : 0;
+    }
     const int level = scan_impl_level(*p);
 #ifdef VMS_EXPERIMENTAL
     if (level >= VMS_IMPL_ROWS && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return scan_rows_fwd_ws_bytes(*p);

@@ -143,8 +143,10 @@ ScanDims scan_checks(const Tensor& u, const Tensor& delta, const Tensor& A, cons
 
 void fill_scan(vms_scan_fwd_params& P, const ScanDims& s, const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B,
                const Tensor& C, const OptT& D_, const OptT& z_, const OptT& delta_bias_, const OptT& out, const OptT& out_z,
-               const OptT& x, bool delta_softplus, bool reverse, int64_t impl, int64_t segments, int64_t bc_pad) {
+               const OptT& x, bool delta_softplus, bool reverse, int64_t impl, int64_t segments, int64_t bc_pad, int64_t reverse_from = 0) {
     P = vms_scan_fwd_params{};
+    TORCH_CHECK(reverse_from >= 0 && reverse_from <= s.batch && (reverse_from == 0 || !reverse), "reverse_from must be in [0, batch] with reverse = False");
+    P.reverse_from = (int)reverse_from;
     P.batch = (int)s.batch; P.dim = (int)s.dim; P.seqlen = (int)s.seqlen; P.dstate = (int)s.dstate;
     P.n_groups = s.var_B ? (int)B.size(1) : (s.var_C ? (int)C.size(1) : 1);
     P.n_chunks = (int)((s.seqlen + 2047) / 2048);
@@ -173,7 +175,7 @@ void fill_scan(vms_scan_fwd_params& P, const ScanDims& s, const Tensor& u, const
 // -> [out, x, (out_z)]   (selective_scan.cpp:226-336).  B / C must already carry the padding bc_pad promises.
 std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
                              const OptT& z_, const OptT& delta_bias_, bool delta_softplus, bool reverse, const OptT& out_z_into,
-                             int64_t bc_pad, int64_t impl, int64_t segments) {
+                             int64_t bc_pad, int64_t impl, int64_t segments, int64_t reverse_from = 0) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
     // before the workspace query and the allocations: the split decision reads the CU count of the CURRENT device
     c10::DeviceGuard guard(u.device());
@@ -193,7 +195,7 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
     // backward kernel (include/vms_hip.h)
     Tensor x = at::empty({s.batch, s.dim, n_chunks, s.dstate * 18}, u.options().dtype(at::kFloat)).narrow(3, 0, s.dstate * 2);
     vms_scan_fwd_params P;
-    fill_scan(P, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, impl, segments, bc_pad);
+    fill_scan(P, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
     P.x_has_sub = 1;
     P.out_z_accumulate = out_z_into.has_value();
     Tensor ws;
@@ -213,7 +215,8 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
 std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
                            const OptT& z_, const OptT& delta_bias_, const Tensor& dout, const OptT& x_, const OptT& out_, const OptT& dz_,
                            bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
-                           bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape) {
+                           bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape,
+                           int64_t reverse_from = 0) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
     c10::DeviceGuard guard(u.device());   // covers the workspace query (CU count of the tensors' device) and the allocations
     auto bdl = [&](const Tensor& t) { return t.dim() == 3 && t.size(0) == s.batch && t.size(1) == s.dim && t.size(2) == s.seqlen; };
@@ -268,7 +271,7 @@ std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A
         if (delta_bias_.has_value()) dbias = at::zeros_like(*delta_bias_);
     }
     vms_scan_bwd_params Q{};
-    fill_scan(Q.f, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x_, delta_softplus, reverse, impl, segments, bc_pad);
+    fill_scan(Q.f, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x_, delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
     Q.dout = dout.data_ptr(); Q.du = du.data_ptr(); Q.ddelta = ddelta.data_ptr(); Q.dz = mptr(dz);
     Q.dA = dA.data_ptr<float>(); Q.dB = dB.data_ptr<float>(); Q.dC = dC.data_ptr<float>();
     Q.dD = dD.has_value() ? dD->data_ptr<float>() : nullptr;
@@ -313,8 +316,11 @@ void conv_common(const Tensor& x, const Tensor& weight, const OptT& bias_) {   /
         TORCH_CHECK(bias_->dim() == 1 && bias_->size(0) == x.size(1), "bias must have shape (dim,)");
     }
 }
-void fill_conv(vms_conv_fwd_params& P, const Tensor& x, const Tensor& weight, const OptT& bias, const OptT& out, bool silu, bool reverse) {
+void fill_conv(vms_conv_fwd_params& P, const Tensor& x, const Tensor& weight, const OptT& bias, const OptT& out, bool silu, bool reverse,
+               int64_t reverse_from = 0) {
     P = vms_conv_fwd_params{};
+    TORCH_CHECK(reverse_from >= 0 && reverse_from <= x.size(0) && (reverse_from == 0 || !reverse), "reverse_from must be in [0, batch] with reverse = False");
+    P.reverse_from = (int)reverse_from;
     P.batch = (int)x.size(0); P.dim = (int)x.size(1); P.seqlen = (int)x.size(2); P.width = (int)weight.size(-1);
     P.dtype = dtype_code(x); P.wdtype = dtype_code(weight);
     P.silu_activation = silu; P.reverse = reverse;
@@ -327,7 +333,7 @@ Tensor channel_last_like(const Tensor& x) {
     return at::empty({x.size(0), x.size(2), x.size(1)}, x.options()).transpose(1, 2);
 }
 
-Tensor conv_fwd(const Tensor& x, const Tensor& weight, const OptT& bias_, bool silu, bool reverse) {   // causal_conv1d.cpp:130-189
+Tensor conv_fwd(const Tensor& x, const Tensor& weight, const OptT& bias_, bool silu, bool reverse, int64_t reverse_from = 0) {   // causal_conv1d.cpp:130-189
     TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
     conv_common(x, weight, bias_);
     TORCH_CHECK(x.stride(2) == 1 || x.stride(1) == 1, "x.stride(2) == 1 || x.stride(1) == 1");
@@ -336,13 +342,13 @@ Tensor conv_fwd(const Tensor& x, const Tensor& weight, const OptT& bias_, bool s
     Tensor out = at::empty_like(x);
     if (channel_last && out.stride(1) != 1) out = channel_last_like(x);
     vms_conv_fwd_params P;
-    fill_conv(P, x, weight, bias_, out, silu, reverse);
+    fill_conv(P, x, weight, bias_, out, silu, reverse, reverse_from);
     call("vms_causal_conv1d_fwd", vms_causal_conv1d_fwd, P, x);
     return out;
 }
 
 std::vector<OptT> conv_bwd(const Tensor& x, const Tensor& weight, const OptT& bias_, Tensor dout, const OptT& dx_, bool silu,
-                           bool reverse, const OptT& zeroed, bool accumulate_dx) {   // causal_conv1d.cpp:191-268
+                           bool reverse, const OptT& zeroed, bool accumulate_dx, int64_t reverse_from = 0) {   // causal_conv1d.cpp:191-268
     TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
     conv_common(x, weight, bias_);
     TORCH_CHECK(dout.is_cuda(), "dout.is_cuda()");
@@ -376,7 +382,7 @@ std::vector<OptT> conv_bwd(const Tensor& x, const Tensor& weight, const OptT& bi
     }
     TORCH_CHECK(!accumulate_dx || dx_.has_value(), "accumulate_dx needs the dx tensor to add to");
     vms_conv_bwd_params Q{};
-    fill_conv(Q.f, x, weight, bias_, c10::nullopt, silu, reverse);
+    fill_conv(Q.f, x, weight, bias_, c10::nullopt, silu, reverse, reverse_from);
     Q.dout = dout.data_ptr(); Q.dx = dx.data_ptr(); Q.dweight = dweight.data_ptr<float>();
     Q.dbias = dbias.has_value() ? dbias->data_ptr<float>() : nullptr;
     Q.dout_batch_stride = dout.stride(0); Q.dout_c_stride = dout.stride(1); Q.dout_l_stride = dout.stride(2);
@@ -408,6 +414,76 @@ Tensor conv_update(const Tensor& x, const Tensor& conv_state, const Tensor& weig
     P.conv_state_batch_stride = conv_state.stride(0); P.conv_state_c_stride = conv_state.stride(1); P.conv_state_l_stride = conv_state.stride(2);
     call("vms_causal_conv1d_update", vms_causal_conv1d_update, P, x);
     return out;
+}
+
+
+// ---- the fused inner node of the Mamba block in one host call -----------------------------------------------------------
+// conv1d + SiLU -> x_proj GEMM -> dt_proj GEMM -> selective scan (+ z gate), and its backward, for the case every module of
+// the suite runs: input-dependent B / C, real A, no fused out_proj, no B / C projection biases
+// (mamba_ssm/ops/selective_scan_interface.py _inner_forward / _inner_backward, reference SSI:155-289).  Same operations in
+// the same order as the Python statement of the node -- the small GEMMs through ATen (hipBLASLt), the kernels through the
+// C ABI -- but one Python -> C++ crossing per direction instead of ~25: launch-bound shapes (the DBM block at
+// (2, 2304, 512)) are bound by exactly that host time.
+struct PaddedBC { Tensor B, C; int64_t pad; };
+PaddedBC pad_bc(const Tensor& B, const Tensor& C, bool reverse, bool both = false) {   // selective_scan_cuda.pad_bc
+    const int64_t L = B.size(-1), pad = (16 - L % 16) % 16;
+    if (pad == 0) return {B, C, 0};
+    if (both) return {at::constant_pad_nd(B, {pad, pad}).narrow(-1, pad, L), at::constant_pad_nd(C, {pad, pad}).narrow(-1, pad, L), pad};
+    if (reverse) return {at::constant_pad_nd(B, {pad, 0}).narrow(-1, pad, L), at::constant_pad_nd(C, {pad, 0}).narrow(-1, pad, L), pad};
+    return {at::constant_pad_nd(B, {0, pad}).narrow(-1, 0, L), at::constant_pad_nd(C, {0, pad}).narrow(-1, 0, L), pad};
+}
+
+// -> [out_z, conv_out, x_dbl, delta, ckpt, out]
+std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
+                              const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
+                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from) {
+    TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
+    c10::DeviceGuard guard(xz.device());
+    const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
+    TORCH_CHECK(xz.size(1) == 2 * d && x_proj_w.size(0) == R + 2 * N && x_proj_w.size(1) == d && dt_proj_w.size(0) == d,
+                "inner_fwd: xz (b, 2d, l), x_proj (R + 2N, d), dt_proj (d, R), A (d, N) expected");
+    const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
+    Tensor conv_out = conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
+    Tensor x_dbl = at::matmul(x_proj_w, conv_out);                       // (b, R + 2N, l): rows R.. are B, the last N are C
+    Tensor delta = at::matmul(dt_proj_w, x_dbl.narrow(1, 0, R));         // (b, d, l)
+    const PaddedBC bc = pad_bc(x_dbl.narrow(1, R, N).unsqueeze(1), x_dbl.narrow(1, R + N, N).unsqueeze(1), reverse, reverse_from > 0);
+    std::vector<Tensor> r = scan_fwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, delta_softplus, reverse, out_z_into, bc.pad, impl, segments,
+                                     reverse_from);
+    return {r[2], conv_out, x_dbl, delta, r[1], r[0]};
+}
+
+// -> [dxz, dconv_w (d, w), dconv_b | undefined, dx_proj_w, ddt_proj_w, dA, dD | undefined, ddelta_bias | undefined]
+// dxz_into: a dxz that already holds what xz received through another node; this node's dx / dz are ADDED by the kernels.
+std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w,
+                            const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
+                            const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
+                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from) {
+    c10::DeviceGuard guard(xz.device());
+    const int64_t b = xz.size(0), d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
+    const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
+    const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
+    const bool acc = dxz_into.has_value();
+    Tensor dxz = acc ? *dxz_into : at::empty_like(xz);
+    Tensor dx = dxz.narrow(1, 0, d), dz = dxz.narrow(1, d, d);
+    const Tensor Bv = x_dbl.narrow(1, R, N).unsqueeze(1), Cv = x_dbl.narrow(1, R + N, N).unsqueeze(1);
+    // one zero fill for every fp32 atomics target of the node (scan: dA, dB, dC, dD, ddelta_bias; conv: dweight, dbias)
+    const int64_t n_scan = A.numel() + 2 * Bv.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
+    const int64_t n_conv = conv_w.numel() + (conv_b.has_value() ? conv_b->numel() : 0);
+    Tensor zeros = at::zeros({n_scan + n_conv}, xz.options().dtype(at::kFloat));
+    const PaddedBC bc = pad_bc(Bv, Cv, reverse, reverse_from > 0);
+    std::vector<OptT> g = scan_bwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, dout, ckpt, out, dz, delta_softplus,
+                                   /*recompute_out_z=*/false, reverse, zeros.narrow(0, 0, n_scan), /*keep_fp32=*/true, acc, bc.pad, impl,
+                                   segments, Bv, Cv, reverse_from);
+    Tensor dconv_out = *g[0], ddelta = *g[1];
+    Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
+    dx_dbl.narrow(1, R, N).copy_(g[3]->squeeze(1));
+    dx_dbl.narrow(1, R + N, N).copy_(g[4]->squeeze(1));
+    Tensor ddt_proj_w = at::matmul(ddelta, x_dbl.narrow(1, 0, R).transpose(1, 2)).sum(0);  // (d, R)
+    dx_dbl.narrow(1, 0, R).copy_(at::matmul(dt_proj_w.t(), ddelta));                        // (b, R, l)
+    Tensor dx_proj_w = at::matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0);                // (R + 2N, d)
+    dconv_out.baddbmm_(x_proj_w.t().expand({b, -1, -1}), dx_dbl);                           // + W_x^T dx_dbl, in place
+    std::vector<OptT> c = conv_bwd(x, conv_w, conv_b, dconv_out, dx, true, reverse, zeros.narrow(0, n_scan, n_conv), acc, reverse_from);
+    return {dxz, c[1], c[2], dx_proj_w, ddt_proj_w, g[2], g[5], g[6]};
 }
 
 // reserve: event pairs created now, outside the timed region (the pool grows on demand if a run needs more)
@@ -444,11 +520,20 @@ std::vector<std::tuple<std::string, double>> timing_stop() {
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.doc() = "compiled PyTorch binding of libvms_hip.so (include/vms_hip.h)";
-    m.def("scan_fwd", &scan_fwd);
-    m.def("scan_bwd", &scan_bwd);
-    m.def("conv_fwd", &conv_fwd);
-    m.def("conv_bwd", &conv_bwd);
+    namespace py = pybind11;
+    m.def("scan_fwd", &scan_fwd, py::arg("u"), py::arg("delta"), py::arg("A"), py::arg("B"), py::arg("C"), py::arg("D"), py::arg("z"),
+          py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("bc_pad"), py::arg("impl"),
+          py::arg("segments"), py::arg("reverse_from") = 0);
+    m.def("scan_bwd", &scan_bwd, py::arg("u"), py::arg("delta"), py::arg("A"), py::arg("B"), py::arg("C"), py::arg("D"), py::arg("z"),
+          py::arg("delta_bias"), py::arg("dout"), py::arg("x"), py::arg("out"), py::arg("dz"), py::arg("delta_softplus"),
+          py::arg("recompute_out_z"), py::arg("reverse"), py::arg("zeroed"), py::arg("keep_fp32"), py::arg("accumulate_dz"), py::arg("bc_pad"),
+          py::arg("impl"), py::arg("segments"), py::arg("Bshape"), py::arg("Cshape"), py::arg("reverse_from") = 0);
+    m.def("conv_fwd", &conv_fwd, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("silu"), py::arg("reverse"), py::arg("reverse_from") = 0);
+    m.def("conv_bwd", &conv_bwd, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("dout"), py::arg("dx"), py::arg("silu"),
+          py::arg("reverse"), py::arg("zeroed"), py::arg("accumulate_dx"), py::arg("reverse_from") = 0);
     m.def("conv_update", &conv_update);
+    m.def("inner_fwd", &inner_fwd);
+    m.def("inner_bwd", &inner_bwd);
     m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0);
     m.def("timing_stop", &timing_stop);
     m.def("abi_version", []() { return vms_abi_version(); });

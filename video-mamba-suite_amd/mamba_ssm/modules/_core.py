@@ -37,6 +37,9 @@ _USE_REVERSE_KERNELS = os.environ.get("VMS_NO_REVERSE", "0") != "1"
 # them (2 x batch x d_inner x seqlen elements per direction) and skip a conv forward and a GEMM per direction.
 # VMS_CHECKPOINT_LVL=1 restores the reference's policy; the values are identical either way.
 _CHECKPOINT_LVL = int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))
+# The DBM block as ONE node on a batch of 2 B whose second half is scanned right-to-left (vms_hip.h reverse_from), with
+# the stacking and un-stacking folded into the projections' weight layouts.  VMS_DBM_TWO_NODES=1: one node per direction.
+_DBM_STACKED = os.environ.get("VMS_DBM_TWO_NODES", "0") != "1"
 
 
 def _s4d_real_log(d_inner, d_state, device):
@@ -179,9 +182,9 @@ class MambaCore(nn.Module):
             if inference_params.seqlen_offset > 0:
                 out, _, _ = self.step(hidden_states, conv_state, ssm_state)
                 return out
-        xz = self._in_projection(hidden_states)
         if self.variant == "dbm":
-            return self._forward_dbm(xz, inference_params)
+            return self._forward_dbm(hidden_states, inference_params)
+        xz = self._in_projection(hidden_states)
         fast = self.use_fast_path and inference_params is None
         if self.bimamba_type == "v2":
             if fast and _USE_REVERSE_KERNELS:
@@ -215,8 +218,20 @@ class MambaCore(nn.Module):
                                                    self.dt_proj, self.D)
         return self.out_proj(y.transpose(1, 2))
 
-    def _forward_dbm(self, xz, inference_params):
+    def _forward_dbm(self, hidden_states, inference_params):
         assert self.use_fast_path and inference_params is None, "Not implemented"  # reference mamba_new.py:216
+        if _USE_REVERSE_KERNELS and _DBM_STACKED:
+            # both halves as one node: the projection emits them stacked on the batch axis, entries >= B run right-to-left
+            # (the reference stacks a flipped copy of the second half, mamba_new.py:192-213, and flips its output back)
+            batch = hidden_states.shape[0]
+            xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True)    # (2 B, 2 d, L)
+            A = -torch.exp(self.A_log.float())
+            out = mamba_inner_fn_no_out_proj(
+                xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
+                self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,
+                checkpoint_lvl=_CHECKPOINT_LVL)                                                            # (2 B, d, L)
+            return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True)
+        xz = self._in_projection(hidden_states)
         xz_f, xz_b = torch.chunk(xz, 2, dim=1)
         if _USE_REVERSE_KERNELS:
             # shared weights, the second half scanned right-to-left: no cat / flip copies

@@ -35,28 +35,57 @@ def _k_splits(k_total, target=8192, most=16):
     return s
 
 
+def _interleave_halves(t, dim):
+    """channels ordered [half][c] along `dim` -> [c][half] (the order in which the two halves of the DBM block's channels
+    become the two halves of a stacked BATCH, see InProjFn): a view."""
+    n = t.shape[dim]
+    shp = list(t.shape)
+    v = t.reshape(shp[:dim] + [2, n // 2] + shp[dim + 1:]).transpose(dim, dim + 1)
+    return v
+
+
 class InProjFn(torch.autograd.Function):
-    """hidden (B, L, d_model), weight (C, d_model), bias (C,) | None -> xz (B, C, L), C-slowest in memory."""
+    """hidden (B, L, d_model), weight (C, d_model), bias (C,) | None -> xz (B, C, L), C-slowest in memory.
+
+    stack_halves (the DBM block, whose projection emits the (x, z) of BOTH directions, C = 2 * 2 d_inner): the result is
+    the (2 B, C / 2, L) tensor whose entries [0, B) are the first half of the channels and [B, 2 B) the second -- what
+    `torch.cat(xz.chunk(2, dim=1), dim=0)` would copy together, obtained for free by emitting the GEMM's output rows in
+    the order [c][half]: the (C, B L) product, read as [c][half][b][l], IS (C / 2, 2 B, L).  The row order is a
+    permutation of the weight's rows, folded into the transposed weight copy this node makes anyway."""
 
     @staticmethod
     @custom_fwd
-    def forward(ctx, hidden, weight, bias):
+    def forward(ctx, hidden, weight, bias, stack_halves=False):
         batch, seqlen, d_model = hidden.shape
+        channels = weight.shape[0]
         x2 = hidden.reshape(batch * seqlen, d_model)
+        if stack_halves:
+            assert channels % 2 == 0
         if hidden.is_cuda:
             dt = _autocast_dtype() or weight.dtype
             # W^T as its own (d_model, channels) matrix in the compute dtype: cast and transpose in one copy kernel
-            wt = torch.empty(d_model, weight.shape[0], dtype=dt, device=weight.device).copy_(weight.t())
+            wt = torch.empty(d_model, channels, dtype=dt, device=weight.device)
+            if stack_halves:   # column c * 2 + half of wt <- row half * (C / 2) + c of the weight
+                wt.view(d_model, channels // 2, 2).copy_(weight.view(2, channels // 2, d_model).permute(2, 1, 0))
+            else:
+                wt.copy_(weight.t())
             if x2.dtype != dt:
                 x2 = x2.to(dt)
-            xz = (wt.t() @ x2.t()).view(weight.shape[0], batch, seqlen).permute(1, 0, 2)
+            prod = wt.t() @ x2.t()                               # (channels, B L)
         else:  # CPU (tests with checker-backed extensions): the plain formulation
             wt = weight
-            xz = (weight @ x2.t()).view(weight.shape[0], batch, seqlen).permute(1, 0, 2)
+            w = _interleave_halves(weight, 0).reshape(channels, d_model) if stack_halves else weight
+            prod = w @ x2.t()
         if bias is not None:
-            xz = xz + bias.to(dtype=xz.dtype)[:, None]
+            b = _interleave_halves(bias, 0).reshape(channels) if stack_halves else bias
+            prod = prod + b.to(dtype=prod.dtype)[:, None]
+        if stack_halves:
+            xz = prod.view(channels // 2, 2 * batch, seqlen).permute(1, 0, 2)
+        else:
+            xz = prod.view(channels, batch, seqlen).permute(1, 0, 2)
         ctx.save_for_backward(hidden, wt)
         ctx.transposed = hidden.is_cuda
+        ctx.stack_halves = stack_halves
         ctx.has_bias = bias is not None
         return xz
 
@@ -67,49 +96,89 @@ class InProjFn(torch.autograd.Function):
         batch, seqlen, d_model = hidden.shape
         rows = batch * seqlen
         channels = wt.shape[1] if ctx.transposed else wt.shape[0]
-        g2 = dxz.permute(1, 0, 2).reshape(channels, rows)       # a view when dxz has xz's layout
+        # rows of g2 in the order the forward emitted them ([c][half] when stacked); a view when dxz has xz's layout
+        g2 = dxz.permute(1, 0, 2).reshape(channels, rows)
         x2 = hidden.reshape(rows, d_model)
+        unstack = (lambda t: t.reshape((channels // 2, 2) + t.shape[1:]).transpose(0, 1).reshape(t.shape)) if ctx.stack_halves \
+            else (lambda t: t)
         dhidden = dweight = dbias = None
         if ctx.needs_input_grad[0]:
             if ctx.transposed:
                 dhidden = (g2.to(wt.dtype).t() @ wt.t()).view(batch, seqlen, d_model).to(hidden.dtype)
             else:
-                dhidden = (g2.t() @ wt).view(batch, seqlen, d_model)
+                w = _interleave_halves(wt, 0).reshape(channels, d_model) if ctx.stack_halves else wt
+                dhidden = (g2.t() @ w).view(batch, seqlen, d_model)
         if ctx.needs_input_grad[1]:
             s = _k_splits(rows)
-            dweight = torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)).sum(0)
+            dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)).sum(0))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            dbias = g2.sum(dim=1)
-        return dhidden, dweight, dbias
+            dbias = unstack(g2.sum(dim=1))
+        return dhidden, dweight, dbias, None
 
 
 class OutProjFn(torch.autograd.Function):
-    """y (B, C, L) with unit seqlen stride, weight (d_model, C), bias | None -> (B, L, d_model)."""
+    """y (B, C, L) with unit seqlen stride, weight (d_model, C), bias | None -> (B, L, d_model).
+
+    stacked_halves (the DBM block): y is the (2 B, C / 2, L) output of the stacked node (entries [0, B): the channels
+    [0, C / 2) of the projection's input, entries [B, 2 B): the channels [C / 2, C)), channel-slowest in memory as the scan
+    leaves it -- i.e. already the (C, B L) matrix with rows [c][half]; the weight's columns are permuted to match (one
+    small copy, with the autocast cast) instead of torch.cat copying the activations."""
 
     @staticmethod
     @custom_fwd
-    def forward(ctx, y, weight, bias):
-        ctx.save_for_backward(y, weight)
+    def forward(ctx, y, weight, bias, stacked_halves=False):
         ctx.has_bias = bias is not None
-        return F.linear(y.transpose(1, 2), weight, bias)
+        ctx.stacked_halves = stacked_halves
+        if not stacked_halves:
+            ctx.save_for_backward(y, weight)
+            return F.linear(y.transpose(1, 2), weight, bias)
+        b2, half_c, seqlen = y.shape
+        batch, d_model = b2 // 2, weight.shape[0]
+        dt = (_autocast_dtype() or weight.dtype) if y.is_cuda else weight.dtype
+        wp = torch.empty(d_model, 2 * half_c, dtype=dt, device=weight.device)     # column c * 2 + half <- column half * C/2 + c
+        wp.view(d_model, half_c, 2).copy_(weight.view(d_model, 2, half_c).transpose(1, 2))
+        y2 = y.permute(1, 0, 2).reshape(2 * half_c, batch * seqlen)                 # a view in the scan's layout
+        if y2.dtype != dt:
+            y2 = y2.to(dt)
+        out = (y2.t() @ wp.t()).view(batch, seqlen, d_model)
+        if bias is not None:
+            out = out + bias.to(out.dtype)
+        ctx.save_for_backward(y2, wp)
+        ctx.dims = (batch, half_c, seqlen)
+        return out
 
     @staticmethod
     @custom_bwd
     def backward(ctx, dout):
-        y, weight = ctx.saved_tensors
+        if not ctx.stacked_halves:
+            y, weight = ctx.saved_tensors
+            dy = dweight = dbias = None
+            if ctx.needs_input_grad[0]:
+                dy = torch.matmul(weight.t(), dout.transpose(1, 2))  # (B, C, L): the layout the scan backward reads
+            if ctx.needs_input_grad[1]:
+                dweight = torch.bmm(y, dout).sum(0).t()              # one K slice per batch entry
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                dbias = dout.sum(dim=(0, 1))
+            return dy, dweight, dbias, None
+        y2, wp = ctx.saved_tensors
+        batch, half_c, seqlen = ctx.dims
+        d_model = wp.shape[0]
+        dout = dout.to(wp.dtype)
         dy = dweight = dbias = None
         if ctx.needs_input_grad[0]:
-            dy = torch.matmul(weight.t(), dout.transpose(1, 2))  # (B, C, L): the layout the scan backward reads
+            dy2 = torch.matmul(wp.t(), dout.reshape(batch * seqlen, d_model).t())        # (C, B L), rows [c][half]
+            dy = dy2.view(half_c, 2 * batch, seqlen).permute(1, 0, 2)                      # (2 B, C / 2, L), the scan's layout
         if ctx.needs_input_grad[1]:
-            dweight = torch.bmm(y, dout).sum(0).t()              # one K slice per batch entry
+            dwp = torch.bmm(y2.view(2 * half_c, batch, seqlen).permute(1, 0, 2), dout).sum(0).t()   # (d_model, C) permuted
+            dweight = dwp.view(d_model, half_c, 2).transpose(1, 2).reshape(d_model, 2 * half_c)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dout.sum(dim=(0, 1))
-        return dy, dweight, dbias
+        return dy, dweight, dbias, None
 
 
-def in_proj_fn(hidden, weight, bias=None):
-    return InProjFn.apply(hidden, weight, bias)
+def in_proj_fn(hidden, weight, bias=None, stack_halves=False):
+    return InProjFn.apply(hidden, weight, bias, stack_halves)
 
 
-def out_proj_fn(y, weight, bias=None):
-    return OutProjFn.apply(y, weight, bias)
+def out_proj_fn(y, weight, bias=None, stacked_halves=False):
+    return OutProjFn.apply(y, weight, bias, stacked_halves)

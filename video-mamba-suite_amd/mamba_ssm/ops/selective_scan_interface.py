@@ -14,6 +14,7 @@ reference's recompute policy (checkpoint_lvl=1: conv output and delta are rebuil
 SSI:218-219, 238-241) and its layout contract (delta and the scan output are "d-slowest",
 dx/dz are written straight into the halves of one dxz buffer, SSI:244-248, 281-283).
 """
+import os
 import warnings
 
 import torch
@@ -21,6 +22,7 @@ import torch.nn.functional as F
 
 import causal_conv1d_cuda
 import selective_scan_cuda
+import vms_hip as _vms
 from causal_conv1d import causal_conv1d_fn
 
 try:  # torch >= 2.4
@@ -152,6 +154,23 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
 # =================================================================================================
 # fused Mamba inner nodes
 # =================================================================================================
+def _inner_ext_module():
+    return _vms.ext()
+
+
+def _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias):
+    """The compiled one-call form of the node (vms_torch.cpp inner_fwd / inner_bwd) when it applies: GPU tensors, the
+    binding built, input-dependent B / C without projection biases, one direction, no fused out_proj -- what every module
+    of the suite runs.  VMS_NO_INNER_EXT=1 keeps the Python statement of the node (tests compare the two)."""
+    if (out_proj is not None or A_b is not None or B is not None or C is not None or B_proj_bias is not None
+            or C_proj_bias is not None or not xz.is_cuda or os.environ.get("VMS_NO_INNER_EXT") == "1"):
+        return None
+    ext = _vms.ext()
+    if ext is None or not hasattr(ext, "inner_fwd") or _vms.scan_impl_from_env() >= _vms.IMPL_ROWS:
+        return None
+    return ext
+
+
 def _autocast_weights(*ws):
     if not torch.is_autocast_enabled():
         return ws
@@ -224,9 +243,10 @@ def _bc_from_x_dblT(x_dblT, lo, hi, bias):
 
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                   checkpoint_lvl, reverse=False, out_z_into=None):
+                   checkpoint_lvl, reverse=False, out_z_into=None, reverse_from=0):
     """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A.
-    reverse: the whole node runs right-to-left (== flip o node o flip, without the copies)."""
+    reverse: the whole node runs right-to-left (== flip o node o flip, without the copies).
+    reverse_from > 0: the batch entries >= reverse_from run right-to-left, the others left-to-right (vms_hip.h ABI v5)."""
     assert checkpoint_lvl in (0, 1)
     batch, _, L = xz.shape
     R = delta_proj_weight.shape[1]
@@ -245,11 +265,31 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     z = xz[:, d_inner:]
     if is_complex:
         raise RuntimeError("selective_scan: complex A is not supported by the MI355X HIP path")
-    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse)
-    x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
-
     ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
     ctx.has_B_proj_bias, ctx.has_C_proj_bias = B_proj_bias is not None, C_proj_bias is not None
+    ext = _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias)
+    ctx.fast = ext is not None
+    if ext is not None:
+        # the whole node in one host call (csrc/torch_binding/vms_torch.cpp inner_fwd): same ops, same order
+        D = D.contiguous() if D is not None else None
+        out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
+            xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from))
+        ctx.reverse_from = int(reverse_from)
+        ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
+        ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
+        ctx.has_out_proj = ctx.has_out_proj_bias = ctx.bidirectional = False
+        ctx.reverse = bool(reverse)
+        if checkpoint_lvl >= 1:
+            conv_out, delta = None, None
+        ctx.save_for_backward(xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, None, conv_out, delta, A, None, None,
+                              D, delta_bias, ckpt, out, None, None, None)
+        return out_z
+    ctx.reverse_from = int(reverse_from)
+    rf = {"reverse_from": int(reverse_from)} if reverse_from else {}
+    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse, **rf)
+    x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
+
     if B is None:
         B = _bc_from_x_dblT(x_dbl, R, R + d_state, B_proj_bias)
     else:
@@ -263,7 +303,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
     # out_z_into: the gated output is added to that tensor by the kernel (second direction of a bidirectional node)
     out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse,
-                                               **({} if out_z_into is None else {"out_z_into": out_z_into}))
+                                               **({} if out_z_into is None else {"out_z_into": out_z_into}), **rf)
     saved_b = (None, None, None)
     if A_b is not None:
         assert not A_b.is_complex(), "A should not be complex!!"
@@ -302,9 +342,18 @@ def _inner_backward(ctx, dout, dxz_into=None):
     d_inner = conv_w.shape[0]
     x, z = xz[:, :d_inner], xz[:, d_inner:]
     dout = _last_dim_contiguous(dout)
+    rf = {"reverse_from": ctx.reverse_from} if getattr(ctx, "reverse_from", 0) else {}
     if ctx.checkpoint_lvl == 1:
-        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse)
+        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse, **rf)
         delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
+    if getattr(ctx, "fast", False):
+        dxz, dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = _inner_ext_module().inner_bwd(
+            dout, xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out,
+            bool(ctx.delta_softplus), ctx.reverse, dxz_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_BWD_SEGMENTS"),
+            getattr(ctx, "reverse_from", 0))
+        return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b, dx_proj_weight=dx_proj_weight,
+                    ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=None, dout_proj_bias=None, dA=dA, dA_b=None,
+                    dB=None, dC=None, dD=dD, ddelta_bias=ddelta_bias, dB_proj_bias=None, dC_proj_bias=None)
     dxz = torch.empty_like(xz) if dxz_into is None else dxz_into
     acc = dxz_into is not None
     dx, dz = dxz[:, :d_inner], dxz[:, d_inner:]
@@ -324,7 +373,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
     want_out_z = ctx.has_out_proj
     dconv_out, ddelta, dA, dB, dC, dD, ddelta_bias, dz, *out_z = selective_scan_cuda.bwd(
         conv_out, delta, A, B, C, D, z, delta_bias, dy, ckpt, out, dz, ctx.delta_softplus, want_out_z, ctx.reverse,
-        zeroed=zeros[:n_scan], keep_fp32=True, accumulate_dz=acc)
+        zeroed=zeros[:n_scan], keep_fp32=True, accumulate_dz=acc, **rf)
     out_z = out_z[0] if out_z else None
     dA_b = None
     if ctx.bidirectional:
@@ -370,7 +419,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
     # in place: dconv_out is this node's own buffer (the scan's du); out-of-place baddbmm copies it first
     dconv_out.baddbmm_(x_proj_weight.t().expand(batch, -1, -1), dx_dbl)                 # + W_x^T dx_dbl
     _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse,
-                                                               zeroed=zeros[zeros.numel() - n_conv:], accumulate_dx=acc)
+                                                               zeroed=zeros[zeros.numel() - n_conv:], accumulate_dx=acc, **rf)
     return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b if conv_b is not None else None,
                 dx_proj_weight=dx_proj_weight, ddelta_proj_weight=ddelta_proj_weight,
                 dout_proj_weight=dout_proj_weight, dout_proj_bias=dout_proj_bias,
@@ -385,11 +434,11 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
     @custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                 A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False):
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False, reverse_from=0):
         """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)"""
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               None, A, None, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
-                              delta_softplus, checkpoint_lvl, reverse)
+                              delta_softplus, checkpoint_lvl, reverse, reverse_from=reverse_from)
 
     @staticmethod
     @custom_bwd
@@ -397,7 +446,7 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
         g = _inner_backward(ctx, dout)
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
                 g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
-                None, None, None)
+                None, None, None, None)
 
 
 class NegExpPairFn(torch.autograd.Function):
@@ -554,15 +603,17 @@ def bimamba_inner_fn(
 def mamba_inner_fn_no_out_proj(
     xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1
+    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1, reverse_from=0
 ):
     """reverse (extension, default off): the node runs right-to-left over xz -- the value of
     flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for.
+    reverse_from (extension): batch entries >= reverse_from run right-to-left, the others left-to-right -- the DBM block's
+    two halves (shared weights) as ONE node on a batch of 2 B (mamba_new.py:192-213 stacks a flipped copy instead).
     checkpoint_lvl (extension; the reference hard-wires its default 1 here): 0 keeps conv_out and delta for the
     backward instead of rebuilding them."""
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                        A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                                       checkpoint_lvl, reverse)
+                                       checkpoint_lvl, reverse, reverse_from)
 
 
 # ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------

@@ -72,7 +72,7 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     return batch, dim, seqlen, dstate, var_B, var_C
 
 
-def pad_bc(B, C, reverse=False):
+def pad_bc(B, C, reverse=False, both=False):
     """Variable B, C (batch, groups, dstate, seqlen) -> (B', C', pad): the same values as views of zero-padded
     copies whose rows stay readable (zeros) for `pad` elements past their logical end -- after the last element, or
     before the first one for a right-to-left scan.  With that guarantee (vms_hip.h bc_pad) the fast kernels, which
@@ -81,24 +81,27 @@ def pad_bc(B, C, reverse=False):
     pad = (-seqlen) % 16
     if pad == 0 or B.dim() != 4 or C.dim() != 4:
         return B, C, 0
+    if both:   # reverse_from: some entries are read past their end, the others before their start
+        return F.pad(B, (pad, pad))[..., pad:pad + seqlen], F.pad(C, (pad, pad))[..., pad:pad + seqlen], pad
     if reverse:
         return F.pad(B, (pad, 0))[..., pad:], F.pad(C, (pad, 0))[..., pad:], pad
     return F.pad(B, (0, pad))[..., :seqlen], F.pad(C, (0, pad))[..., :seqlen], pad
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, bc_pad=None):
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, bc_pad=None, reverse_from=0):
     """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)
     reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies.
     out_z_into (extension): a (batch, dim, seqlen) tensor the gated output is ADDED to (and that is returned as
     out_z) -- the other direction's output of a bidirectional block.
-    bc_pad (extension): None = pad B / C here when the length needs it (pad_bc); an int = the caller already did."""
+    bc_pad (extension): None = pad B / C here when the length needs it (pad_bc); an int = the caller already did.
+    reverse_from (extension, vms_hip.h ABI v5): batch entries >= reverse_from run right-to-left, the others left-to-right."""
     ext = _k.ext()
     impl = _k.scan_impl_from_env()
     if ext is not None and impl < _k.IMPL_ROWS:   # compiled binding: same checks / allocations / launch in C++
         if bc_pad is None:
-            B, C, bc_pad = pad_bc(B, C, reverse)
+            B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         return ext.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, bool(delta_softplus), bool(reverse), out_z_into,
-                            bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"))
+                            bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from))
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
@@ -112,9 +115,9 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
     # x: the reference-shaped (batch, dim, n_chunks, 2*dstate) tensor, allocated by the binding as a view
     # of a larger buffer that also carries the finer checkpoints the backward kernels start from
     if bc_pad is None:
-        B, C, bc_pad = pad_bc(B, C, reverse)
+        B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
     x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse,
-                    out_z_into is not None, bc_pad)
+                    out_z_into is not None, bc_pad, reverse_from)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
@@ -130,7 +133,7 @@ def _carve(flat, offset, like):
 
 
 def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False,
-        zeroed=None, keep_fp32=False, accumulate_dz=False, bc_pad=None):
+        zeroed=None, keep_fp32=False, accumulate_dz=False, bc_pad=None, reverse_from=0):
     """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)
     zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
     ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
@@ -139,12 +142,12 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     impl = _k.scan_impl_from_env()
     if ext is not None and impl < _k.IMPL_ROWS:
         if bc_pad is None:
-            Bk, Ck, bc_pad = pad_bc(B, C, reverse)
+            Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         else:
             Bk, Ck = B, C
         return ext.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out_, dz_, bool(delta_softplus),
                             bool(recompute_out_z), bool(reverse), zeroed, bool(keep_fp32), bool(accumulate_dz), bc_pad, impl,
-                            _k.segments_from_env("VMS_BWD_SEGMENTS"), B, C)
+                            _k.segments_from_env("VMS_BWD_SEGMENTS"), B, C, int(reverse_from))
     batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
     _check(dout.is_cuda, "dout.is_cuda()")
@@ -178,7 +181,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
     if bc_pad is None:
-        Bk, Ck, bc_pad = pad_bc(B, C, reverse)   # B / C themselves keep their shapes for the gradients below
+        Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)   # B / C themselves keep their shapes for the gradients below
     else:
         Bk, Ck = B, C
     if zeroed is not None and not A.is_complex():
@@ -200,7 +203,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         dD = torch.zeros_like(D_) if D_ is not None else None
         ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     _k.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
-                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz), bc_pad)
+                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz), bc_pad, reverse_from)
     if not keep_fp32:
         dB, dC = dB.to(B.dtype), dC.to(C.dtype)
     result = [du, ddelta, dA, dB, dC, dD, ddelta_bias]

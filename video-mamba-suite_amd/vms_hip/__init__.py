@@ -31,7 +31,8 @@ class ScanFwdParams(ctypes.Structure):
             "B_batch_stride", "B_group_stride", "B_d_stride", "B_dstate_stride",
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
         + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("bc_pad", _i32),
-           ("workspace", _vp), ("workspace_bytes", _i64), ("impl", _i32), ("segments", _i32)]
+           ("workspace", _vp), ("workspace_bytes", _i64), ("impl", _i32), ("segments", _i32),
+           ("reverse_from", _i32), ("reserved1", _i32)]
     )
 
 
@@ -57,6 +58,7 @@ class ConvFwdParams(ctypes.Structure):
                                "weight_width_stride", "out_batch_stride", "out_c_stride", "out_l_stride")]
         + [("conv_state", _vp)]
         + [(n, _i64) for n in ("conv_state_batch_stride", "conv_state_c_stride", "conv_state_l_stride")]
+        + [("reverse_from", _i32), ("reserved1", _i32)]
     )
 
 
@@ -157,7 +159,7 @@ def ext():
             lib()
             try:
                 import _vms_torch
-                if _vms_torch.abi_version() == 4:
+                if _vms_torch.abi_version() == 5:
                     _ext = _vms_torch
             except ImportError as e:
                 # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
@@ -209,8 +211,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         L.vms_last_kernel.restype = ctypes.c_char_p
-        if L.vms_abi_version() != 4:
-            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 4: rebuild it")
+        if L.vms_abi_version() != 5:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 5: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams)):
@@ -267,7 +269,7 @@ def dtype_code(t):
         raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
 
 
-def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False):
+def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False, reverse_from=0):
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
     var_B, var_C = B.dim() >= 3, C.dim() >= 3
@@ -277,6 +279,7 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.dtype = dtype_code(u)
     P.is_variable_B, P.is_variable_C, P.delta_softplus = int(var_B), int(var_C), int(bool(delta_softplus))
     P.reverse = int(bool(reverse))
+    P.reverse_from = int(reverse_from)
     P.impl = scan_impl_from_env()
     P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
@@ -332,10 +335,10 @@ def _ws_bytes(fn_name, params, ref_tensor):
 
 
 def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False,
-             out_z_accumulate=False, bc_pad=0):
+             out_z_accumulate=False, bc_pad=0, reverse_from=0):
     """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
     P = ScanFwdParams()
-    fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
+    fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
     P.out_z_accumulate = int(bool(out_z_accumulate))
     P.bc_pad = int(bc_pad)
     P.segments = _segments_from_env("VMS_FWD_SEGMENTS")
@@ -366,9 +369,9 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
 
 
 def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
-             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0):
+             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
     Q = ScanBwdParams()
-    fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse)
+    fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
     if Q.f.impl >= IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
         Q.f.x_has_sub = 2
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
@@ -397,12 +400,13 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
     _call("vms_selective_scan_bwd", Q, u)
 
 
-def fill_conv_fwd(P, x, weight, bias, out, silu, reverse=False):
+def fill_conv_fwd(P, x, weight, bias, out, silu, reverse=False, reverse_from=0):
     P.batch, P.dim, P.seqlen = x.shape
     P.width = weight.shape[-1]
     P.dtype, P.wdtype = dtype_code(x), dtype_code(weight)
     P.silu_activation = int(bool(silu))
     P.reverse = int(bool(reverse))
+    P.reverse_from = int(reverse_from)
     P.x, P.weight, P.bias, P.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(out)
     P.x_batch_stride, P.x_c_stride, P.x_l_stride = x.stride()
     P.weight_c_stride, P.weight_width_stride = weight.stride()
@@ -410,15 +414,15 @@ def fill_conv_fwd(P, x, weight, bias, out, silu, reverse=False):
         P.out_batch_stride, P.out_c_stride, P.out_l_stride = out.stride()
 
 
-def conv_fwd(x, weight, bias, out, silu, reverse=False):
+def conv_fwd(x, weight, bias, out, silu, reverse=False, reverse_from=0):
     P = ConvFwdParams()
-    fill_conv_fwd(P, x, weight, bias, out, silu, reverse)
+    fill_conv_fwd(P, x, weight, bias, out, silu, reverse, reverse_from)
     _call("vms_causal_conv1d_fwd", P, x)
 
 
-def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False, dx_accumulate=False):
+def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False, dx_accumulate=False, reverse_from=0):
     Q = ConvBwdParams()
-    fill_conv_fwd(Q.f, x, weight, bias, None, silu, reverse)
+    fill_conv_fwd(Q.f, x, weight, bias, None, silu, reverse, reverse_from)
     Q.dout, Q.dx, Q.dweight, Q.dbias = _ptr(dout), _ptr(dx), _ptr(dweight), _ptr(dbias)
     Q.dout_batch_stride, Q.dout_c_stride, Q.dout_l_stride = dout.stride()
     Q.dx_batch_stride, Q.dx_c_stride, Q.dx_l_stride = dx.stride()
