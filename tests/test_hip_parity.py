@@ -569,6 +569,36 @@ def test_scan_extension_error_behaviour():
         selective_scan_cuda.bwd(u2, u2, A, B2, B2, None, None, None, u2, None, None, None, False, False)
 
 
+@pytest.mark.parametrize("L", [2048, 1031])
+def test_scan_bwd_softplus_derivative_for_strongly_negative_delta(oracle, L):
+    """fp32: delta + bias in [-14, -5], where softplus' = sigmoid is 1e-6 .. 7e-3.  The derivative must come from the raw
+    pre-activation (e / (1 + e)) as in the reference (selective_scan_bwd_kernel.cuh:439-452); rebuilding it as
+    1 - exp(-softplus) subtracts two numbers next to 1 and loses 2 .. 5 digits there.  ddelta and ddelta_bias
+    are compared RELATIVE TO THEIR OWN SCALE, so the small derivatives are what is tested."""
+    import selective_scan_cuda
+    import vms_hip
+    b, d, N = 2, 32, 16
+    rng = np.random.default_rng(3)
+    f = lambda *s: rng.standard_normal(s).astype(np.float32)
+    u, z, g = f(b, d, L), f(b, d, L), f(b, d, L)
+    delta = (-9.0 + 4.0 * rng.random((b, d, L))).astype(np.float32)          # raw delta
+    bias = (-1.0 + rng.random(d)).astype(np.float32)                          # delta + bias in [-14, -5]
+    A = (-0.5 - rng.random((d, N))).astype(np.float32)
+    Bm, Cm, Dv = f(b, 1, N, L), f(b, 1, N, L), f(d)
+    ref = oracle.scan_bwd(u, delta, A, Bm, Cm, Dv, z, bias, g, True, prec="f64")
+    t = lambda a: torch.tensor(a, device=DEV)
+    out, x, _ = selective_scan_cuda.fwd(t(u), t(delta), t(A), t(Bm), t(Cm), t(Dv), t(z), t(bias), True)
+    got = selective_scan_cuda.bwd(t(u), t(delta), t(A), t(Bm), t(Cm), t(Dv), t(z), t(bias), t(g), x, out, None, True, False)
+    assert vms_hip.last_kernel().startswith("scan_bwd_pair")
+    check(got[1], ref["ddelta"], 1e-3, "ddelta at strongly negative delta + bias")
+    check(got[6], ref["ddelta_bias"], 1e-3, "ddelta_bias at strongly negative delta + bias")
+    # element-wise relative error where the reference is not tiny: the cancellation showed up as 1e-2 .. 1e-4 here
+    r = ref["ddelta"]
+    m = np.abs(r) > 1e-3 * np.abs(r).max()
+    rel = np.abs(got[1].cpu().numpy() - r)[m] / np.abs(r)[m]
+    assert rel.max() < 2e-3, f"element-wise relative error of ddelta {rel.max():.2e}"
+
+
 def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
     """ABI v4: the library reads no environment; the binding turns VMS_SCAN_IMPL / VMS_*_SEGMENTS into the impl /
     segments fields, and vms_last_kernel() names what ran -- so a declined fast path is visible to the caller."""

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 //     instead of 4 rows (1 KB per wave and state), every thread sums the W partials of its (state, tensor,
 //     position)s with 8 ds_read_b32 per pair and issues the atomics;
 //   * no second B / C register set (the fp32 B / C of a state are read from LDS when the state starts), the
-//     softplus derivative is rebuilt in the chunk epilogue as 1 - exp(-delta) instead of being carried, u is
+//     softplus derivative sigmoid(delta_raw) is carried from the prologue (8 registers; round 3), u is
 //     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
 //     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
 #ifndef VMS_BWD_SG
@@ -732,17 +732,28 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
         const uint32_t pl0 = REV ? L - l0 - K : l0;
         const int rd_lo = c * CH + rd_pos;
         float* const rd_dst_c = rd_dst + (REV ? L - 1 - rd_lo : rd_lo);
-        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2];
+        f2 dl2[K / 2], dlu2[K / 2], dy2[K / 2], sg2[K / 2];  // sg = d softplus / d(delta + bias), for the epilogue
         float sdl = 0.f, dl_first = 0.f;
         {
             float dy[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 dy[i] = ok ? pdo.at(i) : 0.f;   // past the end: c = 0, a = 1 (identity for the suffix scan)
-                float t = pdt.at(i) + bias;
-                if (p.delta_softplus) t = softplusf_(t);
+                float t = pdt.at(i) + bias, sg = 1.f;
+                if (p.delta_softplus) {
+                    // softplus and its derivative from ONE exp / rcp / log: e = exp(t), w = 1 + e: softplus = log1p(e) =
+                    // log(w) + (e - (w - 1)) / w, sigmoid(t) = e / w -- accurate for strongly negative t, where
+                    // 1 - exp(-softplus) (the previous form) cancels (selective_scan_fwd_kernel.cuh:153-156, bwd_kernel.cuh:439-452)
+                    const float e = fast_exp(t);
+                    const float w = 1.f + e;
+                    const float rw = fast_rcp(w);
+                    const float sp = fmaf(e - (w - 1.f), rw, fast_log(w));
+                    sg = t <= 20.f ? e * rw : 1.f;
+                    t = t <= 20.f ? sp : t;
+                }
                 t = ok ? t : 0.f;
                 dl2[i / 2][i % 2] = t;
+                sg2[i / 2][i % 2] = sg;
                 sdl += t;
                 if (i == 0) dl_first = t;
             }
@@ -975,9 +986,7 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
             for (int i = 0; i < K; ++i) {
                 const float dl = dl2[i / 2][i % 2];
                 const float s1 = S1[i / 2][i % 2], s2 = S2[i / 2][i % 2];
-                // d softplus / d(delta + bias) = sigmoid = 1 - exp(-softplus); 1 above the reference's threshold, where
-                // exp(-delta) < 2^-28 anyway (selective_scan_bwd_kernel.cuh:439-452)
-                const float sg = p.delta_softplus ? 1.f - fast_exp2(-kLog2e * dl) : 1.f;
+                const float sg = sg2[i / 2][i % 2];   // sigmoid(delta_raw + bias), 1 above the reference's threshold
                 duv[i] = fmaf(dl, s1, Dd * dy2[i / 2][i % 2]);
                 ddl[i] = fmaf(uvv[i], s1, s2) * sg;
                 dbias_acc += ok ? ddl[i] : 0.f;
