@@ -351,7 +351,8 @@ static void scan_bwd_sub_batches(const vms_scan_bwd_params& q, vms_scan_bwd_para
 }
 
 extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
-    if (q != nullptr && q->f.reverse_from > 0 && q->f.reverse_from < q->f.batch) {
+    if (q != nullptr && q->f.reverse_from > 0 && q->f.reverse_from < q->f.batch &&
+        !(scan_impl_level(q->f) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(*q, true) && scan_bwd_pair_native_mixed(*q))) {
         vms_scan_bwd_params lo, hi;
         scan_bwd_sub_batches(*q, lo, hi);
         const int64_t wl = vms_scan_bwd_workspace_bytes(&lo), wh = vms_scan_bwd_workspace_bytes(&hi);
@@ -369,7 +370,8 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
-        if (p.reverse_from < p.batch) {
+        const bool native = scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q);
+        if (p.reverse_from < p.batch && !native) {
             vms_scan_bwd_params lo, hi;
             scan_bwd_sub_batches(q, lo, hi);
             const int64_t wl = round256b(vms_scan_bwd_workspace_bytes(&lo)), wh = vms_scan_bwd_workspace_bytes(&hi);

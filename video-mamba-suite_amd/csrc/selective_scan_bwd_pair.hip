@@ -581,7 +581,7 @@ template <int W> struct B4 {
 };
 
 template <typename T, bool HZ, bool REV, int W>
-__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
+__device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN, CH = kCH;
@@ -1026,6 +1026,20 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
 }
 
 
+// RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from).  A workgroup serves one batch
+// entry: the direction is workgroup-uniform, one branch selects the body.
+template <typename T, bool HZ, int RM, int W>
+__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
+    if constexpr (RM == 2) {
+        const int wg_per_seg = gridDim.x / n_seg;
+        const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
+        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W>(q, n_seg, seg_carry);
+        else scan_bwd_pair4_body<T, HZ, false, W>(q, n_seg, seg_carry);
+    } else {
+        scan_bwd_pair4_body<T, HZ, RM == 1, W>(q, n_seg, seg_carry);
+    }
+}
+
 // (A third generation -- state pairs in packed registers, 1,372 us against this kernel's 949 us -- was measured in round 2,
 // profiles/r02_bwd_state_pairs.md, and removed from the tree in round 3; its source is csrc/selective_scan_bwd_pair.hip
 // :1028-1507 of commit 64fcaa4.)
@@ -1041,8 +1055,7 @@ template <int CTRL>
 __device__ __forceinline__ float row_newbcast(float v) { return bdpp<0x150 + CTRL>(0.f, v); }
 
 template <typename T, bool HZ, bool REV>
-__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_scan_bwd_params q, const int n_seg,
-                                                                        float2* __restrict__ seg_carry) {
+__device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q, const int n_seg, float2* __restrict__ seg_carry) {
     const vms_scan_fwd_params& p = q.f;
     constexpr int K = kBK, N = kBN, CH = kCH;
     const int lane = threadIdx.x & 63;
@@ -1154,8 +1167,35 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_sc
 #undef VMS_OFF
 }
 
-// how many ranges of chunks the backward is split into (1 = not split): enough to give every CU two workgroups,
-// at least 8 chunks (1024 elements) per range; q.f.segments >= 1 forces a count (vms_hip.h)
+template <typename T, bool HZ, int RM>   // RM as for scan_bwd_pair4_kernel
+__global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_scan_bwd_params q, const int n_seg,
+                                                                        float2* __restrict__ seg_carry) {
+    if constexpr (RM == 2) {
+        const int wg_per_seg = gridDim.x / (n_seg - 1);
+        const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
+        if (b >= q.f.reverse_from) scan_bwd_carry_body<T, HZ, true>(q, n_seg, seg_carry);
+        else scan_bwd_carry_body<T, HZ, false>(q, n_seg, seg_carry);
+    } else {
+        scan_bwd_carry_body<T, HZ, RM == 1>(q, n_seg, seg_carry);
+    }
+}
+
+// reverse_from served by ONE launch (plus one carry launch when split): whole-vector rows, i.e. the second generation
+bool scan_bwd_pair_native_mixed(const vms_scan_bwd_params& q) {
+    const vms_scan_fwd_params& p = q.f;
+    return p.reverse_from > 0 && p.reverse_from < p.batch && !p.reverse && p.seqlen % kBK == 0;
+}
+
+// how many ranges of chunks the backward is split into (1 = not split); q.f.segments >= 1 forces a count (vms_hip.h).
+// Measured (profiles/r03_bwd_segments.md, one MI355X, 256 CUs; workgroups = batch x dim / 32):
+//   * grids of more than half the CUs (192 workgroups: (8, 768, 3136), (8, 768, 1568)) LOSE 7 - 20 % with any split: two
+//     workgroups share a CU anyway, the kernel is VALU-bound, and the carry pass is pure overhead -> never split;
+//   * small grids gain up to 3.2x: 32 workgroups (one direction of the DBM block at (2, 512, 2304)) 256 -> 81 us with 6 - 8
+//     ranges, 64 workgroups 259 -> 120 us with 4, 96 workgroups 360 -> 221 us with 6.
+//   The best count is, with one exception, the LARGEST that still gives every workgroup its own CU (one round):
+//   (1, 768, 65536) = 24 workgroups: 10 ranges 1,070 us, 9: 1,174, 12 (288 workgroups, a second round): 1,596, 16: 1,229;
+//   the exception, 96 workgroups, prefers 6 (221 us) to 2 (274 us) -- both far from the unsplit 360 us.
+// Rule: floor(CUs / workgroups) ranges, at least 3 chunks (384 elements) per range, at most 16.
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
     const vms_scan_fwd_params& p = q.f;
     if (p.seqlen % kBK != 0) return 1;
@@ -1165,16 +1205,9 @@ int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
     if (p.segments >= 1) {
         want = p.segments;
     } else {
-        // run time ~ rounds of workgroups over the CUs (one workgroup per CU) x range length, + ~25 % for the
-        // carry pass: take the count that minimises it, and split only for a clear win
         const int cus = device_cu_count();
-        const int most = n_c / 8 < 16 ? n_c / 8 : 16;
-        double best = 1.0 * ((n_wg + cus - 1) / cus);
-        want = 1;
-        for (int s = 2; s <= most; ++s) {
-            const double cost = 1.25 * ((n_wg * s + cus - 1) / cus) / s;
-            if (cost < 0.9 * best) { best = cost; want = s; }
-        }
+        want = cus / (n_wg > 0 ? n_wg : 1);
+        if (want > n_c / 3) want = n_c / 3;
     }
     if (want > 16) want = 16;
     if (want > n_c) want = n_c;
@@ -1233,6 +1266,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         return VMS_ERR_LAUNCH;
     }
     const bool rag = p.seqlen % kBK != 0;
+    const bool mixed = scan_bwd_pair_native_mixed(q);   // reverse_from: the host splits everything else into two problems
     int n_seg = 1;
     float2* carry = nullptr;
     if (p.workspace != nullptr && p.workspace_bytes >= scan_bwd_pair_ws_bytes(q)) {
@@ -1242,8 +1276,9 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     if (n_seg > 1) {
         dim3 cgrid(p.batch * tiles * (n_seg - 1));
 #define VMS_C(Z_, R_) hipLaunchKernelGGL((scan_bwd_carry_kernel<T, Z_, R_>), cgrid, block, 0, stream, q, n_seg, carry)
-        if (p.reverse) { if (p.z) VMS_C(true, true); else VMS_C(false, true); }
-        else { if (p.z) VMS_C(true, false); else VMS_C(false, false); }
+        if (mixed) { if (p.z) VMS_C(true, 2); else VMS_C(false, 2); }
+        else if (p.reverse) { if (p.z) VMS_C(true, 1); else VMS_C(false, 1); }
+        else { if (p.z) VMS_C(true, 0); else VMS_C(false, 0); }
 #undef VMS_C
         grid = dim3(p.batch * tiles * n_seg);
     }
@@ -1263,7 +1298,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
             if (e == hipSuccess)                                                                                         \
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_kernel<T, Z_, R_, WK>),             \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
-            VMS_A4(true, true); VMS_A4(true, false); VMS_A4(false, true); VMS_A4(false, false);
+            VMS_A4(true, 0); VMS_A4(true, 1); VMS_A4(true, 2); VMS_A4(false, 0); VMS_A4(false, 1); VMS_A4(false, 2);
 #undef VMS_A4
             return e;
         });
@@ -1276,14 +1311,17 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q, 1, carry); \
-        else if (four) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK>), grid4, block4, smem4, stream, q, n_seg, carry); \
+        else if (four) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_ ? 1 : 0, WK>), grid4, block4, smem4, stream, q, n_seg, carry); \
         else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q, n_seg, carry); \
     } while (0)
-    if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
+    if (mixed) {
+        if (p.z) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, true, 2, WK>), grid4, block4, smem4, stream, q, n_seg, carry);
+        else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, false, 2, WK>), grid4, block4, smem4, stream, q, n_seg, carry);
+    } else if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
-    set_last_kernel(rag ? "scan_bwd_pair_ragged"
+    set_last_kernel(mixed ? (n_seg > 1 ? "scan_bwd_pair4+mixed+split" : "scan_bwd_pair4+mixed") : rag ? "scan_bwd_pair_ragged"
                         : four ? (n_seg > 1 ? "scan_bwd_pair4+split" : "scan_bwd_pair4")
                                : (n_seg > 1 ? "scan_bwd_pair+split" : "scan_bwd_pair"));
     return VMS_OK;

@@ -253,7 +253,12 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
         VMS_CHECK(p.x_has_sub != 2, "reverse_from is not available with the rows layout");
-        if (p.reverse_from < p.batch) return scan_fwd_mixed(p, stream);
+        if (p.reverse_from < p.batch) {
+            // one launch when the paired LDS kernel takes the problem as it is; otherwise the two sub-batches as two problems
+            const bool native = scan_impl_level(p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, scan_fwd_vec_ok(p)) &&
+                                scan_fwd_pair_native_mixed(p);
+            if (!native) return scan_fwd_mixed(p, stream);
+        }
     }
     VMS_CHECK(p.out && p.x, "out and x must be provided by the caller");
     VMS_CHECK((p.z == nullptr) == (p.out_z == nullptr), "out_z must be given iff z is given");
@@ -293,6 +298,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
     if (p->reverse_from > 0 && p->reverse_from < p->batch) {
+        if (scan_impl_level(*p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_native_mixed(*p)) return 0;
         vms_scan_fwd_params lo, hi;
         scan_fwd_sub_batches(*p, lo, hi);
         const int64_t wl = vms_scan_fwd_workspace_bytes(&lo), wh = vms_scan_fwd_workspace_bytes(&hi);

@@ -321,8 +321,7 @@ struct Raw8 {
 };
 
 template <typename T, bool HZ, bool REV>
-__global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
-                                                                        const float2* __restrict__ seg_carry) {
+__device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, const int n_seg, const float2* __restrict__ seg_carry) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kPK, N = kPN, CS = kWave * K;
     const int lane = threadIdx.x & 63;
@@ -509,6 +508,22 @@ __global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_s
 }
 
 
+// RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from: entries >= p.reverse_from run
+// right-to-left).  A workgroup serves one batch entry, so the direction is workgroup-uniform: one branch, both bodies.
+template <typename T, bool HZ, int RM>
+__global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
+                                                                        const float2* __restrict__ seg_carry) {
+    if constexpr (RM == 2) {
+        const int wg_per_seg = gridDim.x / n_seg;
+        const int b = (int)(blockIdx.x % wg_per_seg) % p.batch;
+        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true>(p, n_seg, seg_carry);
+        else scan_fwd_lds_body<T, HZ, false>(p, n_seg, seg_carry);
+    } else {
+        scan_fwd_lds_body<T, HZ, RM == 1>(p, n_seg, seg_carry);
+    }
+}
+
+
 // ---- state carries of a sequence-split forward --------------------------------------------------------------------
 // (P, q) per (row, state) and range of chunks: the state leaving the range is P x_in + q, P = exp2(A sum(delta)),
 // q = the recurrence run from x = 0.  The forward kernel without its C / y / z half (~60 % of its work).
@@ -636,6 +651,15 @@ bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec) {
     return true;
 }
 
+// reverse_from served by ONE launch: whole-vector rows whose workgroups share a B / C group (the LDS kernel), no sequence split
+bool scan_fwd_pair_native_mixed(const vms_scan_fwd_params& p) {
+    if (!(p.reverse_from > 0 && p.reverse_from < p.batch) || p.reverse) return false;
+    if (p.seqlen % kPK != 0 || (p.dim / p.n_groups) % kLW != 0 || p.x_has_sub == 2) return false;
+    vms_scan_fwd_params t = p;
+    t.reverse_from = 0;
+    return scan_fwd_pair_segments(t) <= 1;
+}
+
 template <typename T>
 static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     const int tiles = (p.dim + kPRows - 1) / kPRows;
@@ -658,20 +682,24 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
 #else
     const bool lds_ok = !rag && (p.dim / p.n_groups) % kLW == 0;   // a workgroup's rows share one B / C group
 #endif
+    const bool mixed = p.reverse_from > 0 && p.reverse_from < p.batch;
     const size_t smem_l = sizeof(float) * 2 * kLGroupFloats;        // 64 KB
     const dim3 grid_l(p.batch * ((p.dim + kLW - 1) / kLW) * n_seg), block_l(kLW * kWave);
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p, 1, carry); \
-        else if (lds_ok) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_>), grid_l, block_l, smem_l, stream, p, n_seg, carry); \
+        else if (lds_ok) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_ ? 1 : 0>), grid_l, block_l, smem_l, stream, p, n_seg, carry); \
         else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p, n_seg, carry); \
     } while (0)
-    if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
+    if (mixed) {   // reverse_from: only the LDS kernel, unsplit (scan_fwd_pair_native_mixed); everything else is split by the host
+        if (p.z) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, true, 2>), grid_l, block_l, smem_l, stream, p, 1, carry);
+        else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, false, 2>), grid_l, block_l, smem_l, stream, p, 1, carry);
+    } else if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
     VMS_LAUNCH_CHECK();
     // distinct names per kernel: a shape that silently falls off the LDS kernel must be visible to callers and tests
-    set_last_kernel(rag ? "scan_fwd_pair_ragged"
+    set_last_kernel(mixed ? "scan_fwd_pair_lds+mixed" : rag ? "scan_fwd_pair_ragged"
                         : lds_ok ? (n_seg > 1 ? "scan_fwd_pair_lds+split" : "scan_fwd_pair_lds")
                                  : (n_seg > 1 ? "scan_fwd_pair+split" : "scan_fwd_pair"));
     return VMS_OK;

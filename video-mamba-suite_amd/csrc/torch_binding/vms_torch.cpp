@@ -457,8 +457,9 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
 std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w,
                             const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
                             const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
-                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from) {
+                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32) {
     c10::DeviceGuard guard(xz.device());
+    const auto wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
     const int64_t b = xz.size(0), d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
     const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
     const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
@@ -478,9 +479,9 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
     Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
     dx_dbl.narrow(1, R, N).copy_(g[3]->squeeze(1));
     dx_dbl.narrow(1, R + N, N).copy_(g[4]->squeeze(1));
-    Tensor ddt_proj_w = at::matmul(ddelta, x_dbl.narrow(1, 0, R).transpose(1, 2)).sum(0);  // (d, R)
+    Tensor ddt_proj_w = at::sum(at::matmul(ddelta, x_dbl.narrow(1, 0, R).transpose(1, 2)), {0}, false, wdt);  // (d, R)
     dx_dbl.narrow(1, 0, R).copy_(at::matmul(dt_proj_w.t(), ddelta));                        // (b, R, l)
-    Tensor dx_proj_w = at::matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0);                // (R + 2N, d)
+    Tensor dx_proj_w = at::sum(at::matmul(dx_dbl, conv_out.transpose(1, 2)), {0}, false, wdt);               // (R + 2N, d)
     dconv_out.baddbmm_(x_proj_w.t().expand({b, -1, -1}), dx_dbl);                           // + W_x^T dx_dbl, in place
     std::vector<OptT> c = conv_bwd(x, conv_w, conv_b, dconv_out, dx, true, reverse, zeros.narrow(0, n_scan, n_conv), acc, reverse_from);
     return {dxz, c[1], c[2], dx_proj_w, ddt_proj_w, g[2], g[5], g[6]};

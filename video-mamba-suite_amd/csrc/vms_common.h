@@ -240,6 +240,8 @@ struct PerDeviceOnce {
 };
 // reverse_from (vms_hip.h, ABI v5): the problem as its left-to-right and right-to-left sub-batches (selective_scan_fwd.hip)
 void scan_fwd_sub_batches(const vms_scan_fwd_params& p, vms_scan_fwd_params& lo, vms_scan_fwd_params& hi);
+bool scan_fwd_pair_native_mixed(const vms_scan_fwd_params& p);   // selective_scan_fwd_pair.hip: reverse_from in one launch
+bool scan_bwd_pair_native_mixed(const vms_scan_bwd_params& q);   // selective_scan_bwd_pair.hip
 // scan kernel generation a call may use (vms_hip.h vms_scan_impl): AUTO = PAIR; FAST / ROWS only when built in
 inline int scan_impl_level(const vms_scan_fwd_params& p) { return p.impl == VMS_IMPL_AUTO ? VMS_IMPL_PAIR : p.impl; }
 #ifdef VMS_EXPERIMENTAL

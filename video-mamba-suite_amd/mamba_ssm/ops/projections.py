@@ -85,6 +85,7 @@ class InProjFn(torch.autograd.Function):
             xz = prod.view(channels, batch, seqlen).permute(1, 0, 2)
         ctx.save_for_backward(hidden, wt)
         ctx.transposed = hidden.is_cuda
+        ctx.w_dtype = weight.dtype   # the K-split partial sums are added in the PARAMETER's dtype: no cast kernel in autograd
         ctx.stack_halves = stack_halves
         ctx.has_bias = bias is not None
         return xz
@@ -110,7 +111,8 @@ class InProjFn(torch.autograd.Function):
                 dhidden = (g2.t() @ w).view(batch, seqlen, d_model)
         if ctx.needs_input_grad[1]:
             s = _k_splits(rows)
-            dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)).sum(0))
+            dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model))
+                              .sum(0, dtype=ctx.w_dtype))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = unstack(g2.sum(dim=1))
         return dhidden, dweight, dbias, None
@@ -129,6 +131,7 @@ class OutProjFn(torch.autograd.Function):
     def forward(ctx, y, weight, bias, stacked_halves=False):
         ctx.has_bias = bias is not None
         ctx.stacked_halves = stacked_halves
+        ctx.w_dtype = weight.dtype
         if not stacked_halves:
             ctx.save_for_backward(y, weight)
             return F.linear(y.transpose(1, 2), weight, bias)
@@ -156,7 +159,7 @@ class OutProjFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dy = torch.matmul(weight.t(), dout.transpose(1, 2))  # (B, C, L): the layout the scan backward reads
             if ctx.needs_input_grad[1]:
-                dweight = torch.bmm(y, dout).sum(0).t()              # one K slice per batch entry
+                dweight = torch.bmm(y, dout).sum(0, dtype=ctx.w_dtype).t()   # one K slice per batch entry, summed in the parameter's dtype
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 dbias = dout.sum(dim=(0, 1))
             return dy, dweight, dbias, None
@@ -169,7 +172,7 @@ class OutProjFn(torch.autograd.Function):
             dy2 = torch.matmul(wp.t(), dout.reshape(batch * seqlen, d_model).t())        # (C, B L), rows [c][half]
             dy = dy2.view(half_c, 2 * batch, seqlen).permute(1, 0, 2)                      # (2 B, C / 2, L), the scan's layout
         if ctx.needs_input_grad[1]:
-            dwp = torch.bmm(y2.view(2 * half_c, batch, seqlen).permute(1, 0, 2), dout).sum(0).t()   # (d_model, C) permuted
+            dwp = torch.bmm(y2.view(2 * half_c, batch, seqlen).permute(1, 0, 2), dout).sum(0, dtype=ctx.w_dtype).t()   # (d_model, C) permuted
             dweight = dwp.view(d_model, half_c, 2).transpose(1, 2).reshape(d_model, 2 * half_c)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dout.sum(dim=(0, 1))

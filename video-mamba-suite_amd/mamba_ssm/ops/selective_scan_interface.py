@@ -253,6 +253,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     is_complex = A.is_complex()
     d_state = A.shape[-1] * (2 if is_complex else 1)
     out_w = out_bias = None
+    # the weight gradients' partial sums over the batch are added in the PARAMETERS' dtype (fp32 under autocast): autograd
+    # then has nothing to cast
+    ctx.w_dtype = x_proj_weight.dtype
     if out_proj is not None:
         x_proj_weight, delta_proj_weight, out_w, out_bias = _autocast_weights(
             x_proj_weight, delta_proj_weight, out_proj[0], out_proj[1])
@@ -350,7 +353,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
         dxz, dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = _inner_ext_module().inner_bwd(
             dout, xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out,
             bool(ctx.delta_softplus), ctx.reverse, dxz_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_BWD_SEGMENTS"),
-            getattr(ctx, "reverse_from", 0))
+            getattr(ctx, "reverse_from", 0), ctx.w_dtype == torch.float32)
         return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b, dx_proj_weight=dx_proj_weight,
                     ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=None, dout_proj_bias=None, dA=dA, dA_b=None,
                     dB=None, dC=None, dD=dD, ddelta_bias=ddelta_bias, dB_proj_bias=None, dC_proj_bias=None)
@@ -413,9 +416,9 @@ def _inner_backward(ctx, dout, dxz_into=None):
             dC_proj_bias = dC2.sum(dim=(0, 2))
         dx_dbl[:, nx - d_state:] = dC2
         dC = None
-    ddelta_proj_weight = torch.matmul(ddelta, x_dbl[:, :R].transpose(1, 2)).sum(0)      # (d, R)
+    ddelta_proj_weight = torch.matmul(ddelta, x_dbl[:, :R].transpose(1, 2)).sum(0, dtype=ctx.w_dtype)      # (d, R)
     dx_dbl[:, :R] = torch.matmul(delta_proj_weight.t(), ddelta)                          # (b, R, l)
-    dx_proj_weight = torch.matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0)              # (R+2N, d)
+    dx_proj_weight = torch.matmul(dx_dbl, conv_out.transpose(1, 2)).sum(0, dtype=ctx.w_dtype)              # (R+2N, d)
     # in place: dconv_out is this node's own buffer (the scan's du); out-of-place baddbmm copies it first
     dconv_out.baddbmm_(x_proj_weight.t().expand(batch, -1, -1), dx_dbl)                 # + W_x^T dx_dbl
     _, dconv_w, dconv_b = causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv_out, dx, True, ctx.reverse,
