@@ -1549,6 +1549,45 @@ def test_norm_shapes_vs_oracle(oracle, N, itype, is_rms, mode):
     check(got["dbias"], ob["db"], tol * 5, "dbias")
 
 
+@pytest.mark.parametrize("pair", [(torch.float32, torch.bfloat16), (torch.float32, torch.float16),
+                                  (torch.float16, torch.bfloat16), (torch.bfloat16, torch.float16)])
+@pytest.mark.parametrize("N", [64, 1000, 1024, 5000])
+@pytest.mark.parametrize("is_rms", [False, True])
+@pytest.mark.parametrize("prenorm", [False, True])
+def test_norm_any_residual_dtype(oracle, pair, N, is_rms, prenorm):
+    """The residual stream in a dtype that is neither x's nor fp32 (the reference's Triton kernels take any pair,
+    layernorm.py:122-173): y in x's dtype, the pre-norm sum and dresidual in the residual's."""
+    import mamba_ssm.ops.triton.layernorm as lnm
+    itype, rtype = pair
+    torch.manual_seed(N + 1)
+    rows = 37 if N >= 2048 else 700
+    x, res = G(torch.randn(rows, N).numpy(), itype, True), G(torch.randn(rows, N).numpy(), rtype, True)
+    w, b = G((1 + 0.5 * torch.randn(N)).numpy(), grad=True), G((0.5 * torch.randn(N)).numpy(), grad=True)
+    gy, gpre = torch.randn(rows, N), torch.randn(rows, N)
+    fn = lnm.rms_norm_fn if is_rms else lnm.layer_norm_fn
+    out = fn(x, w, b, residual=res, eps=1e-5, prenorm=prenorm)
+    y, pre = out if prenorm else (out, None)
+    assert y.dtype == itype and (pre is None or pre.dtype == rtype)
+    loss = (y.float() * G(gy.numpy())).sum()
+    if prenorm:
+        loss = loss + (pre.float() * G(gpre.numpy())).sum()
+    loss.backward()
+    assert x.grad.dtype == itype and res.grad.dtype == rtype
+    f = lambda t: None if t is None else t.detach().float().cpu().numpy()
+    o = oracle.norm_fwd(f(x), f(w), f(b), f(res), 1e-5, is_rms, prec="f64")
+    ob = oracle.norm_bwd(o["res_out"], f(w), o["mean"], o["rstd"], gy.numpy(), gpre.numpy() if prenorm else None, is_rms,
+                         prec="f64")
+    # the kernel normalises the unrounded fp32 sum but the backward re-reads the stored (rounded) one
+    tol = max(TOL[itype], TOL[rtype])
+    check(y, o["y"], TOL[itype], "y")
+    if pre is not None:
+        check(pre, o["res_out"], TOL[rtype], "prenorm sum")
+    check(x.grad, ob["ds"], tol * 2, "dx")
+    check(res.grad, ob["ds"], tol * 2, "dresidual")
+    check(w.grad, ob["dw"], tol * 5, "dweight")
+    check(b.grad, ob["db"], tol * 5, "dbias")
+
+
 def test_norm_extension_errors():
     import layer_norm_cuda
     x = torch.randn(4, 64, device=DEV)

@@ -284,7 +284,7 @@ static int norm_grid(int64_t rows) {
 
 static int validate_norm(const vms_norm_params& p) {
     VMS_CHECK(p.x_dtype == VMS_F32 || p.x_dtype == VMS_F16 || p.x_dtype == VMS_BF16, "x dtype must be fp32/fp16/bf16");
-    VMS_CHECK(p.res_dtype == p.x_dtype || p.res_dtype == VMS_F32, "residual dtype must be the input dtype or fp32");
+    VMS_CHECK(p.res_dtype == VMS_F32 || p.res_dtype == VMS_F16 || p.res_dtype == VMS_BF16, "residual dtype must be fp32/fp16/bf16");
     VMS_CHECK(p.rows > 0 && p.cols > 0, "empty problem");
     VMS_CHECK(p.weight != nullptr && p.rstd != nullptr, "weight and rstd are required");
     return VMS_OK;
@@ -327,18 +327,25 @@ static int norm_bwd_launch(const vms_norm_bwd_params& q, bool vec, hipStream_t s
     return VMS_OK;
 }
 
+// The residual stream (residual in / residual_out, and in backward s / dres_out / dres_in) may have any of the three dtypes
+// whatever x's is, as in the reference's Triton kernels (ops/triton/layernorm.py:122-173).  The pairs the suite uses -- the
+// stream in x's dtype, or in fp32 (residual_in_fp32) -- run on the register-resident vector kernels; the remaining pairs
+// (fp32 x with a 16-bit stream, fp16 x with a bf16 stream and the reverse) on the element-wise kernels.
+#define VMS_NORM_TS(FN, TX_, vec, s)                                                                          \
+    switch (ts_) {                                                                                            \
+        case VMS_F32: return rms_ ? FN<TX_, float, true>(q_, vec && fast_, s) : FN<TX_, float, false>(q_, vec && fast_, s);   \
+        case VMS_F16: return rms_ ? FN<TX_, f16_t, true>(q_, vec && fast_, s) : FN<TX_, f16_t, false>(q_, vec && fast_, s);   \
+        default: return rms_ ? FN<TX_, bf16_t, true>(q_, vec && fast_, s) : FN<TX_, bf16_t, false>(q_, vec && fast_, s);      \
+    }
 #define VMS_NORM_DISPATCH(FN, ARG, vec, s)                                                                    \
     do {                                                                                                      \
-        const bool wide = (ARG).res_dtype == VMS_F32 && (ARG).x_dtype != VMS_F32;                              \
-        const bool rms = (ARG).is_rms != 0;                                                                    \
+        const int ts_ = (ARG).res_dtype;                                                                       \
+        const bool fast_ = ts_ == (ARG).x_dtype || ts_ == VMS_F32;   /* pairs the vector kernels are written for */ \
+        const bool rms_ = (ARG).is_rms != 0;                                                                   \
         switch ((ARG).x_dtype) {                                                                               \
-            case VMS_F32: return rms ? FN<float, float, true>(q_, vec, s) : FN<float, float, false>(q_, vec, s); \
-            case VMS_F16:                                                                                      \
-                if (wide) return rms ? FN<f16_t, float, true>(q_, vec, s) : FN<f16_t, float, false>(q_, vec, s); \
-                return rms ? FN<f16_t, f16_t, true>(q_, vec, s) : FN<f16_t, f16_t, false>(q_, vec, s);         \
-            default:                                                                                           \
-                if (wide) return rms ? FN<bf16_t, float, true>(q_, vec, s) : FN<bf16_t, float, false>(q_, vec, s); \
-                return rms ? FN<bf16_t, bf16_t, true>(q_, vec, s) : FN<bf16_t, bf16_t, false>(q_, vec, s);     \
+            case VMS_F32: VMS_NORM_TS(FN, float, vec, s)                                                       \
+            case VMS_F16: VMS_NORM_TS(FN, f16_t, vec, s)                                                       \
+            default: VMS_NORM_TS(FN, bf16_t, vec, s)                                                           \
         }                                                                                                      \
     } while (0)
 

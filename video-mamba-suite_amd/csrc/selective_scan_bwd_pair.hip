@@ -568,12 +568,8 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 //     softplus derivative sigmoid(delta_raw) is carried from the prologue (8 registers; round 3), u is
 //     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
 //     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
-#ifndef VMS_BWD_SG
-#define VMS_BWD_SG 2
-#endif
 template <int W> struct B4 {
-    // states between two workgroup barriers (= states per slab buffer): 2, or 4 for W = 8 in -DVMS_BWD_SG=4 builds
-    static constexpr int kSG = (W == 8 && VMS_BWD_SG == 4) ? 4 : 2;
+    static constexpr int kSG = 2;   // states between two workgroup barriers (= states per slab buffer)
     static constexpr int kPair = kSG * W * 4 * kWave;   // floats of one group of states: [state][wave][4 lane + k]
     static constexpr int kRows = 4 * W;
     static constexpr int kPPT = 8 / W;                 // B / C pieces and slab outputs per thread (512 per chunk / pair)
@@ -624,12 +620,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
 
     float dAacc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
-#ifdef VMS_BWD_PROF   // in-kernel phase timers (tools/prof_once.py): s_memtime around the phases of a state
-    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = 0;
-#define VMS_TICK2(i) do { unsigned long long tn_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn_) :: "memory"); tacc[i] += tn_ - tprev; tprev = tn_; } while (0)
-#else
-#define VMS_TICK2(i) do {} while (0)
-#endif
 
     // B / C staging of the NEXT chunk: piece (tensor, state, j) = 8 values of one state; a thread owns PPT pieces
     RawB<T, REV> stg[PPT];
@@ -667,18 +657,11 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     // covers 256 contiguous bytes (every atomic leaves the XCD's L2 as its own fabric request: with 16-byte runs
     // 32 bytes apart the same sums cost twice the requests -- profiles/r02_traffic_atomics.md).  Position u & 127 =
     // 8 jj + 4 rho0 + k lives in float 4 (16 (2 tensor + rho0) + jj) + k of a wave's partials; the two rho0 of a
-    // wave's read share LDS banks (2-way conflict on 8 ds_read_b32 per pair: nothing).  VMS_BWD_RD_SLABORDER: the
-    // earlier thread t <-> float t mapping, for A/B measurements.
+    // wave's read share LDS banks (2-way conflict on 8 ds_read_b32 per pair: nothing).
     const int rd_par0 = (int)threadIdx.x >> 8;
-#ifdef VMS_BWD_RD_SLABORDER
-    const int rd_f = threadIdx.x & 255;
-    const int rd_rho = rd_f >> 6, rd_ten = rd_rho >> 1;
-    const int rd_pos = 8 * ((rd_f >> 2) & 15) + 4 * (rd_rho & 1) + (rd_f & 3);
-#else
     const int rd_u = threadIdx.x & 255;
     const int rd_ten = rd_u >> 7, rd_pos = rd_u & 127;
     const int rd_f = 4 * (16 * (2 * rd_ten + ((rd_pos >> 2) & 1)) + (rd_pos >> 3)) + (rd_pos & 3);
-#endif
     const lds_f32* const rd_src = slab1 + rd_f;
     float* const rd_dst = rd_ten ? dCg : dBg;
     const int64_t rd_stride = rd_ten ? q.dC_dstate_stride : q.dB_dstate_stride;
@@ -802,20 +785,13 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             constexpr int SG = B4<W>::kSG;
             const int par = i4 & 1, buf = SG == 4 ? (n >> 2) & 1 : (i4 >> 1) & 1;
             const int st = SG == 4 ? i4 : par;   // state inside its slab group
-            VMS_TICK2(0);   // since the previous tick: barrier exit / chunk prologue + epilogue
-#ifndef VMS_BWD_NO_ALTPRIO
             // waves w and w + 4 share a SIMD, and between equal priorities the older wave wins every issue slot: it would
             // reach each barrier first and wait while its partner runs alone at the single-wave issue rate.  Taking turns
             // (one state each) brings both to the barrier together.
             if (W == 8) {
-#if defined(VMS_BWD_PRIO_YOUNG)      // A/B: static priority for the second-dispatched half (waves 4-7)
-                if (i4 == 0 && n == 0) { if (quad >> 2) __builtin_amdgcn_s_setprio(VMS_BWD_PRIO_YOUNG); }
-#else
                 if ((par ^ (quad >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
-#endif
             }
-#endif
             // fp32 B / C of this state, shared by the workgroup's 32 rows
             const lds_f4* bsrc = bc4 + (n * CH) / 4 + j;
             const f32x4 b0 = bsrc[0], b1 = bsrc[16], c0 = bsrc[N * CH / 4], c1 = bsrc[N * CH / 4 + 16];
@@ -846,27 +822,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                 xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
                 c2[k] = (k == 0 ? f2{c0.x, c0.y} : k == 1 ? f2{c0.z, c0.w} : k == 2 ? f2{c1.x, c1.y} : f2{c1.z, c1.w}) * dy2[k];
             }
-#ifdef VMS_ABL_SEEDS
-            // ablation: forward seeds as if they came from memory (no lane-aggregate chain, no forward half of the row scan)
-            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);
-            float rg = 0.f;
-#pragma unroll
-            for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
-            float ra = fast_exp2((sdl - dl_first) * An) * a_right;
-            rg = fmaf(ra, is_last ? gin : 0.f, rg);
-            asm volatile("s_nop 1\n\t"
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 1"
-                         : "+v"(rg), "+v"(ra));
-            const float xseed = hin * a_right;   // stands for a loaded value
-            float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
-#else
             float px = 0.f;
 #pragma unroll
             for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
@@ -878,12 +833,9 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             float ra = fast_exp2((sdl - dl_first) * An) * a_right;
             px = fmaf(pa, is_first ? hin : 0.f, px);
             rg = fmaf(ra, is_last ? gin : 0.f, rg);
-            VMS_TICK2(1);   // LDS reads, exps, aggregates
             row_scan_pair_b(pa, px, ra, rg);
-            VMS_TICK2(2);   // row scan
             const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);
             float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
-#endif
             if (is_first) *(lds_f2*)(rec1 + 4 * n + 2) = f2{a2[0].x, rg};
             {
                 float xrun = xseed;
@@ -915,7 +867,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             }
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
-            VMS_TICK2(3);   // seeded chains, gradient core, dA
             // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
             asm volatile("s_nop 1\n\t"
                          "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
@@ -940,26 +891,18 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                 __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
             {
                 const float tsum = (rdv[0] + rdv[1]) + (rdv[2] + rdv[3]);
-#ifdef VMS_ABL_NOATOM
-                racc += tsum;
-#else
                 if (W == 8) {
                     racc = par == 0 ? tsum : racc + tsum;
                     if (par == 1 && rd_okp) atomicAdd(rd_ptr + (rd_par0 + (SG == 4 ? 2 * (i4 >> 1) : 0)) * rd_stride, racc);
                 } else if (rd_okp) {
                     atomicAdd(rd_ptr + par * rd_stride, tsum);
                 }
-#endif
             }
-            VMS_TICK2(4);   // swaps, slab write, partial sums, atomic
             if (st == SG - 1) {
                 // the group just written is summed during the next one
                 rd_ptr = rd_dst_c + (int64_t)(n - (SG - 1)) * rd_stride;
                 rd_okp = rd_lo < L;
-#ifndef VMS_ABL_NOBAR
                 lds_barrier_b();  // pair written by all waves; previous pair's buffer free again
-#endif
-                VMS_TICK2(5);   // barrier
             }
         };
 #pragma unroll 1
@@ -1012,11 +955,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             atomicAdd(rd_ptr + par * rd_stride, tsum);
         }
     }
-#ifdef VMS_BWD_PROF
-    if ((blockIdx.x == 3 || blockIdx.x == 200) && lane == 0)
-        printf("wg %d wave %d: lds+exp+aggr %llu  scan %llu  chains+core %llu  swaps+slab %llu  barrier %llu\n", (int)blockIdx.x, quad,
-               tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
-#endif
     const float dD_tot = row_allsum_b(dD_acc), db_tot = row_allsum_b(dbias_acc);
     if (row_ok) {
         if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
@@ -1283,12 +1221,8 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         grid = dim3(p.batch * tiles * n_seg);
     }
     // whole-vector rows run on the second generation (scan_bwd_pair4_kernel, W waves per workgroup)
-#ifndef VMS_BWD_W
-#define VMS_BWD_W 8
-#endif
-    constexpr int W4 = VMS_BWD_W;             // A/B builds: 0 = the first generation for every problem, 4 or 8
-    constexpr bool four = W4 != 0;
-    constexpr int WK = four ? W4 : 4;
+    constexpr bool four = true;   // whole-vector rows: second generation, 8 waves (32 rows) per workgroup
+    constexpr int WK = 8;
     const size_t smem4 = B4<WK>::kSmem;
     if (four && smem4 > 64 * 1024) {   // 4-state slab groups: 88 KB
         static PerDeviceOnce attr4_once;
