@@ -21,6 +21,8 @@
  *        mamba/mamba_ssm/ops/triton/selective_state_update.py:16-154
  *   vms_layer_norm_fwd / _bwd <- the Triton kernels of mamba_ssm.ops.triton.layernorm
  *        mamba/mamba_ssm/ops/triton/layernorm.py:51-377
+ *   vms_proj_apply / vms_proj_wgrad <- the small x_proj / dt_proj GEMMs MambaInnerFn runs through torch
+ *        mamba/mamba_ssm/ops/selective_scan_interface.py:182, 275-279
  *
  * Conventions
  *   - plain C: POD parameter blocks, raw device pointers, sizes; no torch types.
@@ -50,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 5
+#define VMS_ABI_VERSION 6
 
 typedef enum {
     VMS_OK = 0,
@@ -279,6 +281,50 @@ typedef struct {
 
 int vms_selective_state_update(const vms_state_update_params *p, void *stream);
 
+/* ---- small projections of the inner node (ABI v6) ------------------------------------------------------
+ * The skinny GEMMs between conv1d and the scan in MambaInnerFn(NoOutProj)
+ * (mamba/mamba_ssm/ops/selective_scan_interface.py): forward
+ *     delta = delta_proj_weight @ x_dbl[:R]                                  (:182)
+ * backward
+ *     ddelta_proj_weight = einsum("dB,Br->dr", ddelta, x_dbl[:, :R])         (:275)
+ *     dx_dbl[:, :R]      = einsum("dB,dr->Br", ddelta, delta_proj_weight)    (:276)
+ *     dx_proj_weight     = einsum("Br,Bd->rd", dx_dbl, conv1d_out)           (:278)
+ *     dconv1d_out        = addmm(dconv1d_out, x_proj_weight.t(), dx_dbl.t()) (:279)
+ * on this build's (batch, rows, seqlen) activations with a unit seqlen stride.  16-bit activations (bf16 / fp16), fp32
+ * accumulation on the matrix cores; other dtypes / unaligned problems are left to the caller's library GEMM.
+ *
+ * vms_proj_apply:  out[b][d][l] (+)= sum_{r < k} w[d][r] * in[b][r][l]      d < rows, k <= 96
+ *   w: (rows, k) in `dtype`, any strides;  in: (batch, k, seqlen);  out: (batch, rows, seqlen);
+ *   accumulate != 0: out holds a value of `dtype` that the product is added to in fp32 before rounding (:279). */
+typedef struct {
+    int32_t batch, rows, k, seqlen;
+    int32_t dtype;            /* vms_dtype of w, in, out: VMS_BF16 or VMS_F16 */
+    int32_t accumulate;
+    int32_t tiles_per_wg;     /* 64-position tiles a workgroup walks; 0 = chosen from the CU count (a tuning knob, like `segments`) */
+    int32_t reserved;
+    const void *w, *in;
+    void *out;
+    int64_t w_row_stride, w_k_stride;
+    int64_t in_batch_stride, in_k_stride;          /* elements; multiples of 8 */
+    int64_t out_batch_stride, out_row_stride;
+} vms_proj_apply_params;
+
+/* vms_proj_wgrad:  dw[m][n] += sum_{b, l} p[b][m][l] * q[b][n][l]           m <= 128
+ *   p: (batch, m, seqlen), q: (batch, n, seqlen) in `dtype`; dw: (m, n) fp32, ADDED to with fp32 atomics (the caller
+ *   zero-fills it, like the scan's dA / dD), so several calls may accumulate into one buffer. */
+typedef struct {
+    int32_t batch, m, n, seqlen;
+    int32_t dtype;
+    int32_t tiles_per_wg;     /* 64-position tiles per workgroup (each workgroup ends with m x 128 atomics); 0 = automatic */
+    const void *p, *q;
+    float *dw;
+    int64_t p_batch_stride, p_row_stride, q_batch_stride, q_row_stride;   /* elements; multiples of 8 */
+    int64_t dw_row_stride;
+} vms_proj_wgrad_params;
+
+int vms_proj_apply(const vms_proj_apply_params *p, void *stream);
+int vms_proj_wgrad(const vms_proj_wgrad_params *p, void *stream);
+
 /* ---- misc ---------------------------------------------------------------------------- */
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
@@ -295,6 +341,8 @@ int vms_sizeof_conv_bwd_params(void);
 int vms_sizeof_norm_params(void);
 int vms_sizeof_norm_bwd_params(void);
 int vms_sizeof_state_update_params(void);
+int vms_sizeof_proj_apply_params(void);
+int vms_sizeof_proj_wgrad_params(void);
 
 #ifdef __cplusplus
 }

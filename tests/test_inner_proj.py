@@ -1,0 +1,151 @@
+"""The inner node's small projections on the matrix cores (csrc/inner_proj.hip, vms_hip.h vms_proj_apply / vms_proj_wgrad)
+against fp32 / fp64 matrix products of the same 16-bit inputs (the reference computes them with torch GEMMs,
+mamba_ssm/ops/selective_scan_interface.py:182, 275-279).  Tolerances: the product is accumulated in fp32 and rounded once
+to the 16-bit output (proj_apply) or kept in fp32 (proj_wgrad), so the bar is the output format's rounding."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _vms():
+    import vms_hip
+    return vms_hip
+
+
+# (batch, rows, k, seqlen): the block shapes of BASELINE configs (dt_proj: k = dt_rank; x_proj^T: k = dt_rank + 2 d_state),
+# ragged tiles (seqlen % 64, rows % 128, k % 16 != 0), one-tile and sub-tile problems
+APPLY_SHAPES = [(2, 256, 64, 1024), (8, 1024, 96, 8192), (2, 768, 48, 3136), (2, 768, 80, 3136), (2, 512, 32, 2304),
+                (1, 384, 24, 3152), (1, 384, 56, 3152), (3, 200, 17, 72), (2, 96, 96, 8), (1, 130, 5, 200)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", APPLY_SHAPES)
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_proj_apply_vs_matmul(shape, dtype, accumulate):
+    vms = _vms()
+    b, rows, k, L = shape
+    torch.manual_seed(rows + k)
+    w = (torch.randn(rows, k, device=DEV) * 0.2).to(dtype)
+    x = torch.randn(b, k, L, device=DEV).to(dtype)
+    out = torch.randn(b, rows, L, device=DEV).to(dtype)
+    want = w.double() @ x.double()
+    if accumulate:
+        want = want + out.double()
+    vms.proj_apply(w, x, out, accumulate)
+    assert vms.lib().vms_last_kernel().decode().startswith("proj_apply")
+    err = (out.double() - want).abs().max().item()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert err <= eps * want.abs().max().item() * 1.01 + 1e-6, f"max abs err {err:.3e}"
+
+
+def test_proj_apply_strided_views():
+    """in = the first rows of a wider (batch, R + 2N, L) tensor, w = the transposed view of x_proj's weight, out = one half of a
+    (batch, 2 d, L) buffer: exactly the views the inner node passes."""
+    vms = _vms()
+    torch.manual_seed(0)
+    b, d, R, N, L = 2, 256, 48, 16, 640
+    x_dbl = torch.randn(b, R + 2 * N, L, device=DEV).bfloat16()
+    w_dt = (torch.randn(d, R, device=DEV) * 0.2).bfloat16()
+    wide = torch.zeros(b, 2 * d, L, device=DEV, dtype=torch.bfloat16)
+    out = wide[:, d:, :]
+    vms.proj_apply(w_dt, x_dbl[:, :R, :], out, False)
+    want = w_dt.double() @ x_dbl[:, :R, :].double()
+    assert (out.double() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() * 1.01
+    assert wide[:, :d, :].abs().max().item() == 0.0
+    w_x = (torch.randn(R + 2 * N, d, device=DEV) * 0.2).bfloat16()     # x_proj.weight (R + 2N, d): w = its transpose, a view
+    g = torch.randn(b, d, L, device=DEV).bfloat16()
+    want = g.double() + w_x.t().double() @ x_dbl.double()
+    vms.proj_apply(w_x.t(), x_dbl, g, True)
+    assert (g.double() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() * 1.01
+
+
+WGRAD_SHAPES = [(2, 64, 256, 1024), (8, 96, 1024, 8192), (8, 64, 1024, 8192), (2, 48, 768, 3136), (2, 80, 768, 3136),
+                (2, 64, 512, 2304), (1, 24, 384, 3152), (1, 56, 384, 3152), (3, 17, 200, 72), (2, 128, 130, 136), (1, 5, 96, 8)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+def test_proj_wgrad_vs_matmul(shape, dtype):
+    vms = _vms()
+    b, m, n, L = shape
+    torch.manual_seed(m + n)
+    p = torch.randn(b, m, L, device=DEV).to(dtype)
+    q = torch.randn(b, n, L, device=DEV).to(dtype)
+    dw = torch.zeros(m, n, device=DEV)
+    vms.proj_wgrad(p, q, dw)
+    assert vms.lib().vms_last_kernel().decode() == "proj_wgrad"
+    want = torch.einsum("bml,bnl->mn", p.double(), q.double())
+    scale = (p.double().abs().unsqueeze(2) * q.double().abs().unsqueeze(1)).sum(dim=(0, 3)).max().item() if b * m * n * L < 2e8 else want.abs().max().item() * 30
+    err = (dw.double() - want).abs().max().item()
+    assert err <= 1e-5 * scale + 1e-6, f"max abs err {err:.3e} (sum of |products| {scale:.3e})"
+    vms.proj_wgrad(p, q, dw)      # the buffer is added to: a second call doubles it
+    assert (dw.double() - 2 * want).abs().max().item() <= 2e-5 * scale + 1e-6
+
+
+def test_proj_wgrad_strided_rows():
+    vms = _vms()
+    torch.manual_seed(1)
+    b, R, N, d, L = 2, 48, 16, 256, 640
+    x_dbl = torch.randn(b, R + 2 * N, L, device=DEV).bfloat16()
+    xz = torch.randn(b, 2 * d, L, device=DEV).bfloat16()
+    dw = torch.zeros(R, d, device=DEV)
+    vms.proj_wgrad(x_dbl[:, :R, :], xz[:, d:, :], dw)
+    want = torch.einsum("bml,bnl->mn", x_dbl[:, :R, :].double(), xz[:, d:, :].double())
+    assert (dw.double() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+
+
+def test_proj_checks():
+    vms = _vms()
+    w = torch.randn(64, 16, device=DEV).bfloat16()
+    x = torch.randn(1, 16, 64, device=DEV).bfloat16()
+    with pytest.raises(RuntimeError):   # fp32 is left to the library GEMM
+        vms.proj_apply(w.float(), x.float(), torch.empty(1, 64, 64, device=DEV), False)
+    with pytest.raises(RuntimeError):   # seqlen % 8
+        vms.proj_apply(w, x[:, :, :60].contiguous(), torch.empty(1, 64, 60, device=DEV, dtype=torch.bfloat16), False)
+    with pytest.raises(RuntimeError):   # k > 96
+        vms.proj_apply(torch.randn(64, 112, device=DEV).bfloat16(), torch.randn(1, 112, 64, device=DEV).bfloat16(),
+                       torch.empty(1, 64, 64, device=DEV, dtype=torch.bfloat16), False)
+
+
+@pytest.mark.parametrize("shape", [(2, 640, 256, 16), (2, 1024, 96, 8), (1, 2304, 512, 16)])
+def test_inner_node_mfma_projections_vs_library(shape, monkeypatch):
+    """The fused inner node (conv -> x_proj -> dt_proj -> scan, and its backward) with the small GEMMs on the hand-written
+    kernels (VMS_MFMA_PROJ=1) vs the default node (library GEMMs): outputs and every gradient within the bf16 bar."""
+    import vms_hip
+    from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn_no_out_proj
+    if vms_hip.ext() is None:
+        pytest.skip("compiled binding not built")
+    b, L, d, N = shape
+    R = (d + 15) // 16
+    torch.manual_seed(L)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device=DEV) * sc).requires_grad_()
+    xz0 = torch.randn(b, 2 * d, L, device=DEV).bfloat16()   # what in_proj hands the node under autocast
+    conv_w, conv_b = mk(d, 1, 4, sc=0.3), mk(d, sc=0.1)
+    x_proj_w, dt_proj_w = mk(R + 2 * N, d, sc=d ** -0.5), mk(d, R, sc=R ** -0.5)
+    A = (-torch.rand(d, N, device=DEV) - 0.2).requires_grad_()
+    D, bias = mk(d), mk(d, sc=0.3)
+    g = torch.randn(b, d, L, device=DEV)
+    params = (conv_w, conv_b, x_proj_w, dt_proj_w, A, D, bias)
+
+    def run(no_mfma):
+        if no_mfma:
+            monkeypatch.delenv("VMS_MFMA_PROJ", raising=False)
+        else:
+            monkeypatch.setenv("VMS_MFMA_PROJ", "1")
+        xz = xz0.clone().requires_grad_()
+        for t in params:
+            t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = mamba_inner_fn_no_out_proj(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, None, None, D, delta_bias=bias,
+                                             delta_softplus=True)
+        out.backward(g.to(out.dtype))
+        return [out.detach().float(), xz.grad.float()] + [t.grad.float().clone() for t in params]
+
+    got = run(False)
+    want = run(True)
+    names = ["out", "dxz", "dconv_w", "dconv_b", "dx_proj_w", "ddt_proj_w", "dA", "dD", "dbias"]
+    for n, a, w in zip(names, got, want):
+        err = (a - w).abs().max().item() / max(w.abs().max().item(), 1e-6)
+        assert err <= 2e-2, f"{n}: rel err {err:.3e} between the MFMA-projection node and the library-GEMM node"

@@ -433,10 +433,51 @@ PaddedBC pad_bc(const Tensor& B, const Tensor& C, bool reverse, bool both = fals
     return {at::constant_pad_nd(B, {0, pad}).narrow(-1, 0, L), at::constant_pad_nd(C, {0, pad}).narrow(-1, 0, L), pad};
 }
 
+// ---- the inner node's small projections on the matrix cores (vms_hip.h vms_proj_apply / vms_proj_wgrad) ----------------
+// Eligible: 16-bit tensors of one dtype, unit seqlen strides, seqlen and the row / batch strides multiples of 8 elements,
+// 16-byte aligned bases, k <= 96 (apply) / m <= 128 (wgrad).  Anything else stays with the library GEMM the caller had.
+bool proj_ok16(const Tensor& t) {
+    return t.is_cuda() && (t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf) && t.dim() == 3 && t.stride(2) == 1 &&
+           t.size(2) % 8 == 0 && t.stride(0) % 8 == 0 && t.stride(1) % 8 == 0 && (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0;
+}
+bool proj_apply_eligible(const Tensor& w, const Tensor& in, const Tensor& out) {
+    return proj_ok16(in) && proj_ok16(out) && w.is_cuda() && w.dim() == 2 && w.scalar_type() == in.scalar_type() &&
+           out.scalar_type() == in.scalar_type() && w.size(1) == in.size(1) && w.size(1) <= 96 && out.size(1) == w.size(0) &&
+           out.size(0) == in.size(0) && out.size(2) == in.size(2);
+}
+// out[b, d, l] (+)= sum_r w[d, r] in[b, r, l]
+void proj_apply(const Tensor& w, const Tensor& in, const Tensor& out, bool accumulate) {
+    vms_proj_apply_params P{};
+    P.batch = (int)in.size(0); P.rows = (int)w.size(0); P.k = (int)w.size(1); P.seqlen = (int)in.size(2);
+    P.dtype = dtype_code(in); P.accumulate = accumulate;
+    P.w = w.data_ptr(); P.in = in.data_ptr(); P.out = out.data_ptr();
+    P.w_row_stride = w.stride(0); P.w_k_stride = w.stride(1);
+    P.in_batch_stride = in.stride(0); P.in_k_stride = in.stride(1);
+    P.out_batch_stride = out.stride(0); P.out_row_stride = out.stride(1);
+    call("vms_proj_apply", vms_proj_apply, P, in);
+}
+bool proj_wgrad_eligible(const Tensor& p, const Tensor& q) {
+    return proj_ok16(p) && proj_ok16(q) && p.scalar_type() == q.scalar_type() && p.size(0) == q.size(0) && p.size(2) == q.size(2) &&
+           p.size(1) <= 128;
+}
+// dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw: fp32 (m, n), unit column stride, zero-filled by the caller
+void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw) {
+    TORCH_CHECK(dw.scalar_type() == at::kFloat && dw.dim() == 2 && dw.stride(1) == 1 && dw.size(0) == p.size(1) && dw.size(1) == q.size(1),
+                "proj_wgrad: dw must be a float32 (m, n) matrix with unit column stride");
+    vms_proj_wgrad_params P{};
+    P.batch = (int)p.size(0); P.m = (int)p.size(1); P.n = (int)q.size(1); P.seqlen = (int)p.size(2);
+    P.dtype = dtype_code(p);
+    P.p = p.data_ptr(); P.q = q.data_ptr(); P.dw = dw.data_ptr<float>();
+    P.p_batch_stride = p.stride(0); P.p_row_stride = p.stride(1);
+    P.q_batch_stride = q.stride(0); P.q_row_stride = q.stride(1);
+    P.dw_row_stride = dw.stride(0);
+    call("vms_proj_wgrad", vms_proj_wgrad, P, p);
+}
+
 // -> [out_z, conv_out, x_dbl, delta, ckpt, out]
 std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                               const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
-                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from) {
+                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, bool use_mfma_proj) {
     TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
     c10::DeviceGuard guard(xz.device());
     const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
@@ -445,7 +486,13 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
     Tensor conv_out = conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
     Tensor x_dbl = at::matmul(x_proj_w, conv_out);                       // (b, R + 2N, l): rows R.. are B, the last N are C
-    Tensor delta = at::matmul(dt_proj_w, x_dbl.narrow(1, 0, R));         // (b, d, l)
+    Tensor delta;                                                        // (b, d, l) = dt_proj_w @ x_dbl[:, :R]
+    {
+        const Tensor dt_in = x_dbl.narrow(1, 0, R);
+        delta = at::empty({x_dbl.size(0), d, x_dbl.size(2)}, x_dbl.options());
+        if (use_mfma_proj && proj_apply_eligible(dt_proj_w, dt_in, delta)) proj_apply(dt_proj_w, dt_in, delta, false);
+        else at::matmul_out(delta, dt_proj_w, dt_in);
+    }
     const PaddedBC bc = pad_bc(x_dbl.narrow(1, R, N).unsqueeze(1), x_dbl.narrow(1, R + N, N).unsqueeze(1), reverse, reverse_from > 0);
     std::vector<Tensor> r = scan_fwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, delta_softplus, reverse, out_z_into, bc.pad, impl, segments,
                                      reverse_from);
@@ -457,7 +504,8 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
 std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w,
                             const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
                             const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
-                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32) {
+                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32,
+                            bool use_mfma_proj) {
     c10::DeviceGuard guard(xz.device());
     const auto wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
     const int64_t b = xz.size(0), d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
@@ -470,7 +518,11 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
     // one zero fill for every fp32 atomics target of the node (scan: dA, dB, dC, dD, ddelta_bias; conv: dweight, dbias)
     const int64_t n_scan = A.numel() + 2 * Bv.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
     const int64_t n_conv = conv_w.numel() + (conv_b.has_value() ? conv_b->numel() : 0);
-    Tensor zeros = at::zeros({n_scan + n_conv}, xz.options().dtype(at::kFloat));
+    // the two small weight gradients on the matrix cores accumulate in fp32 into the same zero-filled buffer
+    const Tensor dt_in = x_dbl.narrow(1, 0, R);
+    const bool mfma_wg = use_mfma_proj && proj_wgrad_eligible(x_dbl, conv_out) && proj_wgrad_eligible(dt_in, delta);
+    const int64_t n_proj = mfma_wg ? (R + (R + 2 * N)) * d : 0;
+    Tensor zeros = at::zeros({n_scan + n_conv + n_proj}, xz.options().dtype(at::kFloat));
     const PaddedBC bc = pad_bc(Bv, Cv, reverse, reverse_from > 0);
     std::vector<OptT> g = scan_bwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, dout, ckpt, out, dz, delta_softplus,
                                    /*recompute_out_z=*/false, reverse, zeros.narrow(0, 0, n_scan), /*keep_fp32=*/true, acc, bc.pad, impl,
@@ -479,10 +531,24 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
     Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
     dx_dbl.narrow(1, R, N).copy_(g[3]->squeeze(1));
     dx_dbl.narrow(1, R + N, N).copy_(g[4]->squeeze(1));
-    Tensor ddt_proj_w = at::sum(at::matmul(ddelta, x_dbl.narrow(1, 0, R).transpose(1, 2)), {0}, false, wdt);  // (d, R)
+    Tensor ddt_proj_w, dx_proj_w;
+    if (mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
+        Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({R, d});                  // (R, d) = ddt_proj_w^T
+        proj_wgrad(dt_in, ddelta, dw1);
+        ddt_proj_w = dw1.t().to(wdt);                                                       // (d, R)
+    } else {
+        ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
+    }
     dx_dbl.narrow(1, 0, R).copy_(at::matmul(dt_proj_w.t(), ddelta));                        // (b, R, l)
-    Tensor dx_proj_w = at::sum(at::matmul(dx_dbl, conv_out.transpose(1, 2)), {0}, false, wdt);               // (R + 2N, d)
-    dconv_out.baddbmm_(x_proj_w.t().expand({b, -1, -1}), dx_dbl);                           // + W_x^T dx_dbl, in place
+    if (mfma_wg && proj_wgrad_eligible(dx_dbl, conv_out)) {
+        Tensor dw2 = zeros.narrow(0, n_scan + n_conv + R * d, (R + 2 * N) * d).view({R + 2 * N, d});
+        proj_wgrad(dx_dbl, conv_out, dw2);
+        dx_proj_w = dw2.to(wdt);                                                            // (R + 2N, d)
+    } else {
+        dx_proj_w = at::sum(at::matmul(dx_dbl, conv_out.transpose(1, 2)), {0}, false, wdt);
+    }
+    if (use_mfma_proj && proj_apply_eligible(x_proj_w.t(), dx_dbl, dconv_out)) proj_apply(x_proj_w.t(), dx_dbl, dconv_out, true);
+    else dconv_out.baddbmm_(x_proj_w.t().expand({b, -1, -1}), dx_dbl);                      // + W_x^T dx_dbl, in place
     std::vector<OptT> c = conv_bwd(x, conv_w, conv_b, dconv_out, dx, true, reverse, zeros.narrow(0, n_scan, n_conv), acc, reverse_from);
     return {dxz, c[1], c[2], dx_proj_w, ddt_proj_w, g[2], g[5], g[6]};
 }

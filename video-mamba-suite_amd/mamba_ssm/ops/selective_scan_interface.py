@@ -171,6 +171,14 @@ def _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias):
     return ext
 
 
+def _mfma_proj():
+    """VMS_MFMA_PROJ=1: the node's small x_proj / dt_proj GEMMs run on the hand-written matrix-core kernels
+    (csrc/inner_proj.hip) where they apply.  Off by default: replacing the library GEMMs one for one measured no gain inside
+    the block step (4.79-4.81 vs 4.74 ms, profiles/r03_small_gemms.md) -- the passes over the 134 MB activations are what
+    costs, not the kernels that make them; tests compare the two paths."""
+    return os.environ.get("VMS_MFMA_PROJ") == "1"
+
+
 def _autocast_weights(*ws):
     if not torch.is_autocast_enabled():
         return ws
@@ -277,7 +285,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous() if D is not None else None
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
-            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from))
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj())
         ctx.reverse_from = int(reverse_from)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
         ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
@@ -353,7 +361,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
         dxz, dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = _inner_ext_module().inner_bwd(
             dout, xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out,
             bool(ctx.delta_softplus), ctx.reverse, dxz_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_BWD_SEGMENTS"),
-            getattr(ctx, "reverse_from", 0), ctx.w_dtype == torch.float32)
+            getattr(ctx, "reverse_from", 0), ctx.w_dtype == torch.float32, _mfma_proj())
         return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b, dx_proj_weight=dx_proj_weight,
                     ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=None, dout_proj_bias=None, dA=dA, dA_b=None,
                     dB=None, dC=None, dD=dD, ddelta_bias=ddelta_bias, dB_proj_bias=None, dC_proj_bias=None)

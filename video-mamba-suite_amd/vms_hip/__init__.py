@@ -102,6 +102,23 @@ class StateUpdateParams(ctypes.Structure):
     )
 
 
+class ProjApplyParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "rows", "k", "seqlen", "dtype", "accumulate", "tiles_per_wg", "reserved")]
+        + [(n, _vp) for n in ("w", "inp", "out")]
+        + [(n, _i64) for n in ("w_row_stride", "w_k_stride", "in_batch_stride", "in_k_stride", "out_batch_stride",
+                               "out_row_stride")]
+    )
+
+
+class ProjWgradParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "m", "n", "seqlen", "dtype", "tiles_per_wg")]
+        + [(n, _vp) for n in ("p", "q", "dw")]
+        + [(n, _i64) for n in ("p_batch_stride", "p_row_stride", "q_batch_stride", "q_row_stride", "dw_row_stride")]
+    )
+
+
 EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
@@ -110,6 +127,7 @@ EXPORTS = (
     "vms_layer_norm_fwd", "vms_layer_norm_bwd", "vms_layer_norm_bwd_partials", "vms_sizeof_norm_params",
     "vms_sizeof_norm_bwd_params", "vms_selective_state_update", "vms_sizeof_state_update_params",
     "vms_last_kernel", "vms_build_flags",
+    "vms_proj_apply", "vms_proj_wgrad", "vms_sizeof_proj_apply_params", "vms_sizeof_proj_wgrad_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -159,7 +177,7 @@ def ext():
             lib()
             try:
                 import _vms_torch
-                if _vms_torch.abi_version() == 5:
+                if _vms_torch.abi_version() == 6:
                     _ext = _vms_torch
             except ImportError as e:
                 # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
@@ -211,11 +229,12 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         L.vms_last_kernel.restype = ctypes.c_char_p
-        if L.vms_abi_version() != 5:
-            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 5: rebuild it")
+        if L.vms_abi_version() != 6:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 6: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
-                         ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams)):
+                         ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
+                         ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -485,6 +504,42 @@ def norm_bwd(s, dy, weight, mean, rstd, dres_out, dx, dres_in, dw_partial, db_pa
     if dres_in is not None:
         Q.dres_in_row_stride = dres_in.stride(0)
     _call("vms_layer_norm_bwd", Q, s)
+
+
+# ---- small projections of the inner node (csrc/inner_proj.hip) -----------------------------------------------
+def proj_apply(w, inp, out, accumulate=False, tiles_per_wg=0):
+    """out[b, d, l] (+)= sum_r w[d, r] inp[b, r, l];  w (rows, k) any strides, inp (batch, k, seqlen), out (batch, rows, seqlen),
+    unit seqlen strides, 16-bit dtype (vms_hip.h vms_proj_apply)."""
+    P = ProjApplyParams()
+    P.batch, P.k, P.seqlen = inp.shape
+    P.rows = w.shape[0]
+    P.dtype, P.accumulate, P.tiles_per_wg = dtype_code(inp), int(bool(accumulate)), int(tiles_per_wg)
+    if w.dtype != inp.dtype or out.dtype != inp.dtype or inp.stride(2) != 1 or out.stride(2) != 1:
+        raise RuntimeError("proj_apply: w, inp and out must share one 16-bit dtype; unit seqlen strides")
+    if tuple(out.shape) != (inp.shape[0], w.shape[0], inp.shape[2]) or w.shape[1] != inp.shape[1]:
+        raise RuntimeError("proj_apply: out must be (batch, rows, seqlen) and w (rows, k)")
+    P.w, P.inp, P.out = _ptr(w), _ptr(inp), _ptr(out)
+    P.w_row_stride, P.w_k_stride = w.stride(0), w.stride(1)
+    P.in_batch_stride, P.in_k_stride = inp.stride(0), inp.stride(1)
+    P.out_batch_stride, P.out_row_stride = out.stride(0), out.stride(1)
+    _call("vms_proj_apply", P, inp)
+
+
+def proj_wgrad(p, q, dw, tiles_per_wg=0):
+    """dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw fp32 (m, n), added to with atomics (vms_hip.h vms_proj_wgrad)."""
+    P = ProjWgradParams()
+    P.batch, P.m, P.seqlen = p.shape
+    P.n = q.shape[1]
+    P.dtype, P.tiles_per_wg = dtype_code(p), int(tiles_per_wg)
+    if q.dtype != p.dtype or dw.dtype != torch.float32 or p.stride(2) != 1 or q.stride(2) != 1 or dw.stride(1) != 1:
+        raise RuntimeError("proj_wgrad: p and q must share one 16-bit dtype with unit seqlen strides; dw fp32, unit column stride")
+    if tuple(dw.shape) != (p.shape[1], q.shape[1]) or q.shape[0] != p.shape[0] or q.shape[2] != p.shape[2]:
+        raise RuntimeError("proj_wgrad: p (batch, m, seqlen), q (batch, n, seqlen), dw (m, n) expected")
+    P.p, P.q, P.dw = _ptr(p), _ptr(q), _ptr(dw)
+    P.p_batch_stride, P.p_row_stride = p.stride(0), p.stride(1)
+    P.q_batch_stride, P.q_row_stride = q.stride(0), q.stride(1)
+    P.dw_row_stride = dw.stride(0)
+    _call("vms_proj_wgrad", P, p)
 
 
 # ---- single-token SSM step ---------------------------------------------------------------------------------
