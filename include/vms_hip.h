@@ -325,6 +325,35 @@ typedef struct {
 int vms_proj_apply(const vms_proj_apply_params *p, void *stream);
 int vms_proj_wgrad(const vms_proj_wgrad_params *p, void *stream);
 
+/* vms_proj_conv_bwd: selective_scan_interface.py:278-283 in one pass over the activations --
+ *     dx_proj_weight  = einsum("Br,Bd->rd", dx_dbl, conv1d_out)                      -> dw_x (k, dim) fp32, ADDED to (atomics)
+ *     dconv1d_out     = addmm(du, x_proj_weight.t(), dx_dbl.t())                     (never stored: fp32 on chip)
+ *     dx, dconv1d_weight, dconv1d_bias = causal_conv1d_bwd(x, w, b, dconv1d_out, dx, silu = True)
+ * with conv1d_out recomputed from x exactly as vms_causal_conv1d_fwd computes it.  x (the conv's input), du (the scan's
+ * gradient w.r.t. its input u), dx : (batch, dim, seqlen); dx_dbl : (batch, k, seqlen); all `dtype` (bf16 / fp16), unit
+ * seqlen stride; w_x = x_proj.weight (k, dim) in `dtype`, any strides; conv weight (dim, width), bias (dim) or NULL in
+ * `wdtype`; dconv_weight (dim, width), dconv_bias (dim), dw_x (k, dim): fp32 [zeroed] accumulators.  33 <= k <= 96.
+ * reverse / reverse_from / dx_accumulate as in vms_conv_bwd_params. */
+typedef struct {
+    int32_t batch, dim, k, seqlen, width;
+    int32_t dtype, wdtype;
+    int32_t reverse, reverse_from, dx_accumulate;
+    int32_t tiles_per_wg;     /* 0 = automatic */
+    int32_t reserved;
+    const void *x, *du, *dx_dbl, *w_x, *conv_weight, *conv_bias;
+    void *dx;
+    float *dconv_weight, *dconv_bias, *dw_x;
+    int64_t x_batch_stride, x_c_stride;
+    int64_t du_batch_stride, du_c_stride;
+    int64_t dxdbl_batch_stride, dxdbl_k_stride;
+    int64_t wx_k_stride, wx_c_stride;
+    int64_t conv_weight_c_stride, conv_weight_width_stride;
+    int64_t dx_batch_stride, dx_c_stride;
+    int64_t dconv_weight_c_stride, dconv_weight_width_stride;
+    int64_t dwx_k_stride;
+} vms_proj_conv_bwd_params;
+int vms_proj_conv_bwd(const vms_proj_conv_bwd_params *p, void *stream);
+
 /* ---- misc ---------------------------------------------------------------------------- */
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
@@ -343,6 +372,7 @@ int vms_sizeof_norm_bwd_params(void);
 int vms_sizeof_state_update_params(void);
 int vms_sizeof_proj_apply_params(void);
 int vms_sizeof_proj_wgrad_params(void);
+int vms_sizeof_proj_conv_bwd_params(void);
 
 #ifdef __cplusplus
 }

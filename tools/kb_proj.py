@@ -68,6 +68,25 @@ def main():
     xp = torch.empty(b, K2, L, device=dev, dtype=bf)
     t = timeit(lambda: torch.matmul(w_x, conv_out, out=xp))
     print(f"{'x_dbl = W_x @ conv_out (library only)':42s} library {t:7.1f} us   {act + small(K2):6.0f} MB (floor {(act + small(K2)) / 8:5.1f} us)")
+    # the backward's tail: library GEMMs + conv backward vs the one-pass kernel
+    import causal_conv1d_cuda
+    xz = torch.randn(b, 2 * d, L, device=dev, dtype=bf)
+    x = xz[:, :d, :]
+    conv_w, conv_b = torch.randn(d, 4, device=dev) * 0.3, torch.randn(d, device=dev) * 0.1
+    dxz = torch.empty_like(xz)
+    dxh = dxz[:, :d, :]
+
+    def tail_lib():
+        torch.sum(torch.matmul(dx_dbl, conv_out.transpose(1, 2)), 0)
+        dconv.baddbmm_(wxt.expand(b, -1, -1), dx_dbl)
+        causal_conv1d_cuda.causal_conv1d_bwd(x, conv_w, conv_b, dconv, dxh, True)
+
+    zw, zb, zx = torch.zeros(d, 4, device=dev), torch.zeros(d, device=dev), torch.zeros(K2, d, device=dev)
+    t_lib = timeit(tail_lib)
+    print(f"tail: dW_x + dconv_out += + conv1d backward, library + HIP conv: {t_lib:7.1f} us", flush=True)
+    for tp in (0, 4, 8, 16, 32, 64):
+        t_new = timeit(lambda: vms_hip.proj_conv_bwd(x, dconv, dx_dbl, w_x, conv_w, conv_b, dxh, zw, zb, zx, tiles_per_wg=tp))
+        print(f"tail: vms_proj_conv_bwd tiles_per_wg {tp:3d}: {t_new:7.1f} us  ({3 * act / t_new / 1e3 * 1e3:5.2f} TB/s of its 3 passes)", flush=True)
     if "sweep" in sys.argv:
         for tp in (2, 4, 8, 16, 32, 64, 128):
             print(f"tiles_per_wg {tp:3d}:  apply(dt_proj) {timeit(lambda: vms_hip.proj_apply(w_dt, dt_in, delta, False, tp)):6.1f}"

@@ -54,6 +54,7 @@ constexpr int kEpE = 32 + 4;       // LDS row pitch of the fp32 epilogue half ti
 // LDS buffers (two workgroup barriers per tile instead of one) and <= 128 registers give 4 workgroups = 16 waves per CU.
 #define VMS_PROJ_BOUNDS __launch_bounds__(kPT, 4)
 
+__device__ __forceinline__ bool aligned16_dev(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
 __device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -262,6 +263,309 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// proj_conv_bwd: the tail of the inner node's backward in one pass
+// ---------------------------------------------------------------------------------------------------------------------
+// After the scan's backward the reference runs  dx_proj_weight = dx_dbl @ conv1d_out^T (SSI:278),  dconv1d_out += x_proj_weight^T
+// @ dx_dbl (:279)  and causal_conv1d_bwd (:283) -- three kernels that read or write the (batch, dim, seqlen) activations
+// seven times (conv1d_out once, dconv1d_out read + written + read, x once, dx written, + the recompute of conv1d_out's
+// pre-activation inside the conv backward).  Here a workgroup walks 128 channels x 64 positions at a time and does all three
+// on chip: T = W_x^T dx_dbl on the matrix cores (as proj_apply), g = T + du and the conv backward on 8-position row pieces
+// (lane = (channel, piece); the pre-activation, SiLU', dx, dweight / dbias exactly as causal_conv1d_bwd computes them),
+// conv1d_out = silu(pre) rounded to the activation dtype into a wave-private LDS tile that is the B operand of the second
+// MFMA, dW_x += dx_dbl conv1d_out^T.  HBM traffic: du and x read, dx written, dx_dbl from L2 -- the conv backward's own
+// three passes.  dconv1d_out is never materialised (it stays fp32 in registers: one rounding less than the reference).
+// Tiles are walked from the end of the (logical) sequence: dx needs SiLU' * g of the next 3 positions, which the previous
+// iteration left in the piece-0 lanes (`carry`); the first iteration of a workgroup's range recomputes them from the tile after
+// its range without storing anything.  Right-to-left rows (reverse / reverse_from) use the same code on mirrored addresses:
+// a piece is kept in PHYSICAL element order everywhere (LDS tiles, MFMA columns) and indexed through LG() where the conv
+// needs logical order.
+constexpr int kWRowE = 128 + 8;   // LDS row pitch of the W_x tile (k rows x 128 channels), elements
+
+template <typename T, int KS, bool REV>
+__device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg) {
+    constexpr int KR = KS * 16;
+    constexpr int MB = (KR + 31) / 32;      // 32-row blocks of dW_x
+    constexpr int NPASS = MB;               // dx_dbl tile: 32 rows of 8 x 16-byte pieces per pass of the workgroup
+    typedef __attribute__((address_space(3))) short lds_s16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, c32 = lane & 31;
+    const int b = blockIdx.z, d0w = blockIdx.y * 128, d0 = d0w + wave * 32;
+    const int L = p.seqlen, R = p.k;
+    const T* const in_b = static_cast<const T*>(p.dx_dbl) + (int64_t)b * p.dxdbl_batch_stride;
+    lds_s16* const in_lds = (lds_s16*)reinterpret_cast<short*>(smem);                                                      // [MB * 32][kRowE]
+    lds_f32* const ep = (lds_f32*)reinterpret_cast<float*>(smem + MB * 32 * kRowE * 2) + wave * (32 * kEpE);               // [32][kEpE] fp32, this wave's
+    lds_s16* const co = (lds_s16*)reinterpret_cast<short*>(smem + MB * 32 * kRowE * 2 + 4 * 32 * kEpE * 4) + wave * (32 * kRowE);   // [32][kRowE], this wave's
+    lds_s16* const w_lds = (lds_s16*)reinterpret_cast<short*>(smem + MB * 32 * kRowE * 2 + 4 * 32 * kEpE * 4 + 4 * 32 * kRowE * 2);   // [KR][kWRowE]
+
+    const int n_tiles = (L + kTL - 1) / kTL;
+    const int t_lo = blockIdx.x * tiles_per_wg;
+    const int t_hi = t_lo + tiles_per_wg < n_tiles ? t_lo + tiles_per_wg : n_tiles;
+    if (t_lo >= t_hi) return;
+
+    // W_x[:, d0w .. d0w + 128) as it is stored (row k, channels contiguous), zero beyond the matrix; the A operand of the first
+    // product (i = channel, k strided) comes out of it through the transposing read, like the B operand out of the dx_dbl tile
+    {
+        const T* const wx = static_cast<const T*>(p.w_x);
+        const bool vec = p.wx_c_stride == 1 && p.wx_k_stride % 8 == 0 && aligned16_dev(wx) && d0w + 128 <= p.dim;
+        if (vec) {   // 16 lanes x 16 bytes per row: KR / 16 independent loads per thread
+#pragma unroll
+            for (int it = 0; it < KR / 16; ++it) {
+                const int k = it * 16 + (tid >> 4), c = 8 * (tid & 15);
+                const bool okw = k < R;
+                const s16x8 v = *reinterpret_cast<const s16x8*>(wx + (int64_t)(okw ? k : 0) * p.wx_k_stride + d0w + c);
+                *reinterpret_cast<lds_s16x8*>(w_lds + k * kWRowE + c) = okw ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        } else {
+            for (int idx = tid; idx < KR * 128; idx += kPT) {
+                const int k = idx >> 7, c = idx & 127;
+                const bool okw = k < R && d0w + c < p.dim;
+                const T v = okw ? wx[(int64_t)k * p.wx_k_stride + (int64_t)(d0w + c) * p.wx_c_stride] : static_cast<T>(0.f);
+                w_lds[k * kWRowE + c] = __builtin_bit_cast(short, v);
+            }
+        }
+    }
+
+    // lane -> channel rows er + 16 pp (pp = 0, 1), piece q of a 32-position half tile
+    const int er = lane >> 2, q = lane & 3, ec = 8 * q;
+    const T* xrow[2];
+    const T* durow[2];
+    T* dxrow[2];
+    bool row_ok[2];
+    float taps[2][4], cbias[2];
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int d = d0 + er + 16 * pp;
+        row_ok[pp] = d < p.dim;
+        const int dc = row_ok[pp] ? d : 0;
+        xrow[pp] = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)dc * p.x_c_stride;
+        durow[pp] = static_cast<const T*>(p.du) + (int64_t)b * p.du_batch_stride + (int64_t)dc * p.du_c_stride;
+        dxrow[pp] = static_cast<T*>(p.dx) + (int64_t)b * p.dx_batch_stride + (int64_t)dc * p.dx_c_stride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {   // taps[k] multiplies x[t - 3 + k]; widths < 4 get leading zeros (causal_conv1d.hip load_taps)
+            const int w = k - (4 - p.width);
+            float v = 0.f;
+            if (w >= 0) {
+                const int64_t idx = (int64_t)dc * p.conv_weight_c_stride + (int64_t)w * p.conv_weight_width_stride;
+                v = p.wdtype == VMS_F32 ? static_cast<const float*>(p.conv_weight)[idx]
+                    : p.wdtype == VMS_F16 ? static_cast<float>(static_cast<const f16_t*>(p.conv_weight)[idx])
+                                          : static_cast<float>(static_cast<const bf16_t*>(p.conv_weight)[idx]);
+            }
+            taps[pp][k] = v;
+        }
+        cbias[pp] = !p.conv_bias ? 0.f
+                    : p.wdtype == VMS_F32 ? static_cast<const float*>(p.conv_bias)[dc]
+                    : p.wdtype == VMS_F16 ? static_cast<float>(static_cast<const f16_t*>(p.conv_bias)[dc])
+                                          : static_cast<float>(static_cast<const bf16_t*>(p.conv_bias)[dc]);
+    }
+
+    // staging of the dx_dbl tile (logical tile t): thread -> row (tid >> 3) + 32 pass, logical piece tid & 7
+    s16x8 stg[NPASS];
+    auto stage_load = [&](int t) __attribute__((always_inline)) {
+        const int tl = t * kTL + 8 * (tid & 7);                      // logical start of the piece
+        const int pl = REV ? L - tl - 8 : tl;                         // its physical vector
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int r = (tid >> 3) + 32 * ps;
+            const bool ok = r < R && tl < L && t >= t_lo;
+            const s16x8 v = *reinterpret_cast<const s16x8*>(in_b + (int64_t)(ok ? r : 0) * p.dxdbl_k_stride + (ok ? pl : 0));
+            stg[ps] = ok ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    };
+    auto stage_store = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps)
+            *reinterpret_cast<lds_s16x8*>(in_lds + ((tid >> 3) + 32 * ps) * kRowE + 8 * (tid & 7)) = stg[ps];
+    };
+    // transposing reads (tools/tr_probe.hip): lane i of a 16-lane group supplies row i / 4, columns 4 (i % 4) .. + 3 of a
+    // [4][16] block and receives column i of its 4 rows
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const lds_s16* const tb = in_lds + (8 * (g16 >> 1) + (i16 >> 2)) * kRowE + 16 * (g16 & 1) + 4 * (i16 & 3);
+    const lds_s16* const ta = w_lds + (8 * (g16 >> 1) + (i16 >> 2)) * kWRowE + wave * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+
+    f32x16 accw[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
+    float dwacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbacc[2] = {0.f, 0.f};
+    float carry[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // SiLU' g of the first 3 positions of the piece after this quad's last one
+
+    // This lane's four pieces of a tile in processing order ss = 0..3: half j = 1 - (ss >> 1) (from the end of the logical tile),
+    // rows er + 16 (ss & 1).  Their x / du vectors are requested a whole tile ahead: set ss is refilled for tile t - 1 as soon as
+    // its values for tile t have been widened (a piece one step ahead left every piece waiting for HBM: 165 us per call).
+    struct Raw { vec_t<T, 8> x, du; vec_t<T, 4> xh; };
+    Raw raw[4];
+    auto piece_load = [&](Raw& r, int t, int ss) __attribute__((always_inline)) {
+        const int j = 1 - (ss >> 1), pp = ss & 1;
+        const int tl = t * kTL + 32 * j + ec;
+        const int pl = REV ? L - tl - 8 : tl;
+        const bool okp = row_ok[pp] && tl < L && t >= t_lo;
+        const int po = okp ? pl : 0;
+        r.x = *reinterpret_cast<const vec_t<T, 8>*>(xrow[pp] + po);
+        r.du = *reinterpret_cast<const vec_t<T, 8>*>(durow[pp] + po);
+        // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left
+        const bool hok = okp && tl > 0;
+        r.xh = *reinterpret_cast<const vec_t<T, 4>*>(xrow[pp] + (hok ? (REV ? pl + 8 : pl - 4) : 0));
+        if (!hok) r.xh = vec_t<T, 4>{static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
+    };
+
+    // the tile after the range only feeds `carry`
+    const int t_first = t_hi < n_tiles ? t_hi : t_hi - 1;
+    stage_load(t_first);
+#pragma unroll
+    for (int ss = 0; ss < 4; ++ss) piece_load(raw[ss], t_first, ss);
+    for (int t = t_first; t >= t_lo; --t) {
+        const bool emit = t < t_hi;
+        stage_store();
+        __syncthreads();          // tile t (and, the first time, the W_x tile) is in LDS
+        stage_load(t - 1);        // travels during the rest of the iteration
+        vec_t<T, 8> dxold[2];
+        auto dxold_load = [&](int ss) __attribute__((always_inline)) {
+            const int j = 1 - (ss >> 1), pp = ss & 1;
+            const int tl = t * kTL + 32 * j + ec;
+            const bool okp = row_ok[pp] && tl < L;
+            dxold[ss & 1] = *reinterpret_cast<const vec_t<T, 8>*>(dxrow[pp] + (okp ? (REV ? L - tl - 8 : tl) : 0));
+        };
+        if (p.dx_accumulate && emit) dxold_load(0);
+#pragma unroll
+        for (int ss = 0; ss < 4; ++ss) {
+            const int j = 1 - (ss >> 1), pp = ss & 1;
+            if (p.dx_accumulate && emit && ss < 3) dxold_load(ss + 1);
+            if (pp == 0) {
+                // first product for this half: T[d][l], this wave's 32 channels x 32 positions, into the wave's fp32 tile
+                f32x16 acc;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (16 * s) * kWRowE));
+                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (16 * s + 4) * kWRowE));
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s) * kRowE + 32 * j));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s + 4) * kRowE + 32 * j));
+                    const s16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const s16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc = Mfma32<T>::run(af, bf, acc);
+                }
+                lds_order();   // the previous half's reads of `ep` are done
+#pragma unroll
+                for (int v = 0; v < 16; ++v) ep[((v & 3) + 8 * (v >> 2) + 4 * h) * kEpE + c32] = acc[v];
+                lds_order();
+            }
+            const int tl = t * kTL + 32 * j + ec;
+            const bool okp = row_ok[pp] && tl < L;
+            float xv[8 + 3], gp[8 + 3];     // inputs t - 3 .. t + 7 and SiLU' g of t .. t + 10, logical order
+            float duf[8];
+            // logical order: element i of the piece is physical element (REV ? 7 - i : i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) xv[k] = static_cast<float>(raw[ss].xh[REV ? 2 - k : 1 + k]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xv[3 + i] = static_cast<float>(raw[ss].x[REV ? 7 - i : i]);
+                duf[i] = static_cast<float>(raw[ss].du[REV ? 7 - i : i]);
+            }
+            asm volatile("" ::: "memory");     // keeps the refill below the widening (same registers)
+            piece_load(raw[ss], t - 1, ss);
+            const lds_f32x4* src = (const lds_f32x4*)(ep + (er + 16 * pp) * kEpE + ec);
+            const f32x4 tq0 = src[0], tq1 = src[1];
+            const float tv[8] = {tq0.x, tq0.y, tq0.z, tq0.w, tq1.x, tq1.y, tq1.z, tq1.w};
+            vec_t<T, 8> cov;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = REV ? 7 - i : i;
+                float pre = cbias[pp];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre = fmaf(taps[pp][k], xv[i + k], pre);
+                const float sg = sigmoidf_(pre);
+                const float g = tv[e] + duf[i];
+                gp[i] = okp ? g * (sg * (1.f + pre * (1.f - sg))) : 0.f;
+                cov[e] = static_cast<T>(okp ? pre * sg : 0.f);
+            }
+            *reinterpret_cast<__attribute__((address_space(3))) vec_t<T, 8>*>(co + (er + 16 * pp) * kRowE + 32 * j + ec) = cov;
+            // the next piece's first three values: lane + 1 of the quad; the last piece of the half takes what piece 0 of the
+            // previously processed half (or tile) left in `carry`
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float v = q == 0 ? carry[pp][k] : gp[k];
+                gp[8 + k] = dpp_mov<0x39, 0xf>(0.f, v);   // quad_perm [1, 2, 3, 0]
+                carry[pp][k] = gp[k];
+            }
+            if (emit) {
+                vec_t<T, 8> o;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int e = REV ? 7 - i : i;
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a = fmaf(taps[pp][k], gp[i + 3 - k], a);
+                    if (p.dx_accumulate) a += static_cast<float>(dxold[ss & 1][e]);
+                    o[e] = static_cast<T>(a);
+                    dbacc[pp] += gp[i];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dwacc[pp][k] = fmaf(xv[i + k], gp[i], dwacc[pp][k]);
+                }
+                if (okp) *reinterpret_cast<vec_t<T, 8>*>(dxrow[pp] + (REV ? L - tl - 8 : tl)) = o;
+            }
+        }
+        // second product: dW_x[r][d] += sum_l dx_dbl[r][l] conv1d_out[d][l] over the tile (same column order in both tiles)
+        if (emit) {
+            lds_order();
+            const lds_s16* const pa = in_lds + c32 * kRowE + 8 * h;
+            const lds_s16* const qa = co + c32 * kRowE + 8 * h;
+#pragma unroll
+            for (int s = 0; s < kTL / 16; ++s) {
+                const s16x8 bq = *reinterpret_cast<const lds_s16x8*>(qa + 16 * s);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const s16x8 ap = *reinterpret_cast<const lds_s16x8*>(pa + 32 * mb * kRowE + 16 * s);
+                    accw[mb] = Mfma32<T>::run(ap, bq, accw[mb]);
+                }
+            }
+        }
+        __syncthreads();          // every wave has read tile t: the dx_dbl buffer may be overwritten
+    }
+    // dW_x: one atomic per (r, channel) and workgroup
+    {
+        const int d = d0 + c32;
+        if (d < p.dim) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = 32 * mb + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (m < R) atomicAdd(p.dw_x + (int64_t)m * p.dwx_k_stride + d, accw[mb][v]);
+                }
+        }
+    }
+    // conv dweight / dbias: the 4 lanes of a quad hold one channel's partial sums
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        float v[5] = {dwacc[pp][0], dwacc[pp][1], dwacc[pp][2], dwacc[pp][3], dbacc[pp]};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            v[k] += dpp_mov<0xB1, 0xf>(0.f, v[k]);   // quad_perm [1, 0, 3, 2]
+            v[k] += dpp_mov<0x4E, 0xf>(0.f, v[k]);   // quad_perm [2, 3, 0, 1]
+        }
+        if (q == 0 && row_ok[pp]) {
+            const int d = d0 + er + 16 * pp;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int wi = k - (4 - p.width);
+                if (wi >= 0) atomicAdd(p.dconv_weight + (int64_t)d * p.dconv_weight_c_stride + (int64_t)wi * p.dconv_weight_width_stride, v[k]);
+            }
+            if (p.dconv_bias) atomicAdd(p.dconv_bias + d, v[4]);
+        }
+    }
+}
+
+template <typename T, int KS>
+__global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg) {
+    const bool rev = p.reverse != 0 || (p.reverse_from > 0 && (int)blockIdx.z >= p.reverse_from);   // workgroup-uniform
+    if (rev) proj_conv_bwd_body<T, KS, true>(p, tiles_per_wg);
+    else proj_conv_bwd_body<T, KS, false>(p, tiles_per_wg);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -325,6 +629,45 @@ static int dispatch_wgrad(const vms_proj_wgrad_params& p, hipStream_t stream) {
     }
 }
 
+template <typename T, int KS>
+static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream) {
+    constexpr int MB = (KS * 16 + 31) / 32;
+    const int n_tiles = (p.seqlen + kTL - 1) / kTL;
+    const int d_tiles = (p.dim + 127) / 128;
+    // ~2 workgroups per CU; every workgroup pays one extra tile (the carry) and dim-tile x k atomics at its end
+    const int64_t want = 2 * (int64_t)device_cu_count();
+    int tpw = (int)(((int64_t)n_tiles * d_tiles * p.batch + want - 1) / want);
+    if (tpw < 8) tpw = 8;
+    if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
+    if (tpw > n_tiles) tpw = n_tiles;
+    const dim3 grid((n_tiles + tpw - 1) / tpw, d_tiles, p.batch), block(kPT);
+    const size_t smem = (size_t)MB * 32 * kRowE * 2 + (size_t)4 * 32 * kEpE * sizeof(float) + (size_t)4 * 32 * kRowE * 2 + (size_t)KS * 16 * kWRowE * 2;
+    if (smem > 64 * 1024) {   // k > 64: 76 KB, admitted per kernel and per device before the first launch there
+        static PerDeviceOnce attr_once;
+        const hipError_t arc = attr_once.run([&]() -> hipError_t {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
+        if (arc != hipSuccess) {
+            set_error("hipFuncSetAttribute(proj_conv_bwd, %zu bytes of LDS) failed: %s", smem, hipGetErrorString(arc));
+            return VMS_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS>), grid, block, smem, stream, p, tpw);
+    VMS_LAUNCH_CHECK();
+    set_last_kernel("proj_conv_bwd");
+    return VMS_OK;
+}
+
+template <typename T>
+static int dispatch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream) {
+    switch ((p.k + 15) / 16) {
+        case 3: return launch_conv_bwd<T, 3>(p, stream);
+        case 4: return launch_conv_bwd<T, 4>(p, stream);
+        case 5: return launch_conv_bwd<T, 5>(p, stream);
+        default: return launch_conv_bwd<T, 6>(p, stream);
+    }
+}
+
 }  // namespace vms
 
 using namespace vms;
@@ -359,3 +702,22 @@ extern "C" int vms_proj_wgrad(const vms_proj_wgrad_params* pp, void* stream) {
 
 extern "C" int vms_sizeof_proj_apply_params(void) { return (int)sizeof(vms_proj_apply_params); }
 extern "C" int vms_sizeof_proj_wgrad_params(void) { return (int)sizeof(vms_proj_wgrad_params); }
+
+extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* stream) {
+    VMS_CHECK(pp != nullptr, "null parameter block");
+    const vms_proj_conv_bwd_params& p = *pp;
+    VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_conv_bwd: 16-bit activations only (bf16 / fp16)");
+    VMS_CHECK(p.wdtype == VMS_F32 || p.wdtype == VMS_F16 || p.wdtype == VMS_BF16, "conv weight dtype must be fp32/fp16/bf16");
+    VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0, "empty problem");
+    VMS_CHECK(p.k >= 33 && p.k <= 96, "proj_conv_bwd: 33 <= k <= 96");
+    VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
+    VMS_CHECK(p.x && p.du && p.dx_dbl && p.w_x && p.conv_weight && p.dx && p.dconv_weight && p.dw_x, "x, du, dx_dbl, w_x, conv_weight, dx, dconv_weight, dw_x are required");
+    VMS_CHECK(!(p.reverse && p.reverse_from), "reverse and reverse_from are exclusive");
+    VMS_CHECK(p.seqlen % 8 == 0 && p.x_batch_stride % 8 == 0 && p.x_c_stride % 8 == 0 && p.du_batch_stride % 8 == 0 && p.du_c_stride % 8 == 0 &&
+                  p.dx_batch_stride % 8 == 0 && p.dx_c_stride % 8 == 0 && p.dxdbl_batch_stride % 8 == 0 && p.dxdbl_k_stride % 8 == 0 &&
+                  aligned16(p.x) && aligned16(p.du) && aligned16(p.dx) && aligned16(p.dx_dbl),
+              "proj_conv_bwd: seqlen and the activation strides (elements) must be multiples of 8, bases 16-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return p.dtype == VMS_BF16 ? dispatch_conv_bwd<bf16_t>(p, s) : dispatch_conv_bwd<f16_t>(p, s);
+}
+extern "C" int vms_sizeof_proj_conv_bwd_params(void) { return (int)sizeof(vms_proj_conv_bwd_params); }

@@ -474,10 +474,41 @@ void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw) {
     call("vms_proj_wgrad", vms_proj_wgrad, P, p);
 }
 
+bool proj_conv_bwd_eligible(const Tensor& x, const Tensor& du_like, const Tensor& dx_dbl_like, const Tensor& w_x, const Tensor& conv_w,
+                            const OptT& conv_b, const Tensor& dx) {
+    const int64_t k = dx_dbl_like.size(1);
+    return proj_ok16(x) && proj_ok16(du_like) && proj_ok16(dx_dbl_like) && proj_ok16(dx) && w_x.scalar_type() == x.scalar_type() &&
+           du_like.scalar_type() == x.scalar_type() && dx_dbl_like.scalar_type() == x.scalar_type() && dx.scalar_type() == x.scalar_type() &&
+           k >= 33 && k <= 96 && conv_w.dim() == 2 && conv_w.size(1) >= 2 && conv_w.size(1) <= 4 && is_itype(conv_w) &&
+           (!conv_b.has_value() || conv_b->scalar_type() == conv_w.scalar_type());
+}
+// vms_hip.h vms_proj_conv_bwd: dw_x += dx_dbl conv1d_out^T; dx, dconv_w, dconv_b = conv1d backward of (du + w_x^T dx_dbl)
+void proj_conv_bwd(const Tensor& x, const Tensor& du, const Tensor& dx_dbl, const Tensor& w_x, const Tensor& conv_w, const OptT& conv_b,
+                   const Tensor& dx, const Tensor& dconv_w, const OptT& dconv_b, const Tensor& dw_x, bool reverse, int64_t reverse_from,
+                   bool accumulate_dx) {
+    vms_proj_conv_bwd_params P{};
+    P.batch = (int)x.size(0); P.dim = (int)x.size(1); P.seqlen = (int)x.size(2); P.k = (int)dx_dbl.size(1); P.width = (int)conv_w.size(1);
+    P.dtype = dtype_code(x); P.wdtype = dtype_code(conv_w);
+    P.reverse = reverse; P.reverse_from = (int)reverse_from; P.dx_accumulate = accumulate_dx;
+    P.x = x.data_ptr(); P.du = du.data_ptr(); P.dx_dbl = dx_dbl.data_ptr(); P.w_x = w_x.data_ptr();
+    P.conv_weight = conv_w.data_ptr(); P.conv_bias = cptr(conv_b);
+    P.dx = dx.data_ptr(); P.dconv_weight = dconv_w.data_ptr<float>(); P.dconv_bias = dconv_b.has_value() ? dconv_b->data_ptr<float>() : nullptr;
+    P.dw_x = dw_x.data_ptr<float>();
+    P.x_batch_stride = x.stride(0); P.x_c_stride = x.stride(1);
+    P.du_batch_stride = du.stride(0); P.du_c_stride = du.stride(1);
+    P.dxdbl_batch_stride = dx_dbl.stride(0); P.dxdbl_k_stride = dx_dbl.stride(1);
+    P.wx_k_stride = w_x.stride(0); P.wx_c_stride = w_x.stride(1);
+    P.conv_weight_c_stride = conv_w.stride(0); P.conv_weight_width_stride = conv_w.stride(1);
+    P.dx_batch_stride = dx.stride(0); P.dx_c_stride = dx.stride(1);
+    P.dconv_weight_c_stride = dconv_w.stride(0); P.dconv_weight_width_stride = dconv_w.stride(1);
+    P.dwx_k_stride = dw_x.stride(0);
+    call("vms_proj_conv_bwd", vms_proj_conv_bwd, P, x);
+}
+
 // -> [out_z, conv_out, x_dbl, delta, ckpt, out]
 std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                               const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
-                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, bool use_mfma_proj) {
+                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, int64_t proj_flags) {
     TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
     c10::DeviceGuard guard(xz.device());
     const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
@@ -490,7 +521,7 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     {
         const Tensor dt_in = x_dbl.narrow(1, 0, R);
         delta = at::empty({x_dbl.size(0), d, x_dbl.size(2)}, x_dbl.options());
-        if (use_mfma_proj && proj_apply_eligible(dt_proj_w, dt_in, delta)) proj_apply(dt_proj_w, dt_in, delta, false);
+        if ((proj_flags & 1) && proj_apply_eligible(dt_proj_w, dt_in, delta)) proj_apply(dt_proj_w, dt_in, delta, false);
         else at::matmul_out(delta, dt_proj_w, dt_in);
     }
     const PaddedBC bc = pad_bc(x_dbl.narrow(1, R, N).unsqueeze(1), x_dbl.narrow(1, R + N, N).unsqueeze(1), reverse, reverse_from > 0);
@@ -505,7 +536,8 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
                             const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
                             const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
                             bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32,
-                            bool use_mfma_proj) {
+                            int64_t proj_flags) {
+    const bool use_mfma_proj = (proj_flags & 1) != 0;
     c10::DeviceGuard guard(xz.device());
     const auto wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
     const int64_t b = xz.size(0), d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
@@ -522,7 +554,9 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
     const Tensor dt_in = x_dbl.narrow(1, 0, R);
     const bool mfma_wg = use_mfma_proj && proj_wgrad_eligible(x_dbl, conv_out) && proj_wgrad_eligible(dt_in, delta);
     const int64_t n_proj = mfma_wg ? (R + (R + 2 * N)) * d : 0;
-    Tensor zeros = at::zeros({n_scan + n_conv + n_proj}, xz.options().dtype(at::kFloat));
+    const int64_t K2 = R + 2 * N;
+    const bool fused_tail = (proj_flags & 2) && proj_conv_bwd_eligible(x, conv_out, x_dbl, x_proj_w, conv_w, conv_b, dx);
+    Tensor zeros = at::zeros({n_scan + n_conv + n_proj + (fused_tail ? K2 * d : 0)}, xz.options().dtype(at::kFloat));
     const PaddedBC bc = pad_bc(Bv, Cv, reverse, reverse_from > 0);
     std::vector<OptT> g = scan_bwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, dout, ckpt, out, dz, delta_softplus,
                                    /*recompute_out_z=*/false, reverse, zeros.narrow(0, 0, n_scan), /*keep_fp32=*/true, acc, bc.pad, impl,
@@ -540,6 +574,17 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
         ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
     }
     dx_dbl.narrow(1, 0, R).copy_(at::matmul(dt_proj_w.t(), ddelta));                        // (b, R, l)
+    if (fused_tail) {
+        // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
+        Tensor dwx = zeros.narrow(0, n_scan + n_conv + n_proj, K2 * d).view({K2, d});
+        Tensor dcw = zeros.narrow(0, n_scan, conv_w.numel()).view(conv_w.sizes());
+        OptT dcb;
+        if (conv_b.has_value()) dcb = zeros.narrow(0, n_scan + conv_w.numel(), conv_b->numel());
+        proj_conv_bwd(x, dconv_out, dx_dbl, x_proj_w, conv_w, conv_b, dx, dcw, dcb, dwx, reverse, reverse_from, acc);
+        OptT db;
+        if (conv_b.has_value()) db = dcb->to(conv_b->scalar_type());
+        return {dxz, dcw.to(conv_w.scalar_type()), db, dwx.to(wdt), ddt_proj_w, g[2], g[5], g[6]};
+    }
     if (mfma_wg && proj_wgrad_eligible(dx_dbl, conv_out)) {
         Tensor dw2 = zeros.narrow(0, n_scan + n_conv + R * d, (R + 2 * N) * d).view({R + 2 * N, d});
         proj_wgrad(dx_dbl, conv_out, dw2);

@@ -176,7 +176,9 @@ def _mfma_proj():
     (csrc/inner_proj.hip) where they apply.  Off by default: replacing the library GEMMs one for one measured no gain inside
     the block step (4.79-4.81 vs 4.74 ms, profiles/r03_small_gemms.md) -- the passes over the 134 MB activations are what
     costs, not the kernels that make them; tests compare the two paths."""
-    return os.environ.get("VMS_MFMA_PROJ") == "1"
+    # bit 1 (default on; VMS_NO_FUSED_TAIL=1 clears it): the backward's tail -- dx_proj.weight, dconv1d_out += W_x^T dx_dbl and
+    # the conv1d backward -- as ONE pass over the activations (vms_proj_conv_bwd) instead of three kernels and seven
+    return (1 if os.environ.get("VMS_MFMA_PROJ") == "1" else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2)
 
 
 def _autocast_weights(*ws):

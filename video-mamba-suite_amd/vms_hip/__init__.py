@@ -119,6 +119,18 @@ class ProjWgradParams(ctypes.Structure):
     )
 
 
+class ProjConvBwdParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "dim", "k", "seqlen", "width", "dtype", "wdtype", "reverse", "reverse_from",
+                             "dx_accumulate", "tiles_per_wg", "reserved")]
+        + [(n, _vp) for n in ("x", "du", "dx_dbl", "w_x", "conv_weight", "conv_bias", "dx", "dconv_weight", "dconv_bias", "dw_x")]
+        + [(n, _i64) for n in ("x_batch_stride", "x_c_stride", "du_batch_stride", "du_c_stride", "dxdbl_batch_stride",
+                               "dxdbl_k_stride", "wx_k_stride", "wx_c_stride", "conv_weight_c_stride",
+                               "conv_weight_width_stride", "dx_batch_stride", "dx_c_stride", "dconv_weight_c_stride",
+                               "dconv_weight_width_stride", "dwx_k_stride")]
+    )
+
+
 EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
@@ -128,6 +140,7 @@ EXPORTS = (
     "vms_sizeof_norm_bwd_params", "vms_selective_state_update", "vms_sizeof_state_update_params",
     "vms_last_kernel", "vms_build_flags",
     "vms_proj_apply", "vms_proj_wgrad", "vms_sizeof_proj_apply_params", "vms_sizeof_proj_wgrad_params",
+    "vms_proj_conv_bwd", "vms_sizeof_proj_conv_bwd_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -234,7 +247,8 @@ def lib():
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
-                         ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams)):
+                         ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams),
+                         ("proj_conv_bwd", ProjConvBwdParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -540,6 +554,38 @@ def proj_wgrad(p, q, dw, tiles_per_wg=0):
     P.q_batch_stride, P.q_row_stride = q.stride(0), q.stride(1)
     P.dw_row_stride = dw.stride(0)
     _call("vms_proj_wgrad", P, p)
+
+
+def proj_conv_bwd(x, du, dx_dbl, w_x, conv_w, conv_b, dx, dconv_w, dconv_b, dw_x, reverse=False, reverse_from=0,
+                  dx_accumulate=False, tiles_per_wg=0):
+    """dw_x += dx_dbl conv1d_out^T;  dx, dconv_w, dconv_b = conv1d backward of (du + w_x^T dx_dbl), SiLU on
+    (vms_hip.h vms_proj_conv_bwd).  x, du, dx: (batch, dim, seqlen); dx_dbl: (batch, k, seqlen); w_x: (k, dim);
+    conv_w: (dim, width); dconv_w / dconv_b / dw_x: fp32, zero-filled by the caller."""
+    P = ProjConvBwdParams()
+    P.batch, P.dim, P.seqlen = x.shape
+    P.k, P.width = dx_dbl.shape[1], conv_w.shape[1]
+    P.dtype, P.wdtype = dtype_code(x), dtype_code(conv_w)
+    P.reverse, P.reverse_from, P.dx_accumulate, P.tiles_per_wg = int(bool(reverse)), int(reverse_from), int(bool(dx_accumulate)), int(tiles_per_wg)
+    for t, name in ((x, "x"), (du, "du"), (dx_dbl, "dx_dbl"), (dx, "dx")):
+        if t.dtype != x.dtype or t.stride(2) != 1:
+            raise RuntimeError(f"proj_conv_bwd: {name} must have x's dtype and a unit seqlen stride")
+    if w_x.dtype != x.dtype or tuple(w_x.shape) != (P.k, P.dim) or tuple(du.shape) != tuple(x.shape) or tuple(dx.shape) != tuple(x.shape):
+        raise RuntimeError("proj_conv_bwd: w_x must be (k, dim) in x's dtype; du and dx shaped like x")
+    if dw_x.dtype != torch.float32 or dconv_w.dtype != torch.float32 or dw_x.stride(1) != 1 or tuple(dw_x.shape) != (P.k, P.dim):
+        raise RuntimeError("proj_conv_bwd: dw_x (k, dim) and dconv_w (dim, width) must be float32 accumulators")
+    if conv_b is not None and conv_b.dtype != conv_w.dtype:
+        raise RuntimeError("proj_conv_bwd: conv bias must have the conv weight's dtype")
+    P.x, P.du, P.dx_dbl, P.w_x, P.conv_weight, P.conv_bias = _ptr(x), _ptr(du), _ptr(dx_dbl), _ptr(w_x), _ptr(conv_w), _ptr(conv_b)
+    P.dx, P.dconv_weight, P.dconv_bias, P.dw_x = _ptr(dx), _ptr(dconv_w), _ptr(dconv_b), _ptr(dw_x)
+    P.x_batch_stride, P.x_c_stride = x.stride(0), x.stride(1)
+    P.du_batch_stride, P.du_c_stride = du.stride(0), du.stride(1)
+    P.dxdbl_batch_stride, P.dxdbl_k_stride = dx_dbl.stride(0), dx_dbl.stride(1)
+    P.wx_k_stride, P.wx_c_stride = w_x.stride(0), w_x.stride(1)
+    P.conv_weight_c_stride, P.conv_weight_width_stride = conv_w.stride(0), conv_w.stride(1)
+    P.dx_batch_stride, P.dx_c_stride = dx.stride(0), dx.stride(1)
+    P.dconv_weight_c_stride, P.dconv_weight_width_stride = dconv_w.stride(0), dconv_w.stride(1)
+    P.dwx_k_stride = dw_x.stride(0)
+    _call("vms_proj_conv_bwd", P, x)
 
 
 # ---- single-token SSM step ---------------------------------------------------------------------------------
