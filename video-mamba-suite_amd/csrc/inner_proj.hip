@@ -268,57 +268,82 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
 // After the scan's backward the reference runs  dx_proj_weight = dx_dbl @ conv1d_out^T (SSI:278),  dconv1d_out += x_proj_weight^T
 // @ dx_dbl (:279)  and causal_conv1d_bwd (:283) -- three kernels that read or write the (batch, dim, seqlen) activations
 // seven times (conv1d_out once, dconv1d_out read + written + read, x once, dx written, + the recompute of conv1d_out's
-// pre-activation inside the conv backward).  Here a workgroup walks 128 channels x 64 positions at a time and does all three
-// on chip: T = W_x^T dx_dbl on the matrix cores (as proj_apply), g = T + du and the conv backward on 8-position row pieces
-// (lane = (channel, piece); the pre-activation, SiLU', dx, dweight / dbias exactly as causal_conv1d_bwd computes them),
-// conv1d_out = silu(pre) rounded to the activation dtype into a wave-private LDS tile that is the B operand of the second
-// MFMA, dW_x += dx_dbl conv1d_out^T.  HBM traffic: du and x read, dx written, dx_dbl from L2 -- the conv backward's own
-// three passes.  dconv1d_out is never materialised (it stays fp32 in registers: one rounding less than the reference).
+// pre-activation inside the conv backward).  Here a workgroup (4 waves x 16 channels) walks 64 channels x 64 positions at a
+// time and does all three on chip:
+//   * T = W_x^T dx_dbl on the matrix cores (16x16x32; both operands k-strided in memory: transposing LDS reads of the dx_dbl
+//     tile and of the W_x tile, which stays in LDS for the workgroup's whole range), through a wave-private fp32 LDS tile into
+//     8-position row pieces: lane = (channel row lane >> 3, piece lane & 7), so a wave's load / store covers 8 full 128-byte lines;
+//   * g = T + du and the conv backward on the pieces: pre-activation, SiLU', dx, dweight / dbias exactly as causal_conv1d_bwd
+//     computes them; dconv1d_out is never materialised (fp32 in registers: one rounding less than the reference);
+//   * conv1d_out = silu(pre) rounded to the activation dtype into a wave-private LDS tile = the B operand of the second
+//     product, dW_x += dx_dbl conv1d_out^T (16x16x32, fp32 accumulators over the range, one atomic per (k, channel) at the end).
+// HBM traffic: du and x read, dx written, dx_dbl from L2 -- the conv backward's own three passes.
 // Tiles are walked from the end of the (logical) sequence: dx needs SiLU' * g of the next 3 positions, which the previous
 // iteration left in the piece-0 lanes (`carry`); the first iteration of a workgroup's range recomputes them from the tile after
 // its range without storing anything.  Right-to-left rows (reverse / reverse_from) use the same code on mirrored addresses:
-// a piece is kept in PHYSICAL element order everywhere (LDS tiles, MFMA columns) and indexed through LG() where the conv
-// needs logical order.
-constexpr int kWRowE = 128 + 8;   // LDS row pitch of the W_x tile (k rows x 128 channels), elements
+// a piece is kept in PHYSICAL element order everywhere (LDS tiles, MFMA columns) and read through (REV ? 7 - i : i) where the
+// conv needs logical order.
+// Where the time goes (profiles/r03_small_gemms.md): 2 waves per SIMD (203-240 VGPRs: the dW_x accumulators, a tile of requests
+// in flight, the conv's working set); with its parts removed the kernel takes 77 us (loads + barriers only, one tile of
+// requests per workgroup = latency-bound at 3.5 TB/s) + 31 (stores) + 33 (arithmetic) = its 130-150 us at (8, 1024, 8192):
+// the parts do not overlap at this occupancy.  A 3-waves-per-SIMD build spills (143 registers) and is 2.7x slower.
+typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPBufFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format (as causal_conv1d.hip)
+constexpr int kCD = 64;             // channels per workgroup of proj_conv_bwd (16 per wave)
+constexpr int kWRowE = kCD + 8;     // LDS row pitch of the W_x tile (k rows x 64 channels), elements
+constexpr int kEpT = kTL + 4;       // LDS row pitch of the fp32 tile of the first product (16 channels x 64 positions), floats
 
-template <typename T, int KS, bool REV>
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    typedef __bf16 V __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x4 run(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    typedef _Float16 V __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ f32x4 run(s16x8 a, s16x8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V, a), __builtin_bit_cast(V, b), c, 0, 0, 0);
+    }
+};
+
+template <typename T, int KS, bool REV, bool DXACC>
 __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg) {
-    constexpr int KR = KS * 16;
-    constexpr int MB = (KR + 31) / 32;      // 32-row blocks of dW_x
-    constexpr int NPASS = MB;               // dx_dbl tile: 32 rows of 8 x 16-byte pieces per pass of the workgroup
+    constexpr int MB = (KS * 16 + 31) / 32;      // 32-deep k steps of the first product
+    constexpr int KP = MB * 32;                  // k padded to the matrix instructions' depth (rows beyond k are zero)
+    constexpr int NPASS = MB;                    // dx_dbl tile: 32 rows of 8 x 16-byte pieces per pass of the workgroup
     typedef __attribute__((address_space(3))) short lds_s16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, c32 = lane & 31;
-    const int b = blockIdx.z, d0w = blockIdx.y * 128, d0 = d0w + wave * 32;
+    const int b = blockIdx.z, d0w = blockIdx.y * kCD, d0 = d0w + wave * 16;
     const int L = p.seqlen, R = p.k;
     const T* const in_b = static_cast<const T*>(p.dx_dbl) + (int64_t)b * p.dxdbl_batch_stride;
-    lds_s16* const in_lds = (lds_s16*)reinterpret_cast<short*>(smem);                                                      // [MB * 32][kRowE]
-    lds_f32* const ep = (lds_f32*)reinterpret_cast<float*>(smem + MB * 32 * kRowE * 2) + wave * (32 * kEpE);               // [32][kEpE] fp32, this wave's
-    lds_s16* const co = (lds_s16*)reinterpret_cast<short*>(smem + MB * 32 * kRowE * 2 + 4 * 32 * kEpE * 4) + wave * (32 * kRowE);   // [32][kRowE], this wave's
-    lds_s16* const w_lds = (lds_s16*)reinterpret_cast<short*>(smem + MB * 32 * kRowE * 2 + 4 * 32 * kEpE * 4 + 4 * 32 * kRowE * 2);   // [KR][kWRowE]
+    lds_s16* const in_lds = (lds_s16*)reinterpret_cast<short*>(smem);                                                      // [KP][kRowE]
+    lds_f32* const ep = (lds_f32*)reinterpret_cast<float*>(smem + KP * kRowE * 2) + wave * (16 * kEpT);                    // [16][kEpT] fp32, this wave's
+    lds_s16* const co = (lds_s16*)reinterpret_cast<short*>(smem + KP * kRowE * 2 + 4 * 16 * kEpT * 4) + wave * (16 * kRowE);   // [16][kRowE], this wave's
+    lds_s16* const w_lds = (lds_s16*)reinterpret_cast<short*>(smem + KP * kRowE * 2 + 4 * 16 * kEpT * 4 + 4 * 16 * kRowE * 2);   // [KP][kWRowE]
 
     const int n_tiles = (L + kTL - 1) / kTL;
     const int t_lo = blockIdx.x * tiles_per_wg;
     const int t_hi = t_lo + tiles_per_wg < n_tiles ? t_lo + tiles_per_wg : n_tiles;
     if (t_lo >= t_hi) return;
 
-    // W_x[:, d0w .. d0w + 128) as it is stored (row k, channels contiguous), zero beyond the matrix; the A operand of the first
+    // W_x[:, d0w .. d0w + 64) as it is stored (row k, channels contiguous), zero beyond the matrix; the A operand of the first
     // product (i = channel, k strided) comes out of it through the transposing read, like the B operand out of the dx_dbl tile
     {
         const T* const wx = static_cast<const T*>(p.w_x);
-        const bool vec = p.wx_c_stride == 1 && p.wx_k_stride % 8 == 0 && aligned16_dev(wx) && d0w + 128 <= p.dim;
-        if (vec) {   // 16 lanes x 16 bytes per row: KR / 16 independent loads per thread
+        const bool vec = p.wx_c_stride == 1 && p.wx_k_stride % 8 == 0 && aligned16_dev(wx) && d0w + kCD <= p.dim;
+        if (vec) {   // 8 lanes x 16 bytes per row: KP / 32 independent loads per thread
 #pragma unroll
-            for (int it = 0; it < KR / 16; ++it) {
-                const int k = it * 16 + (tid >> 4), c = 8 * (tid & 15);
+            for (int it = 0; it < KP / 32; ++it) {
+                const int k = it * 32 + (tid >> 3), c = 8 * (tid & 7);
                 const bool okw = k < R;
                 const s16x8 v = *reinterpret_cast<const s16x8*>(wx + (int64_t)(okw ? k : 0) * p.wx_k_stride + d0w + c);
                 *reinterpret_cast<lds_s16x8*>(w_lds + k * kWRowE + c) = okw ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
             }
         } else {
-            for (int idx = tid; idx < KR * 128; idx += kPT) {
-                const int k = idx >> 7, c = idx & 127;
+            for (int idx = tid; idx < KP * kCD; idx += kPT) {
+                const int k = idx / kCD, c = idx % kCD;
                 const bool okw = k < R && d0w + c < p.dim;
                 const T v = okw ? wx[(int64_t)k * p.wx_k_stride + (int64_t)(d0w + c) * p.wx_c_stride] : static_cast<T>(0.f);
                 w_lds[k * kWRowE + c] = __builtin_bit_cast(short, v);
@@ -326,21 +351,29 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
         }
     }
 
-    // lane -> channel rows er + 16 pp (pp = 0, 1), piece q of a 32-position half tile
-    const int er = lane >> 2, q = lane & 3, ec = 8 * q;
-    const T* xrow[2];
-    const T* durow[2];
-    T* dxrow[2];
-    bool row_ok[2];
+    // A lane's pieces: 8 lanes x 16 bytes cover the 64 positions of one channel row of the tile (full 128-byte lines: with 4
+    // lanes per row every load fetched 16 half lines and the kernel streamed at 2.8 TB/s with all of its arithmetic removed);
+    // sub-step ss = 0, 1 handles channel row 8 ss + rr of the wave's 16.
+    const int rr = lane >> 3, pc = lane & 7, ec = 8 * pc;
+    // Every global access of the loop goes through a buffer resource per tensor and batch entry with an out-of-range offset
+    // for what must not be touched (rows beyond dim, positions beyond seqlen, tiles beyond the range): such loads return 0 and
+    // such stores are dropped, so NO access sits under a branch or feeds a select -- the compiler can count them and waits
+    // with s_waitcnt vmcnt(N) for exactly the loads it needs (with predicated accesses it drained everything, vmcnt(0), at
+    // every barrier: the "tile ahead" requests then had a quarter of an iteration to land and the kernel took 147 us).
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride), 0, (int)(p.dim * p.x_c_stride * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t du_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(static_cast<const T*>(p.du) + (int64_t)b * p.du_batch_stride), 0, (int)(p.dim * p.du_c_stride * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t dx_rs = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<T*>(p.dx) + (int64_t)b * p.dx_batch_stride, 0, (int)(p.dim * p.dx_c_stride * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(in_b), 0, (int)(R * p.dxdbl_k_stride * 2), kPBufFlags);
+    constexpr int kOOB = -1;    // as an unsigned byte offset: beyond every buffer
     float taps[2][4], cbias[2];
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int d = d0 + er + 16 * pp;
-        row_ok[pp] = d < p.dim;
-        const int dc = row_ok[pp] ? d : 0;
-        xrow[pp] = static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)dc * p.x_c_stride;
-        durow[pp] = static_cast<const T*>(p.du) + (int64_t)b * p.du_batch_stride + (int64_t)dc * p.du_c_stride;
-        dxrow[pp] = static_cast<T*>(p.dx) + (int64_t)b * p.dx_batch_stride + (int64_t)dc * p.dx_c_stride;
+    for (int ss = 0; ss < 2; ++ss) {
+        const int d = d0 + 8 * ss + rr;
+        const int dc = d < p.dim ? d : 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {   // taps[k] multiplies x[t - 3 + k]; widths < 4 get leading zeros (causal_conv1d.hip load_taps)
             const int w = k - (4 - p.width);
@@ -351,9 +384,9 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
                     : p.wdtype == VMS_F16 ? static_cast<float>(static_cast<const f16_t*>(p.conv_weight)[idx])
                                           : static_cast<float>(static_cast<const bf16_t*>(p.conv_weight)[idx]);
             }
-            taps[pp][k] = v;
+            taps[ss][k] = v;
         }
-        cbias[pp] = !p.conv_bias ? 0.f
+        cbias[ss] = !p.conv_bias ? 0.f
                     : p.wdtype == VMS_F32 ? static_cast<const float*>(p.conv_bias)[dc]
                     : p.wdtype == VMS_F16 ? static_cast<float>(static_cast<const f16_t*>(p.conv_bias)[dc])
                                           : static_cast<float>(static_cast<const bf16_t*>(p.conv_bias)[dc]);
@@ -368,8 +401,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = (tid >> 3) + 32 * ps;
             const bool ok = r < R && tl < L && t >= t_lo;
-            const s16x8 v = *reinterpret_cast<const s16x8*>(in_b + (int64_t)(ok ? r : 0) * p.dxdbl_k_stride + (ok ? pl : 0));
-            stg[ps] = ok ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            stg[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? (int)((r * p.dxdbl_k_stride + pl) * 2) : kOOB, 0, 0));
         }
     };
     auto stage_store = [&]() __attribute__((always_inline)) {
@@ -378,176 +410,199 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
             *reinterpret_cast<lds_s16x8*>(in_lds + ((tid >> 3) + 32 * ps) * kRowE + 8 * (tid & 7)) = stg[ps];
     };
     // transposing reads (tools/tr_probe.hip): lane i of a 16-lane group supplies row i / 4, columns 4 (i % 4) .. + 3 of a
-    // [4][16] block and receives column i of its 4 rows
+    // [4][16] block and receives column i of its 4 rows.  16x16x32 operands: lane -> (row / column lane & 15, k = 8 (lane >> 4) .. + 7)
     const int i16 = lane & 15, g16 = lane >> 4;
-    const lds_s16* const tb = in_lds + (8 * (g16 >> 1) + (i16 >> 2)) * kRowE + 16 * (g16 & 1) + 4 * (i16 & 3);
-    const lds_s16* const ta = w_lds + (8 * (g16 >> 1) + (i16 >> 2)) * kWRowE + wave * 32 + 16 * (g16 & 1) + 4 * (i16 & 3);
+    const lds_s16* const tb = in_lds + (8 * g16 + (i16 >> 2)) * kRowE + 4 * (i16 & 3);
+    const lds_s16* const ta = w_lds + (8 * g16 + (i16 >> 2)) * kWRowE + wave * 16 + 4 * (i16 & 3);
 
-    f32x16 accw[MB];
+    f32x4 accw[KP / 16];    // dW_x[16 mb + 4 g16 + v][d0 + i16]
 #pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
+    for (int mb = 0; mb < KP / 16; ++mb) accw[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float dwacc[2][4], dbacc[2], carry[2][3];   // carry: SiLU' g of the first 3 positions after this row's last piece (piece-0 lanes)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) accw[mb][v] = 0.f;
-    float dwacc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dbacc[2] = {0.f, 0.f};
-    float carry[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // SiLU' g of the first 3 positions of the piece after this quad's last one
+    for (int ss = 0; ss < 2; ++ss) {
+        dbacc[ss] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dwacc[ss][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) carry[ss][k] = 0.f;
+    }
 
-    // This lane's four pieces of a tile in processing order ss = 0..3: half j = 1 - (ss >> 1) (from the end of the logical tile),
-    // rows er + 16 (ss & 1).  Their x / du vectors are requested a whole tile ahead: set ss is refilled for tile t - 1 as soon as
-    // its values for tile t have been widened (a piece one step ahead left every piece waiting for HBM: 165 us per call).
+    // The x / du vectors of a tile's two pieces are requested a whole tile ahead, at the top of the previous iteration, and
+    // WIDENED at its bottom: nothing loaded is carried across the loop's back edge (hipcc waits for loop-carried loads with a
+    // full s_waitcnt vmcnt(0) at the loop head, which also drains the dx stores of the iteration), so the waits are counted
+    // and leave the stores in flight.
     struct Raw { vec_t<T, 8> x, du; vec_t<T, 4> xh; };
-    Raw raw[4];
+    Raw raw[2];
+    float xvc[2][8 + 3], duc[2][8];     // inputs t - 3 .. t + 7 and du of the piece, logical order, of the tile being processed
+    auto widen = [&](int ss) __attribute__((always_inline)) {
+        // logical order: element i of the piece is physical element (REV ? 7 - i : i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) xvc[ss][k] = static_cast<float>(raw[ss].xh[REV ? 2 - k : 1 + k]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xvc[ss][3 + i] = static_cast<float>(raw[ss].x[REV ? 7 - i : i]);
+            duc[ss][i] = static_cast<float>(raw[ss].du[REV ? 7 - i : i]);
+        }
+    };
     auto piece_load = [&](Raw& r, int t, int ss) __attribute__((always_inline)) {
-        const int j = 1 - (ss >> 1), pp = ss & 1;
-        const int tl = t * kTL + 32 * j + ec;
+        const int d = d0 + 8 * ss + rr;
+        const int tl = t * kTL + ec;
         const int pl = REV ? L - tl - 8 : tl;
-        const bool okp = row_ok[pp] && tl < L && t >= t_lo;
-        const int po = okp ? pl : 0;
-        r.x = *reinterpret_cast<const vec_t<T, 8>*>(xrow[pp] + po);
-        r.du = *reinterpret_cast<const vec_t<T, 8>*>(durow[pp] + po);
-        // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left
-        const bool hok = okp && tl > 0;
-        r.xh = *reinterpret_cast<const vec_t<T, 4>*>(xrow[pp] + (hok ? (REV ? pl + 8 : pl - 4) : 0));
-        if (!hok) r.xh = vec_t<T, 4>{static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f), static_cast<T>(0.f)};
+        const bool okp = d < p.dim && tl < L && t >= t_lo;
+        const int xo = (int)((d * p.x_c_stride + pl) * 2);
+        r.x = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(x_rs, okp ? xo : kOOB, 0, 0));
+        r.du = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(du_rs, okp ? (int)((d * p.du_c_stride + pl) * 2) : kOOB, 0, 0));
+        // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left; zeros before the row
+        r.xh = __builtin_bit_cast(vec_t<T, 4>, __builtin_amdgcn_raw_buffer_load_b64(x_rs, okp && tl > 0 ? xo + (REV ? 16 : -8) : kOOB, 0, 0));
     };
 
     // the tile after the range only feeds `carry`
     const int t_first = t_hi < n_tiles ? t_hi : t_hi - 1;
     stage_load(t_first);
 #pragma unroll
-    for (int ss = 0; ss < 4; ++ss) piece_load(raw[ss], t_first, ss);
+    for (int ss = 0; ss < 2; ++ss) piece_load(raw[ss], t_first, ss);
+    stage_store();
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) widen(ss);
     for (int t = t_first; t >= t_lo; --t) {
         const bool emit = t < t_hi;
-        stage_store();
         __syncthreads();          // tile t (and, the first time, the W_x tile) is in LDS
-        stage_load(t - 1);        // travels during the rest of the iteration
+        stage_load(t - 1);        // travel during the rest of the iteration
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) piece_load(raw[ss], t - 1, ss);
+        const int tl = t * kTL + ec;
+        const int pl = REV ? L - tl - 8 : tl;
         vec_t<T, 8> dxold[2];
-        auto dxold_load = [&](int ss) __attribute__((always_inline)) {
-            const int j = 1 - (ss >> 1), pp = ss & 1;
-            const int tl = t * kTL + 32 * j + ec;
-            const bool okp = row_ok[pp] && tl < L;
-            dxold[ss & 1] = *reinterpret_cast<const vec_t<T, 8>*>(dxrow[pp] + (okp ? (REV ? L - tl - 8 : tl) : 0));
-        };
-        if (p.dx_accumulate && emit) dxold_load(0);
+        if (DXACC) {
 #pragma unroll
-        for (int ss = 0; ss < 4; ++ss) {
-            const int j = 1 - (ss >> 1), pp = ss & 1;
-            if (p.dx_accumulate && emit && ss < 3) dxold_load(ss + 1);
-            if (pp == 0) {
-                // first product for this half: T[d][l], this wave's 32 channels x 32 positions, into the wave's fp32 tile
-                f32x16 acc;
+            for (int ss = 0; ss < 2; ++ss) {
+                const int d = d0 + 8 * ss + rr;
+                const bool okp = d < p.dim && tl < L && emit;
+                dxold[ss] = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(dx_rs, okp ? (int)((d * p.dx_c_stride + pl) * 2) : kOOB, 0, 0));
+            }
+        }
+        {
+            // first product: this wave's 16 channels x the tile's 64 positions, into the wave's fp32 tile
+            f32x4 acc[4];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (16 * s) * kWRowE));
-                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (16 * s + 4) * kWRowE));
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s) * kRowE + 32 * j));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (16 * s + 4) * kRowE + 32 * j));
-                    const s16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int s = 0; s < MB; ++s) {
+                const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s) * kWRowE));
+                const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s + 4) * kWRowE));
+                const s16x8 af = __builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s) * kRowE + 16 * nb));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s + 4) * kRowE + 16 * nb));
                     const s16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc = Mfma32<T>::run(af, bf, acc);
+                    acc[nb] = Mfma16<T>::run(af, bf, acc[nb]);
                 }
-                lds_order();   // the previous half's reads of `ep` are done
-#pragma unroll
-                for (int v = 0; v < 16; ++v) ep[((v & 3) + 8 * (v >> 2) + 4 * h) * kEpE + c32] = acc[v];
-                lds_order();
             }
-            const int tl = t * kTL + 32 * j + ec;
-            const bool okp = row_ok[pp] && tl < L;
-            float xv[8 + 3], gp[8 + 3];     // inputs t - 3 .. t + 7 and SiLU' g of t .. t + 10, logical order
-            float duf[8];
-            // logical order: element i of the piece is physical element (REV ? 7 - i : i)
+            lds_order();   // the previous tile's reads of `ep` are done
+            // C layout: column = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-            for (int k = 0; k < 3; ++k) xv[k] = static_cast<float>(raw[ss].xh[REV ? 2 - k : 1 + k]);
+            for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                xv[3 + i] = static_cast<float>(raw[ss].x[REV ? 7 - i : i]);
-                duf[i] = static_cast<float>(raw[ss].du[REV ? 7 - i : i]);
-            }
-            asm volatile("" ::: "memory");     // keeps the refill below the widening (same registers)
-            piece_load(raw[ss], t - 1, ss);
-            const lds_f32x4* src = (const lds_f32x4*)(ep + (er + 16 * pp) * kEpE + ec);
+                for (int v = 0; v < 4; ++v) ep[(4 * g16 + v) * kEpT + 16 * nb + i16] = acc[nb][v];
+            lds_order();
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+            const int d = d0 + 8 * ss + rr;
+            const bool okp = d < p.dim && tl < L;
+            float gp[8 + 3];                 // SiLU' g of t .. t + 10, logical order
+            const float (&xv)[8 + 3] = xvc[ss];
+            const float (&duf)[8] = duc[ss];
+            const lds_f32x4* src = (const lds_f32x4*)(ep + (8 * ss + rr) * kEpT + ec);
             const f32x4 tq0 = src[0], tq1 = src[1];
             const float tv[8] = {tq0.x, tq0.y, tq0.z, tq0.w, tq1.x, tq1.y, tq1.z, tq1.w};
             vec_t<T, 8> cov;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int e = REV ? 7 - i : i;
-                float pre = cbias[pp];
+                float pre = cbias[ss];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) pre = fmaf(taps[pp][k], xv[i + k], pre);
+                for (int k = 0; k < 4; ++k) pre = fmaf(taps[ss][k], xv[i + k], pre);
                 const float sg = sigmoidf_(pre);
                 const float g = tv[e] + duf[i];
                 gp[i] = okp ? g * (sg * (1.f + pre * (1.f - sg))) : 0.f;
                 cov[e] = static_cast<T>(okp ? pre * sg : 0.f);
             }
-            *reinterpret_cast<__attribute__((address_space(3))) vec_t<T, 8>*>(co + (er + 16 * pp) * kRowE + 32 * j + ec) = cov;
-            // the next piece's first three values: lane + 1 of the quad; the last piece of the half takes what piece 0 of the
-            // previously processed half (or tile) left in `carry`
+            *reinterpret_cast<__attribute__((address_space(3))) vec_t<T, 8>*>(co + (8 * ss + rr) * kRowE + ec) = cov;
+            // the next piece's first three values: lane + 1 (the 8 lanes of a channel row are contiguous); the row's last piece
+            // takes what piece 0 of the previously processed tile left in `carry` (7 lanes down)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const float v = q == 0 ? carry[pp][k] : gp[k];
-                gp[8 + k] = dpp_mov<0x39, 0xf>(0.f, v);   // quad_perm [1, 2, 3, 0]
-                carry[pp][k] = gp[k];
+                const float fromnext = dpp_mov<DPP_ROW_SHL1, 0xf>(0.f, gp[k]);
+                const float fromcarry = dpp_mov<0x117, 0xf>(0.f, carry[ss][k]);   // row_shr:7
+                gp[8 + k] = pc == 7 ? fromcarry : fromnext;
+                carry[ss][k] = gp[k];
             }
-            if (emit) {
+            {
                 vec_t<T, 8> o;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int e = REV ? 7 - i : i;
                     float a = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) a = fmaf(taps[pp][k], gp[i + 3 - k], a);
-                    if (p.dx_accumulate) a += static_cast<float>(dxold[ss & 1][e]);
+                    for (int k = 0; k < 4; ++k) a = fmaf(taps[ss][k], gp[i + 3 - k], a);
+                    if (DXACC) a += static_cast<float>(dxold[ss][e]);
                     o[e] = static_cast<T>(a);
-                    dbacc[pp] += gp[i];
+                    const float ge = emit ? gp[i] : 0.f;    // the tile after the range contributes nothing
+                    dbacc[ss] += ge;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) dwacc[pp][k] = fmaf(xv[i + k], gp[i], dwacc[pp][k]);
+                    for (int k = 0; k < 4; ++k) dwacc[ss][k] = fmaf(xv[i + k], ge, dwacc[ss][k]);
                 }
-                if (okp) *reinterpret_cast<vec_t<T, 8>*>(dxrow[pp] + (REV ? L - tl - 8 : tl)) = o;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, o), dx_rs, okp && emit ? (int)((d * p.dx_c_stride + pl) * 2) : kOOB, 0, 0);
             }
         }
         // second product: dW_x[r][d] += sum_l dx_dbl[r][l] conv1d_out[d][l] over the tile (same column order in both tiles)
         if (emit) {
             lds_order();
-            const lds_s16* const pa = in_lds + c32 * kRowE + 8 * h;
-            const lds_s16* const qa = co + c32 * kRowE + 8 * h;
+            const lds_s16* const pa = in_lds + i16 * kRowE + 8 * g16;
+            const lds_s16* const qa = co + i16 * kRowE + 8 * g16;
 #pragma unroll
-            for (int s = 0; s < kTL / 16; ++s) {
-                const s16x8 bq = *reinterpret_cast<const lds_s16x8*>(qa + 16 * s);
+            for (int s = 0; s < kTL / 32; ++s) {
+                const s16x8 bq = *reinterpret_cast<const lds_s16x8*>(qa + 32 * s);
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const s16x8 ap = *reinterpret_cast<const lds_s16x8*>(pa + 32 * mb * kRowE + 16 * s);
-                    accw[mb] = Mfma32<T>::run(ap, bq, accw[mb]);
+                for (int mb = 0; mb < KP / 16; ++mb) {
+                    const s16x8 ap = *reinterpret_cast<const lds_s16x8*>(pa + 16 * mb * kRowE + 32 * s);
+                    accw[mb] = Mfma16<T>::run(ap, bq, accw[mb]);
                 }
             }
         }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) widen(ss);   // the next tile's inputs (the loads of this iteration's top)
         __syncthreads();          // every wave has read tile t: the dx_dbl buffer may be overwritten
+        stage_store();
     }
     // dW_x: one atomic per (r, channel) and workgroup
     {
-        const int d = d0 + c32;
+        const int d = d0 + i16;
         if (d < p.dim) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < KP / 16; ++mb)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = 32 * mb + (v & 3) + 8 * (v >> 2) + 4 * h;
+                for (int v = 0; v < 4; ++v) {
+                    const int m = 16 * mb + 4 * g16 + v;
                     if (m < R) atomicAdd(p.dw_x + (int64_t)m * p.dwx_k_stride + d, accw[mb][v]);
                 }
         }
     }
-    // conv dweight / dbias: the 4 lanes of a quad hold one channel's partial sums
+    // conv dweight / dbias: the 8 lanes of a channel row hold its partial sums
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        float v[5] = {dwacc[pp][0], dwacc[pp][1], dwacc[pp][2], dwacc[pp][3], dbacc[pp]};
+    for (int ss = 0; ss < 2; ++ss) {
+        float v[5] = {dwacc[ss][0], dwacc[ss][1], dwacc[ss][2], dwacc[ss][3], dbacc[ss]};
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            v[k] += dpp_mov<0xB1, 0xf>(0.f, v[k]);   // quad_perm [1, 0, 3, 2]
-            v[k] += dpp_mov<0x4E, 0xf>(0.f, v[k]);   // quad_perm [2, 3, 0, 1]
+            v[k] += dpp_mov<DPP_ROW_SHL1, 0xf>(0.f, v[k]);
+            v[k] += dpp_mov<DPP_ROW_SHL2, 0xf>(0.f, v[k]);
+            v[k] += dpp_mov<DPP_ROW_SHL4, 0xf>(0.f, v[k]);
         }
-        if (q == 0 && row_ok[pp]) {
-            const int d = d0 + er + 16 * pp;
+        const int d = d0 + 8 * ss + rr;
+        if (pc == 0 && d < p.dim) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int wi = k - (4 - p.width);
@@ -558,11 +613,11 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
     }
 }
 
-template <typename T, int KS>
+template <typename T, int KS, bool DXACC>
 __global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg) {
     const bool rev = p.reverse != 0 || (p.reverse_from > 0 && (int)blockIdx.z >= p.reverse_from);   // workgroup-uniform
-    if (rev) proj_conv_bwd_body<T, KS, true>(p, tiles_per_wg);
-    else proj_conv_bwd_body<T, KS, false>(p, tiles_per_wg);
+    if (rev) proj_conv_bwd_body<T, KS, true, DXACC>(p, tiles_per_wg);
+    else proj_conv_bwd_body<T, KS, false, DXACC>(p, tiles_per_wg);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -633,26 +688,29 @@ template <typename T, int KS>
 static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream) {
     constexpr int MB = (KS * 16 + 31) / 32;
     const int n_tiles = (p.seqlen + kTL - 1) / kTL;
-    const int d_tiles = (p.dim + 127) / 128;
-    // ~2 workgroups per CU; every workgroup pays one extra tile (the carry) and dim-tile x k atomics at its end
-    const int64_t want = 2 * (int64_t)device_cu_count();
+    const int d_tiles = (p.dim + kCD - 1) / kCD;
+    // ~4 workgroups per CU (3 resident); every workgroup pays one extra tile (the carry) and 64 x k atomics at its end
+    const int64_t want = 4 * (int64_t)device_cu_count();
     int tpw = (int)(((int64_t)n_tiles * d_tiles * p.batch + want - 1) / want);
     if (tpw < 8) tpw = 8;
     if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
     if (tpw > n_tiles) tpw = n_tiles;
     const dim3 grid((n_tiles + tpw - 1) / tpw, d_tiles, p.batch), block(kPT);
-    const size_t smem = (size_t)MB * 32 * kRowE * 2 + (size_t)4 * 32 * kEpE * sizeof(float) + (size_t)4 * 32 * kRowE * 2 + (size_t)KS * 16 * kWRowE * 2;
+    const size_t smem = (size_t)MB * 32 * kRowE * 2 + (size_t)4 * 16 * kEpT * sizeof(float) + (size_t)4 * 16 * kRowE * 2 + (size_t)MB * 32 * kWRowE * 2;
     if (smem > 64 * 1024) {   // k > 64: 76 KB, admitted per kernel and per device before the first launch there
         static PerDeviceOnce attr_once;
         const hipError_t arc = attr_once.run([&]() -> hipError_t {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e2 != hipSuccess) return e2;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         });
         if (arc != hipSuccess) {
             set_error("hipFuncSetAttribute(proj_conv_bwd, %zu bytes of LDS) failed: %s", smem, hipGetErrorString(arc));
             return VMS_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS>), grid, block, smem, stream, p, tpw);
+    if (p.dx_accumulate) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, true>), grid, block, smem, stream, p, tpw);
+    else hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, false>), grid, block, smem, stream, p, tpw);
     VMS_LAUNCH_CHECK();
     set_last_kernel("proj_conv_bwd");
     return VMS_OK;
@@ -713,6 +771,12 @@ extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* strea
     VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
     VMS_CHECK(p.x && p.du && p.dx_dbl && p.w_x && p.conv_weight && p.dx && p.dconv_weight && p.dw_x, "x, du, dx_dbl, w_x, conv_weight, dx, dconv_weight, dw_x are required");
     VMS_CHECK(!(p.reverse && p.reverse_from), "reverse and reverse_from are exclusive");
+    {
+        const int64_t lim = (int64_t)1 << 31;   // a batch entry of each tensor is addressed through one buffer resource
+        VMS_CHECK(p.dim * p.x_c_stride * 2 < lim && p.dim * p.du_c_stride * 2 < lim && p.dim * p.dx_c_stride * 2 < lim && p.k * p.dxdbl_k_stride * 2 < lim &&
+                      p.x_c_stride >= p.seqlen && p.du_c_stride >= p.seqlen && p.dx_c_stride >= p.seqlen && p.dxdbl_k_stride >= p.seqlen,
+                  "proj_conv_bwd: a batch entry (dim * channel stride) must span < 2 GiB, rows must not overlap");
+    }
     VMS_CHECK(p.seqlen % 8 == 0 && p.x_batch_stride % 8 == 0 && p.x_c_stride % 8 == 0 && p.du_batch_stride % 8 == 0 && p.du_c_stride % 8 == 0 &&
                   p.dx_batch_stride % 8 == 0 && p.dx_c_stride % 8 == 0 && p.dxdbl_batch_stride % 8 == 0 && p.dxdbl_k_stride % 8 == 0 &&
                   aligned16(p.x) && aligned16(p.du) && aligned16(p.dx) && aligned16(p.dx_dbl),
