@@ -563,8 +563,9 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
                                    segments, Bv, Cv, reverse_from);
     Tensor dconv_out = *g[0], ddelta = *g[1];
     Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
-    dx_dbl.narrow(1, R, N).copy_(g[3]->squeeze(1));
-    dx_dbl.narrow(1, R + N, N).copy_(g[4]->squeeze(1));
+    // dB and dC sit back to back in the zero-filled buffer (scan_bwd carves dA, dB, dC, ...): one cast kernel for both
+    dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)})
+        .copy_(zeros.narrow(0, A.numel(), 2 * Bv.numel()).view({2, b, N, dx_dbl.size(2)}).permute({1, 0, 2, 3}));
     Tensor ddt_proj_w, dx_proj_w;
     if (mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
         Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({R, d});                  // (R, d) = ddt_proj_w^T
@@ -573,7 +574,10 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
     } else {
         ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
     }
-    dx_dbl.narrow(1, 0, R).copy_(at::matmul(dt_proj_w.t(), ddelta));                        // (b, R, l)
+    {   // (b, R, l) = W_dt^T ddelta, written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
+        Tensor d_dt = dx_dbl.narrow(1, 0, R);
+        at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
+    }
     if (fused_tail) {
         // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
         Tensor dwx = zeros.narrow(0, n_scan + n_conv + n_proj, K2 * d).view({K2, d});
