@@ -73,6 +73,9 @@ def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, g
         "vms_selective_scan_bwd": (9 if bwd_out_z else 8) * bdl * s + bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4,
         "vms_causal_conv1d_fwd": 2 * bdl * s + dim * (w + 1) * 4,
         "vms_causal_conv1d_bwd": 3 * bdl * s + 2 * dim * (w + 1) * 4,
+        # the fused backward tail (SSI:278-283 in one pass): x and du read, dx written (+ dx read when it
+        # accumulates the other direction's gradient: not counted), dx_dbl (R + 2N rows) read, the weights and fp32 accumulators
+        "vms_proj_conv_bwd": 3 * bdl * s + batch * (-(-dim // 16) + 2 * n) * seqlen * s + (dim * (w + 1) + (-(-dim // 16) + 2 * n) * dim) * 4,
     }
 
 
@@ -497,6 +500,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                                "traffic_source": (f"{src}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel at this "
                                                   "size, committed profile (not measured in this run)") if src else None,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+            if dom == "vms_selective_scan_bwd":   # SURVEY 8d also counts an out_z rewrite (9 B D L s) the blocks' nodes never ask for
+                ab8 = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l, bwd_out_z=True)[dom]
+                res["roofline"]["algorithmic_bytes_survey_8d"] = ab8
+                res["roofline"]["frac_survey_8d"] = ab8 / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if on_gpu and world == 1 and projections and config == "block":
             res["projections"] = projection_mfma(block, hidden)
         if world == 1 and cpu_base:
