@@ -308,14 +308,22 @@ template <> struct Mfma16<f16_t> {
 };
 
 template <typename T, int KS, bool REV, bool DXACC>
-__device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg) {
+__device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg, const int2 p_grid) {
     constexpr int MB = (KS * 16 + 31) / 32;      // 32-deep k steps of the first product
     constexpr int KP = MB * 32;                  // k padded to the matrix instructions' depth (rows beyond k are zero)
     constexpr int NPASS = MB;                    // dx_dbl tile: 32 rows of 8 x 16-byte pieces per pass of the workgroup
     typedef __attribute__((address_space(3))) short lds_s16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, d0w = blockIdx.y * kCD, d0 = d0w + wave * 16;
+    // 1-D grid, decoded so that the workgroups that share a dx_dbl range -- the channel tiles of one (batch entry, range of
+    // positions) -- run on ONE XCD (workgroup id % 8 on this chip) and re-read it from that XCD's L2: with a (ranges, channel
+    // tiles, batch) grid they were spread over all 8 and every L2 fetched its own copy (FETCH_SIZE 394 MB for 281 MB of inputs)
+    // (consecutive ids of one XCD = the channel tiles of one range: they are resident together)
+    const int n_rng = p_grid.x, n_dt = p_grid.y, n_pairs = n_rng * p.batch;
+    const int slot = (int)blockIdx.x >> 3, pair = (slot / n_dt) * 8 + ((int)blockIdx.x & 7);
+    if (pair >= n_pairs) return;
+    const int bid_x = pair % n_rng, b = pair / n_rng, bid_y = slot % n_dt;
+    const int d0w = bid_y * kCD, d0 = d0w + wave * 16;
     const int L = p.seqlen, R = p.k;
     const T* const in_b = static_cast<const T*>(p.dx_dbl) + (int64_t)b * p.dxdbl_batch_stride;
     lds_s16* const in_lds = (lds_s16*)reinterpret_cast<short*>(smem);                                                      // [KP][kRowE]
@@ -324,7 +332,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
     lds_s16* const w_lds = (lds_s16*)reinterpret_cast<short*>(smem + KP * kRowE * 2 + 4 * 16 * kEpT * 4 + 4 * 16 * kRowE * 2);   // [KP][kWRowE]
 
     const int n_tiles = (L + kTL - 1) / kTL;
-    const int t_lo = blockIdx.x * tiles_per_wg;
+    const int t_lo = bid_x * tiles_per_wg;
     const int t_hi = t_lo + tiles_per_wg < n_tiles ? t_lo + tiles_per_wg : n_tiles;
     if (t_lo >= t_hi) return;
 
@@ -486,8 +494,6 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
             // first product: this wave's 16 channels x the tile's 64 positions, into the wave's fp32 tile
             f32x4 acc[4];
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
             for (int s = 0; s < MB; ++s) {
                 const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s) * kWRowE));
                 const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s + 4) * kWRowE));
@@ -497,7 +503,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s) * kRowE + 16 * nb));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s + 4) * kRowE + 16 * nb));
                     const s16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[nb] = Mfma16<T>::run(af, bf, acc[nb]);
+                    acc[nb] = Mfma16<T>::run(af, bf, s == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[nb]);
                 }
             }
             lds_order();   // the previous tile's reads of `ep` are done
@@ -526,9 +532,12 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
 #pragma unroll
                 for (int k = 0; k < 4; ++k) pre = fmaf(taps[ss][k], xv[i + k], pre);
                 const float sg = sigmoidf_(pre);
+                // beyond the row / the sequence every load returned 0: T = 0 (zero dx_dbl columns, zero W_x rows), du = 0, so
+                // g = 0 and gp = 0 without a select; conv1d_out is silu(bias) there but meets a zero dx_dbl column (or a dW_x
+                // column that is never written) in the second product
                 const float g = tv[e] + duf[i];
-                gp[i] = okp ? g * (sg * (1.f + pre * (1.f - sg))) : 0.f;
-                cov[e] = static_cast<T>(okp ? pre * sg : 0.f);
+                gp[i] = g * (sg * (1.f + pre * (1.f - sg)));
+                cov[e] = static_cast<T>(pre * sg);
             }
             *reinterpret_cast<__attribute__((address_space(3))) vec_t<T, 8>*>(co + (8 * ss + rr) * kRowE + ec) = cov;
             // the next piece's first three values: lane + 1 (the 8 lanes of a channel row are contiguous); the row's last piece
@@ -550,10 +559,14 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
                     for (int k = 0; k < 4; ++k) a = fmaf(taps[ss][k], gp[i + 3 - k], a);
                     if (DXACC) a += static_cast<float>(dxold[ss][e]);
                     o[e] = static_cast<T>(a);
-                    const float ge = emit ? gp[i] : 0.f;    // the tile after the range contributes nothing
-                    dbacc[ss] += ge;
+                }
+                if (emit) {     // the tile after the range contributes nothing (wave-uniform branch, no memory access under it)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) dwacc[ss][k] = fmaf(xv[i + k], ge, dwacc[ss][k]);
+                    for (int i = 0; i < 8; ++i) {
+                        dbacc[ss] += gp[i];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dwacc[ss][k] = fmaf(xv[i + k], gp[i], dwacc[ss][k]);
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, o), dx_rs, okp && emit ? (int)((d * p.dx_c_stride + pl) * 2) : kOOB, 0, 0);
             }
@@ -614,10 +627,13 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
 }
 
 template <typename T, int KS, bool DXACC>
-__global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg) {
-    const bool rev = p.reverse != 0 || (p.reverse_from > 0 && (int)blockIdx.z >= p.reverse_from);   // workgroup-uniform
-    if (rev) proj_conv_bwd_body<T, KS, true, DXACC>(p, tiles_per_wg);
-    else proj_conv_bwd_body<T, KS, false, DXACC>(p, tiles_per_wg);
+__global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg, const int2 p_grid) {
+    // the batch entry of this workgroup (same decode as in the body) decides the direction: workgroup-uniform
+    const int pair = (((int)blockIdx.x >> 3) / p_grid.y) * 8 + ((int)blockIdx.x & 7);
+    const int b = pair / p_grid.x;    // >= batch for the padding workgroups of the last group of 8, which return at once
+    const bool rev = p.reverse != 0 || (p.reverse_from > 0 && b >= p.reverse_from);
+    if (rev) proj_conv_bwd_body<T, KS, true, DXACC>(p, tiles_per_wg, p_grid);
+    else proj_conv_bwd_body<T, KS, false, DXACC>(p, tiles_per_wg, p_grid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -696,7 +712,9 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
     if (tpw < 8) tpw = 8;
     if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
     if (tpw > n_tiles) tpw = n_tiles;
-    const dim3 grid((n_tiles + tpw - 1) / tpw, d_tiles, p.batch), block(kPT);
+    const int n_rng = (n_tiles + tpw - 1) / tpw;
+    const int2 pg = make_int2(n_rng, d_tiles);
+    const dim3 grid(8 * ((n_rng * p.batch + 7) / 8) * d_tiles), block(kPT);
     const size_t smem = (size_t)MB * 32 * kRowE * 2 + (size_t)4 * 16 * kEpT * sizeof(float) + (size_t)4 * 16 * kRowE * 2 + (size_t)MB * 32 * kWRowE * 2;
     if (smem > 64 * 1024) {   // k > 64: 76 KB, admitted per kernel and per device before the first launch there
         static PerDeviceOnce attr_once;
@@ -710,8 +728,8 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
             return VMS_ERR_LAUNCH;
         }
     }
-    if (p.dx_accumulate) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, true>), grid, block, smem, stream, p, tpw);
-    else hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, false>), grid, block, smem, stream, p, tpw);
+    if (p.dx_accumulate) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, true>), grid, block, smem, stream, p, tpw, pg);
+    else hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, false>), grid, block, smem, stream, p, tpw, pg);
     VMS_LAUNCH_CHECK();
     set_last_kernel("proj_conv_bwd");
     return VMS_OK;
