@@ -283,10 +283,10 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
 // its range without storing anything.  Right-to-left rows (reverse / reverse_from) use the same code on mirrored addresses:
 // a piece is kept in PHYSICAL element order everywhere (LDS tiles, MFMA columns) and read through (REV ? 7 - i : i) where the
 // conv needs logical order.
-// Where the time goes (profiles/r03_small_gemms.md): 2 waves per SIMD (203-240 VGPRs: the dW_x accumulators, a tile of requests
-// in flight, the conv's working set); with its parts removed the kernel takes 77 us (loads + barriers only, one tile of
-// requests per workgroup = latency-bound at 3.5 TB/s) + 31 (stores) + 33 (arithmetic) = its 130-150 us at (8, 1024, 8192):
-// the parts do not overlap at this occupancy.  A 3-waves-per-SIMD build spills (143 registers) and is 2.7x slower.
+// Where the time goes (profiles/r03_small_gemms.md, r03_sq_tail.md): 2 waves per SIMD (176-188 VGPRs: the dW_x accumulators, a
+// tile of requests in flight, the conv's working set), the VALU pipe 72 % busy with 36 instructions per element (the stand-alone
+// conv backward: 34), HBM traffic 1.20x the algorithmic bytes: bound by vector issue, 114-119 us at (8, 1024, 8192) where its
+// three passes would take 75 at the chip's streaming rate.  A 3-waves-per-SIMD build spills and is slower.
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPBufFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format (as causal_conv1d.hip)
 constexpr int kCD = 64;             // channels per workgroup of proj_conv_bwd (16 per wave)
