@@ -224,3 +224,46 @@ def test_proj_conv_bwd_vs_reference(shape, dtype, mode):
     # conv1d_out enters dW_x rounded to the 16-bit dtype; the kernel's sigmoid (v_exp / v_rcp) and torch's differ in the last
     # fp32 bit, which flips the rounding of a few elements: ~1e-4 of the sum
     assert rel(dW, r_dW) <= 1e-3, f"dW_x rel err {rel(dW, r_dW):.3e}"
+
+
+def test_proj_conv_bwd_random_shapes():
+    """40 seeded random problems (batch 1-3, dim 8-300, k 33-96, seqlen a multiple of 8 up to 1,000, width 2-4, every direction
+    mode, +-bias, +-dx_accumulate, strided channel-half views) against the fp64 statement: tile edges, channel tails, the carry
+    across tiles and across workgroup ranges (tiles_per_wg forced small)."""
+    vms = _vms()
+    import random
+    rng = random.Random(1234)
+    for case in range(40):
+        b, d = rng.randint(1, 3), rng.randint(8, 300)
+        k, L, W = rng.randint(33, 96), 8 * rng.randint(1, 125), rng.randint(2, 4)
+        mode = rng.choice(["fwd", "rev", "mixed"]) if b > 1 else rng.choice(["fwd", "rev"])
+        acc, has_bias, dtype = rng.random() < 0.5, rng.random() < 0.7, rng.choice([torch.bfloat16, torch.float16])
+        tpw = rng.choice([0, 1, 2, 3])
+        torch.manual_seed(case)
+        xz = torch.randn(b, 2 * d, L, device=DEV).to(dtype)
+        x, du = xz[:, :d, :], torch.randn(b, d, L, device=DEV).to(dtype)
+        dx_dbl = (torch.randn(b, k, L, device=DEV) * 0.5).to(dtype)
+        w_x = (torch.randn(k, d, device=DEV) * d ** -0.5).to(dtype)
+        conv_w = torch.randn(d, W, device=DEV) * 0.4
+        conv_b = torch.randn(d, device=DEV) * 0.2 if has_bias else None
+        dxz = torch.randn(b, 2 * d, L, device=DEV).to(dtype)
+        dx = dxz[:, :d, :]
+        old, z_before = dx.clone(), dxz[:, d:, :].clone()
+        dcw, dW = torch.zeros(d, W, device=DEV), torch.zeros(k, d, device=DEV)
+        dcb = torch.zeros(d, device=DEV) if has_bias else None
+        rf = rng.randint(1, b - 1) if mode == "mixed" else 0
+        rev_rows = [mode == "rev" or (mode == "mixed" and i >= rf) for i in range(b)]
+        vms.proj_conv_bwd(x, du, dx_dbl, w_x, conv_w, conv_b, dx, dcw, dcb, dW, reverse=mode == "rev", reverse_from=rf,
+                          dx_accumulate=acc, tiles_per_wg=tpw)
+        r_dx, r_dcw, r_dcb, r_dW = _conv_tail_reference(x, du, dx_dbl, w_x, conv_w, conv_b, rev_rows)
+        if acc:
+            r_dx = r_dx + old.double()
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        rel = lambda a, r: (a.double() - r).abs().max().item() / max(r.abs().max().item(), 1e-9)
+        tag = f"case {case}: b={b} d={d} k={k} L={L} W={W} {mode} rf={rf} acc={acc} bias={has_bias} {dtype} tpw={tpw}"
+        assert rel(dx, r_dx) <= eps * 1.5, f"{tag}: dx rel err {rel(dx, r_dx):.3e}"
+        assert torch.equal(dxz[:, d:, :], z_before), f"{tag}: the z half of dxz was touched"
+        assert rel(dcw, r_dcw) <= 1e-3, f"{tag}: dconv_w rel err {rel(dcw, r_dcw):.3e}"
+        if has_bias:
+            assert rel(dcb, r_dcb) <= 1e-3, f"{tag}: dconv_b rel err {rel(dcb, r_dcb):.3e}"
+        assert rel(dW, r_dW) <= 2e-3, f"{tag}: dW_x rel err {rel(dW, r_dW):.3e}"

@@ -265,7 +265,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     out_w = out_bias = None
     # the weight gradients' partial sums over the batch are added in the PARAMETERS' dtype (fp32 under autocast): autograd
     # then has nothing to cast
-    ctx.w_dtype = x_proj_weight.dtype
+    ctx.w_dtype = getattr(ctx, "w_dtype_override", None) or x_proj_weight.dtype
     if out_proj is not None:
         x_proj_weight, delta_proj_weight, out_w, out_bias = _autocast_weights(
             x_proj_weight, delta_proj_weight, out_proj[0], out_proj[1])
@@ -501,6 +501,7 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
     def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
         n = BiMambaInnerFnNoOutProj.N_PER_DIR
         assert len(params) == 2 * n
+        param_dtype = params[2].dtype
         if torch.is_autocast_enabled():  # the four small projection weights of both directions: one cast kernel
             params = list(params)
             idx = [2, 3, n + 2, n + 3]
@@ -514,6 +515,7 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         for i in range(2):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
             sub = _SubCtx()
+            sub.w_dtype_override = param_dtype   # the PARAMETERS' dtype, not that of the autocast copies made above
             # the second direction's scan adds its gated output to the first's
             out = _inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
                                  delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out)
