@@ -160,7 +160,9 @@ def test_inner_node_variants_vs_library(shape, variant, reverse, monkeypatch):
 
 # (batch, dim, k, seqlen, width)
 CONV_BWD_SHAPES = [(2, 256, 96, 1024, 4), (2, 128, 64, 512, 4), (1, 200, 80, 328, 3), (3, 96, 56, 72, 2), (2, 130, 48, 8, 4),
-                   (1, 768, 80, 3136, 4), (2, 64, 36, 1152, 4)]
+                   (1, 768, 80, 3136, 4), (2, 64, 36, 1152, 4),
+                   # ragged lengths (seqlen % 8 != 0: odd row strides, a partly valid last piece per row): 8 x 196 + 1, short rows
+                   (2, 192, 80, 1569, 4), (2, 100, 96, 77, 3), (3, 64, 48, 17, 4), (1, 96, 64, 7, 4), (2, 72, 40, 131, 2)]
 
 
 def _conv_tail_reference(x, du, dx_dbl, w_x, conv_w, conv_b, reverse_rows):
@@ -211,7 +213,7 @@ def test_proj_conv_bwd_vs_reference(shape, dtype, mode):
     rev_rows = [mode == "rev" or (mode == "mixed" and i >= 1) for i in range(b)]
     vms.proj_conv_bwd(x, du, dx_dbl, w_x, conv_w, conv_b, dx, dcw, dcb, dW, reverse=mode == "rev",
                       reverse_from=1 if mode == "mixed" else 0, dx_accumulate=mode == "acc")
-    assert vms.lib().vms_last_kernel().decode() == "proj_conv_bwd"
+    assert vms.lib().vms_last_kernel().decode() == ("proj_conv_bwd" if L % 8 == 0 else "proj_conv_bwd_ragged")
     r_dx, r_dcw, r_dcb, r_dW = _conv_tail_reference(x, du, dx_dbl, w_x, conv_w, conv_b, rev_rows)
     if mode == "acc":
         r_dx = r_dx + old.double()
@@ -227,7 +229,7 @@ def test_proj_conv_bwd_vs_reference(shape, dtype, mode):
 
 
 def test_proj_conv_bwd_random_shapes():
-    """40 seeded random problems (batch 1-3, dim 8-300, k 33-96, seqlen a multiple of 8 up to 1,000, width 2-4, every direction
+    """40 seeded random problems (batch 1-3, dim 8-300, k 33-96, seqlen up to 1,000 -- half of them not a multiple of 8 --, width 2-4, every direction
     mode, +-bias, +-dx_accumulate, strided channel-half views) against the fp64 statement: tile edges, channel tails, the carry
     across tiles and across workgroup ranges (tiles_per_wg forced small)."""
     vms = _vms()
@@ -235,7 +237,7 @@ def test_proj_conv_bwd_random_shapes():
     rng = random.Random(1234)
     for case in range(40):
         b, d = rng.randint(1, 3), rng.randint(8, 300)
-        k, L, W = rng.randint(33, 96), 8 * rng.randint(1, 125), rng.randint(2, 4)
+        k, L, W = rng.randint(33, 96), (8 * rng.randint(1, 125) if rng.random() < 0.5 else rng.randint(1, 1000)), rng.randint(2, 4)
         mode = rng.choice(["fwd", "rev", "mixed"]) if b > 1 else rng.choice(["fwd", "rev"])
         acc, has_bias, dtype = rng.random() < 0.5, rng.random() < 0.7, rng.choice([torch.bfloat16, torch.float16])
         tpw = rng.choice([0, 1, 2, 3])

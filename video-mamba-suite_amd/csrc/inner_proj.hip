@@ -307,7 +307,7 @@ template <> struct Mfma16<f16_t> {
     }
 };
 
-template <typename T, int KS, bool REV, bool DXACC>
+template <typename T, int KS, bool REV, bool DXACC, bool RAG>
 __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg, const int2 p_grid) {
     constexpr int MB = (KS * 16 + 31) / 32;      // 32-deep k steps of the first product
     constexpr int KP = MB * 32;                  // k padded to the matrix instructions' depth (rows beyond k are zero)
@@ -400,16 +400,43 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
                                           : static_cast<float>(static_cast<const bf16_t*>(p.conv_bias)[dc]);
     }
 
+    // A piece = the 8 logical positions [tl, tl + 8) of a row, kept in PHYSICAL element order.  RAG (seqlen % 8 != 0, or rows that
+    // are not 16-byte aligned): gfx950 serves 16-byte buffer accesses at any 2-byte alignment, so whole pieces move as before;
+    // the row's single partly valid piece (nv = seqlen - tl < 8 positions) moves element by element and reads as zeros beyond the
+    // row, which is all the arithmetic needs (as for rows / tiles out of range).  `row` = element offset of the row in the buffer.
+    auto ld8 = [&](const __amdgpu_buffer_rsrc_t& rs, int64_t row, int tl, bool ok) __attribute__((always_inline)) -> s16x8 {
+        const int pl = REV ? L - tl - 8 : tl;
+        if (!RAG || L - tl >= 8 || !ok)
+            return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (int)((row + pl) * 2) : kOOB, 0, 0));
+        s16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {     // logical element i = physical element (REV ? 7 - i : i) of the piece
+            const int phys = REV ? L - 1 - (tl + i) : tl + i;
+            v[REV ? 7 - i : i] = (short)__builtin_amdgcn_raw_buffer_load_b16(rs, tl + i < L ? (int)((row + phys) * 2) : kOOB, 0, 0);
+        }
+        return v;
+    };
+    auto st8 = [&](const __amdgpu_buffer_rsrc_t& rs, int64_t row, int tl, bool ok, const s16x8& v) __attribute__((always_inline)) {
+        const int pl = REV ? L - tl - 8 : tl;
+        if (!RAG || L - tl >= 8 || !ok) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, v), rs, ok ? (int)((row + pl) * 2) : kOOB, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int phys = REV ? L - 1 - (tl + i) : tl + i;
+                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v[REV ? 7 - i : i], rs, tl + i < L ? (int)((row + phys) * 2) : kOOB, 0, 0);
+            }
+        }
+    };
+
     // staging of the dx_dbl tile (logical tile t): thread -> row (tid >> 3) + 32 pass, logical piece tid & 7
     s16x8 stg[NPASS];
     auto stage_load = [&](int t) __attribute__((always_inline)) {
         const int tl = t * kTL + 8 * (tid & 7);                      // logical start of the piece
-        const int pl = REV ? L - tl - 8 : tl;                         // its physical vector
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = (tid >> 3) + 32 * ps;
-            const bool ok = r < R && tl < L && t >= t_lo;
-            stg[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? (int)((r * p.dxdbl_k_stride + pl) * 2) : kOOB, 0, 0));
+            stg[ps] = ld8(in_rs, (int64_t)r * p.dxdbl_k_stride, tl, r < R && tl < L && t >= t_lo);
         }
     };
     auto stage_store = [&]() __attribute__((always_inline)) {
@@ -459,9 +486,10 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
         const int pl = REV ? L - tl - 8 : tl;
         const bool okp = d < p.dim && tl < L && t >= t_lo;
         const int xo = (int)((d * p.x_c_stride + pl) * 2);
-        r.x = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(x_rs, okp ? xo : kOOB, 0, 0));
-        r.du = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(du_rs, okp ? (int)((d * p.du_c_stride + pl) * 2) : kOOB, 0, 0));
-        // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left; zeros before the row
+        r.x = __builtin_bit_cast(vec_t<T, 8>, ld8(x_rs, (int64_t)d * p.x_c_stride, tl, okp));
+        r.du = __builtin_bit_cast(vec_t<T, 8>, ld8(du_rs, (int64_t)d * p.du_c_stride, tl, okp));
+        // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left (always inside the
+        // row: tl >= 8 there); zeros before the row
         r.xh = __builtin_bit_cast(vec_t<T, 4>, __builtin_amdgcn_raw_buffer_load_b64(x_rs, okp && tl > 0 ? xo + (REV ? 16 : -8) : kOOB, 0, 0));
     };
 
@@ -480,14 +508,13 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) piece_load(raw[ss], t - 1, ss);
         const int tl = t * kTL + ec;
-        const int pl = REV ? L - tl - 8 : tl;
         vec_t<T, 8> dxold[2];
         if (DXACC) {
 #pragma unroll
             for (int ss = 0; ss < 2; ++ss) {
                 const int d = d0 + 8 * ss + rr;
                 const bool okp = d < p.dim && tl < L && emit;
-                dxold[ss] = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(dx_rs, okp ? (int)((d * p.dx_c_stride + pl) * 2) : kOOB, 0, 0));
+                dxold[ss] = __builtin_bit_cast(vec_t<T, 8>, ld8(dx_rs, (int64_t)d * p.dx_c_stride, tl, okp));
             }
         }
         {
@@ -568,7 +595,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
                         for (int k = 0; k < 4; ++k) dwacc[ss][k] = fmaf(xv[i + k], gp[i], dwacc[ss][k]);
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, o), dx_rs, okp && emit ? (int)((d * p.dx_c_stride + pl) * 2) : kOOB, 0, 0);
+                st8(dx_rs, (int64_t)d * p.dx_c_stride, tl, okp && emit, __builtin_bit_cast(s16x8, o));
             }
         }
         // second product: dW_x[r][d] += sum_l dx_dbl[r][l] conv1d_out[d][l] over the tile (same column order in both tiles)
@@ -626,14 +653,14 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
     }
 }
 
-template <typename T, int KS, bool DXACC>
+template <typename T, int KS, bool DXACC, bool RAG>
 __global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg, const int2 p_grid) {
     // the batch entry of this workgroup (same decode as in the body) decides the direction: workgroup-uniform
     const int pair = (((int)blockIdx.x >> 3) / p_grid.y) * 8 + ((int)blockIdx.x & 7);
     const int b = pair / p_grid.x;    // >= batch for the padding workgroups of the last group of 8, which return at once
     const bool rev = p.reverse != 0 || (p.reverse_from > 0 && b >= p.reverse_from);
-    if (rev) proj_conv_bwd_body<T, KS, true, DXACC>(p, tiles_per_wg, p_grid);
-    else proj_conv_bwd_body<T, KS, false, DXACC>(p, tiles_per_wg, p_grid);
+    if (rev) proj_conv_bwd_body<T, KS, true, DXACC, RAG>(p, tiles_per_wg, p_grid);
+    else proj_conv_bwd_body<T, KS, false, DXACC, RAG>(p, tiles_per_wg, p_grid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -716,22 +743,30 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
     const int2 pg = make_int2(n_rng, d_tiles);
     const dim3 grid(8 * ((n_rng * p.batch + 7) / 8) * d_tiles), block(kPT);
     const size_t smem = (size_t)MB * 32 * kRowE * 2 + (size_t)4 * 16 * kEpT * sizeof(float) + (size_t)4 * 16 * kRowE * 2 + (size_t)MB * 32 * kWRowE * 2;
-    if (smem > 64 * 1024) {   // k > 64: 76 KB, admitted per kernel and per device before the first launch there
+    // whole 16-byte pieces everywhere (the tuned path) vs rows with a partly valid last piece / 2-byte aligned rows
+    const bool rag = p.seqlen % 8 != 0;
+    if (smem > 64 * 1024) {   // admitted per kernel and per device before the first launch there
         static PerDeviceOnce attr_once;
         const hipError_t arc = attr_once.run([&]() -> hipError_t {
-            const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e2 != hipSuccess) return e2;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipError_t e = hipSuccess;
+#define VMS_PCB_ATTR(A_, R_)                                                                                                     \
+            if (e == hipSuccess)                                                                                                \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&proj_conv_bwd_kernel<T, KS, A_, R_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+            VMS_PCB_ATTR(true, true); VMS_PCB_ATTR(true, false); VMS_PCB_ATTR(false, true); VMS_PCB_ATTR(false, false);
+#undef VMS_PCB_ATTR
+            return e;
         });
         if (arc != hipSuccess) {
             set_error("hipFuncSetAttribute(proj_conv_bwd, %zu bytes of LDS) failed: %s", smem, hipGetErrorString(arc));
             return VMS_ERR_LAUNCH;
         }
     }
-    if (p.dx_accumulate) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, true>), grid, block, smem, stream, p, tpw, pg);
-    else hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, false>), grid, block, smem, stream, p, tpw, pg);
+#define VMS_PCB_LAUNCH(A_, R_) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, A_, R_>), grid, block, smem, stream, p, tpw, pg)
+    if (p.dx_accumulate) { if (rag) VMS_PCB_LAUNCH(true, true); else VMS_PCB_LAUNCH(true, false); }
+    else { if (rag) VMS_PCB_LAUNCH(false, true); else VMS_PCB_LAUNCH(false, false); }
+#undef VMS_PCB_LAUNCH
     VMS_LAUNCH_CHECK();
-    set_last_kernel("proj_conv_bwd");
+    set_last_kernel(rag ? "proj_conv_bwd_ragged" : "proj_conv_bwd");
     return VMS_OK;
 }
 
@@ -796,10 +831,13 @@ extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* strea
                       p.x_c_stride >= p.seqlen && p.du_c_stride >= p.seqlen && p.dx_c_stride >= p.seqlen && p.dxdbl_k_stride >= p.seqlen,
                   "proj_conv_bwd: a batch entry (dim * channel stride) must span < 2 GiB, rows must not overlap");
     }
-    VMS_CHECK(p.seqlen % 8 == 0 && p.x_batch_stride % 8 == 0 && p.x_c_stride % 8 == 0 && p.du_batch_stride % 8 == 0 && p.du_c_stride % 8 == 0 &&
-                  p.dx_batch_stride % 8 == 0 && p.dx_c_stride % 8 == 0 && p.dxdbl_batch_stride % 8 == 0 && p.dxdbl_k_stride % 8 == 0 &&
-                  aligned16(p.x) && aligned16(p.du) && aligned16(p.dx) && aligned16(p.dx_dbl),
-              "proj_conv_bwd: seqlen and the activation strides (elements) must be multiples of 8, bases 16-byte aligned");
+    // seqlen % 8 == 0: every row piece is a whole 16-byte vector and must be 16-byte aligned; otherwise (ragged rows) the vectors
+    // are served at 2-byte alignment and the row's last piece moves element by element
+    VMS_CHECK(p.seqlen % 8 != 0 ||
+                  (p.x_batch_stride % 8 == 0 && p.x_c_stride % 8 == 0 && p.du_batch_stride % 8 == 0 && p.du_c_stride % 8 == 0 &&
+                   p.dx_batch_stride % 8 == 0 && p.dx_c_stride % 8 == 0 && p.dxdbl_batch_stride % 8 == 0 && p.dxdbl_k_stride % 8 == 0 &&
+                   aligned16(p.x) && aligned16(p.du) && aligned16(p.dx) && aligned16(p.dx_dbl)),
+              "proj_conv_bwd: with seqlen % 8 == 0 the activation strides (elements) must be multiples of 8, bases 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == VMS_BF16 ? dispatch_conv_bwd<bf16_t>(p, s) : dispatch_conv_bwd<f16_t>(p, s);
 }

@@ -477,7 +477,13 @@ void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw) {
 bool proj_conv_bwd_eligible(const Tensor& x, const Tensor& du_like, const Tensor& dx_dbl_like, const Tensor& w_x, const Tensor& conv_w,
                             const OptT& conv_b, const Tensor& dx) {
     const int64_t k = dx_dbl_like.size(1);
-    return proj_ok16(x) && proj_ok16(du_like) && proj_ok16(dx_dbl_like) && proj_ok16(dx) && w_x.scalar_type() == x.scalar_type() &&
+    // seqlen % 8 == 0: whole 16-byte pieces (aligned bases / strides); otherwise the ragged flavour, any 2-byte alignment
+    auto ok = [&](const Tensor& t) {
+        if (x.size(2) % 8 == 0) return proj_ok16(t);
+        return t.is_cuda() && (t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf) && t.dim() == 3 && t.stride(2) == 1 &&
+               t.stride(1) >= t.size(2);
+    };
+    return ok(x) && ok(du_like) && ok(dx_dbl_like) && ok(dx) && w_x.scalar_type() == x.scalar_type() &&
            du_like.scalar_type() == x.scalar_type() && dx_dbl_like.scalar_type() == x.scalar_type() && dx.scalar_type() == x.scalar_type() &&
            k >= 33 && k <= 96 && conv_w.dim() == 2 && conv_w.size(1) >= 2 && conv_w.size(1) <= 4 && is_itype(conv_w) &&
            (!conv_b.has_value() || conv_b->scalar_type() == conv_w.scalar_type());
