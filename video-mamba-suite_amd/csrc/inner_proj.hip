@@ -733,7 +733,7 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
     const int n_tiles = (p.seqlen + kTL - 1) / kTL;
     const int d_tiles = (p.dim + kCD - 1) / kCD;
     // ~2 workgroups per CU (2 are resident); every workgroup pays one extra tile (the carry) and 64 x k atomics at its end:
-    // (8, 1024, 8192) 130 us with 32 tiles per workgroup, 137 with 16, 157 with 8, 155 with 64 (profiles/r03s_kb_proj.txt)
+    // (8, 1024, 8192) 113 us with 32 tiles per workgroup, 119 with 16, 132 with 8, 144 with 64 (profiles/r03w_kb_proj.txt)
     const int64_t want = 2 * (int64_t)device_cu_count();
     int tpw = (int)(((int64_t)n_tiles * d_tiles * p.batch + want - 1) / want);
     if (tpw < 8) tpw = 8;
