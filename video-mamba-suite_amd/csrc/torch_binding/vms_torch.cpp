@@ -483,7 +483,10 @@ bool proj_conv_bwd_eligible(const Tensor& x, const Tensor& du_like, const Tensor
         return t.is_cuda() && (t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf) && t.dim() == 3 && t.stride(2) == 1 &&
                t.stride(1) >= t.size(2);
     };
-    return ok(x) && ok(du_like) && ok(dx_dbl_like) && ok(dx) && w_x.scalar_type() == x.scalar_type() &&
+    // a batch entry of each tensor is addressed through one buffer resource: (rows - 1) * row stride + seqlen elements must span < 2 GiB
+    auto fits = [&](const Tensor& t) { return ((t.size(1) - 1) * t.stride(1) + t.size(2)) * 2 < ((int64_t)1 << 31) && t.size(1) * t.stride(1) * 2 < ((int64_t)1 << 31); };
+    return ok(x) && ok(du_like) && ok(dx_dbl_like) && ok(dx) && fits(x) && fits(du_like) && fits(dx_dbl_like) && fits(dx) &&
+           w_x.scalar_type() == x.scalar_type() &&
            du_like.scalar_type() == x.scalar_type() && dx_dbl_like.scalar_type() == x.scalar_type() && dx.scalar_type() == x.scalar_type() &&
            k >= 33 && k <= 96 && conv_w.dim() == 2 && conv_w.size(1) >= 2 && conv_w.size(1) <= 4 && is_itype(conv_w) &&
            (!conv_b.has_value() || conv_b->scalar_type() == conv_w.scalar_type());
