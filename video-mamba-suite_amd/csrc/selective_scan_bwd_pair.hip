@@ -670,6 +670,8 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     bool rd_okp = false;
 
     RawB<T, REV> pu, pdt, pdo, pz, pout;   // row data of the NEXT chunk: requested while the current one computes
+    RawB<T, REV> pdzo;                     // dz_accumulate: what dz holds (round 3: requested with the row data instead of right
+                                           // before its use, where every chunk waited for it: +36 -> +? us for the accumulating launch)
     float hck_next = 0.f;
     const int n_c = (L + CH - 1) / CH;
     const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
@@ -683,6 +685,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         if (HZ) {
             pz.load_stream(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
             pout.load_stream(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+            if (q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
         }
         const int e128 = cc * (CH / 128) - 1;
         const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
@@ -752,13 +755,11 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                     dy[i] *= silu;
                     ov[i] *= silu;
                 }
-                if (ok) {
-                    if (q.dz_accumulate) {  // dz += (vms_hip.h)
-                        RawB<T, REV> od;
-                        od.load(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0, true);
+                if (q.dz_accumulate) {  // dz += (vms_hip.h)
 #pragma unroll
-                        for (int i = 0; i < K; ++i) dzv[i] += od.at(i);
-                    }
+                    for (int i = 0; i < K; ++i) dzv[i] += pdzo.at(i);
+                }
+                if (ok) {
                     store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
                     if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
                 }
