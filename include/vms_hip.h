@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 6
+#define VMS_ABI_VERSION 7
 
 typedef enum {
     VMS_OK = 0,
@@ -109,6 +109,13 @@ typedef struct {
      * "rows" checkpoint region written by the row-major fast kernels: float hck[batch][dim/64][ceil(seqlen/128)]
      * [dstate][64] = the state BEFORE 128-element chunk c of row (b, 64*rb + lane), in scan order
      * (dstate == 16, (dim / n_groups) % 64 == 0 only).  vms_scan_x_elems() gives the total size. */
+    /* x_has_sub == 3 ("lane checkpoints", ABI v7): the pitch is >= 258*dstate (even; x 8-byte aligned) and
+     * x[b,d,c, 2*dstate + ((n/4)*256 + i)*4 + n%4], i = 0..255, holds state n after the first 8*(i+1) elements of chunk c,
+     * in scan order (16x the data of x_has_sub == 1, of which every 16th entry is the same 128-element checkpoint).
+     * The forward writes them from values it already has; the whole-vector backward kernel (dstate 16, variable B / C,
+     * seqlen % 8 == 0) then takes the state entering each lane's 8 elements from x instead of rebuilding it (-10 % of its
+     * instructions: 897 -> 805 us at (8, 1024, 8192); the forward pays 35-40 us for the 537 MB of stores).
+     * vms_scan_x_pitch() says when the library wants it. */
     int32_t x_has_sub;
     /* reverse != 0 (an extension; the reference has no such flag): the scan runs right-to-left,
      * i.e. the call equals flip(op(flip(every seqlen-indexed tensor))) without the copies the
@@ -179,6 +186,12 @@ int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params *p);
 /* number of floats of an x allocation that carries the "rows" checkpoint region (x_has_sub == 2),
  * or batch*dim*n_chunks*2*dstate when the shape is not eligible */
 int64_t vms_scan_x_elems(const vms_scan_fwd_params *p);
+/* the x pitch (floats between x[b,d,c,:] and x[b,d,c+1,:]) to allocate for this problem; only sizes and flags of *p are
+ * read.  mode 0: 2*dstate (the reference's tensor, selective_scan.cpp:313: no fast backward); 1: 18*dstate (x_has_sub == 1);
+ * 3 or -1 (the library's choice for a forward whose backward will run): 258*dstate (x_has_sub == 3) when the backward
+ * kernel that uses it takes the problem and x stays under 2 GiB, else 18*dstate.  The caller sets x_chunk_stride to the
+ * pitch and x_has_sub to 3 / 1 / 0 for pitch >= 258*dstate / >= 18*dstate / less. */
+int64_t vms_scan_x_pitch(const vms_scan_fwd_params *p, int32_t mode);
 
 /* ---- causal depthwise conv1d ---------------------------------------------------------
  * x, out, dout, dx : (batch, dim, seqlen); either unit seqlen stride (any batch/channel

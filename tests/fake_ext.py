@@ -20,7 +20,7 @@ def make_fakes(oracle):
 
     sl = lambda t, a, b: None if t is None else t[a:b]
 
-    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, reverse_from=0):
+    def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, reverse_from=0, for_backward=True):
         if reverse_from:   # by definition (vms_hip.h ABI v5): the two sub-batches, the second one right-to-left
             k, n = reverse_from, u.shape[0]
             lo = fwd(u[:k], delta[:k], A, sl(B, 0, k) if B.dim() >= 3 else B, sl(C, 0, k) if C.dim() >= 3 else C, D_, sl(z_, 0, k),

@@ -505,6 +505,58 @@ def test_scan_rows_checkpoint_region(oracle, monkeypatch):
 
 
 
+@pytest.mark.parametrize("L", [2512, 2504, 8])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_scan_lane_checkpoints(oracle, L, reverse):
+    """ABI v7, x_has_sub == 3: where the whole-vector backward kernel takes the problem, the forward (the LDS kernel at
+    L % 16 == 0, the per-wave kernel otherwise) leaves the state after every 8 elements behind the reference-shaped x, and the
+    backward starts every lane from them.  Checkpoints vs the oracle's last_state of the truncated problem; gradients vs the oracle."""
+    import selective_scan_cuda
+    import vms_hip
+    torch.manual_seed(3)
+    b, d, N = 2, 32, 16
+    u = torch.randn(b, d, L, device=DEV)
+    z = torch.randn(b, d, L, device=DEV)
+    delta = 0.5 * torch.rand(b, d, L, device=DEV)
+    A = -0.5 * torch.rand(d, N, device=DEV)
+    B = torch.randn(b, 1, N, L, device=DEV)
+    C = torch.randn(b, 1, N, L, device=DEV)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
+    nch = (L + 2047) // 2048
+    assert x.shape == (b, d, nch, 2 * N) and x.stride(2) == 258 * N and vms_hip.x_layout_of(x, N) == 3
+    assert vms_hip.last_kernel().startswith("scan_fwd_pair_lds" if L % 16 == 0 else "scan_fwd_pair")
+    xfull = x.as_strided((b, d, nch, 258 * N), (d * nch * 258 * N, nch * 258 * N, 258 * N, 1))
+    f = lambda t: t.detach().float().cpu().numpy()
+    lf = (lambda t: t.flip(-1)) if reverse else (lambda t: t)     # x is in scan order
+    for cut in sorted({8, 16, 128, 1024, 1032, 2048, 2056, 2496, L} & set(range(8, L + 1, 8))):
+        t = oracle.scan_fwd(f(lf(u)[..., :cut]), f(lf(delta)[..., :cut]), f(A), f(lf(B)[..., :cut]), f(lf(C)[..., :cut]), f(D),
+                            f(lf(z)[..., :cut]), f(bias), True, prec="f64")
+        i8 = cut // 8 - 1
+        c, i = i8 // 256, i8 % 256
+        got = torch.stack([xfull[:, :, c, 2 * N + ((n // 4) * 256 + i) * 4 + n % 4] for n in range(N)], dim=-1)
+        check(got, t["last_state"], 1e-3, f"state after {cut} elements")
+    o = oracle.scan_fwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), True, prec="f64")
+    check(lf(out_z), o["out_z"], 1e-3, "out_z")
+    check(x, o["x"], 1e-3, "x (mid + end slots)")
+    dout = torch.randn(b, d, L, device=DEV)
+    res = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse=reverse)
+    assert vms_hip.last_kernel().startswith("scan_bwd_pair4")
+    ob = oracle.scan_bwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), f(lf(dout)), True, prec="f64")
+    names = ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz")
+    for name, got in zip(names, res):
+        want = ob[name]
+        g = lf(got) if got.ndim >= 3 and got.shape[-1] == L else got
+        check(g, want.reshape(g.shape), 2e-3, f"{name} (lane checkpoints, reverse={reverse})")
+    # the same backward from the 128-element layout: x_has_sub == 1 (VMS_X_LAYOUT=1) gives the same gradients
+    out1, x1, _ = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse, for_backward=False)
+    assert x1.stride(2) == 18 * N
+    res1 = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x1, out1, None, True, False, reverse=reverse)
+    for name, a, c_ in zip(names, res, res1):
+        check(a, f(c_), 1e-4, f"{name}: lane checkpoints vs 128-element checkpoints")
+
+
 def test_scan_strided_views_and_checkpoints(oracle):
     """u/z are channel halves of one xz buffer, delta is d-slowest, out inherits delta's layout,
     dz is written into a slice of a pre-allocated dxz (SSI:175, 182, 244-248); raw extension ABI."""

@@ -112,6 +112,13 @@ __device__ __forceinline__ void store_stream_b(T* __restrict__ ptr, const float 
     }
 }
 
+// element offset (inside a row's x) of the state after the first 128 (e128 + 1) elements for state n: the 128-element
+// sub-checkpoints of x_has_sub == 1, or every 16th of the 8-element checkpoints of x_has_sub == 3 (vms_hip.h)
+__device__ __forceinline__ uint32_t x_sub_off(int e128, int n, int pitch, bool lane_ckpt) {
+    return lane_ckpt ? (uint32_t)((e128 >> 4) * pitch + 2 * kBN + ((n >> 2) * 256 + (e128 & 15) * 16 + 15) * 4 + (n & 3))
+                     : (uint32_t)((e128 >> 4) * pitch + 2 * kBN + (e128 & 15) * kBN + n);
+}
+
 template <int CTRL>
 __device__ __forceinline__ float bdpp(float old, float src) {
     return dpp_mov<CTRL, 0xf>(old, src);
@@ -130,6 +137,16 @@ __device__ __forceinline__ void row_scan_pair_b(float& pa, float& px, float& ra,
     "v_mul_f32_dpp %3, %3, %3 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"
     asm volatile("s_nop 1\n\t" VMS_STEP(1) VMS_STEP(2) VMS_STEP(4) VMS_STEP(8) "s_nop 1"
                  : "+v"(px), "+v"(pa), "+v"(rg), "+v"(ra));
+#undef VMS_STEP
+}
+
+__device__ __forceinline__ void row_scan_suffix_b(float& ra, float& rg) {
+#define VMS_STEP(S)                                                                   \
+    "v_fmac_f32_dpp %0, %0, %1 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %1, %1, %1 row_shl:" #S " row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t" VMS_STEP(1) VMS_STEP(2) VMS_STEP(4) VMS_STEP(8) "s_nop 0"
+                 : "+v"(rg), "+v"(ra));
 #undef VMS_STEP
 }
 
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         }
         // state entering chunk cc = 128-element sub-checkpoint cc-1 (vms_hip.h); lane j loads state j
         const int e128 = cc * (CH / 128) - 1;
-        const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
+        const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, j, (int)p.x_chunk_stride, p.x_has_sub == 3) : 0u;
         hck_next = x_b[xo];
     };
     const int cps = (n_c + n_seg - 1) / n_seg;                        // chunks per segment
@@ -576,7 +593,7 @@ template <int W> struct B4 {
     static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kBN * 4);
 };
 
-template <typename T, bool HZ, bool REV, int W>
+template <typename T, bool HZ, bool REV, int W, bool XL>
 __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -673,8 +690,25 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     RawB<T, REV> pdzo;                     // dz_accumulate: what dz holds (round 3: requested with the row data instead of right
                                            // before its use, where every chunk waited for it: +36 -> +? us for the accumulating launch)
     float hck_next = 0.f;
+    // XL (x_has_sub == 3): the forward left the state after every 8 elements; a lane takes the one entering its elements
+    // instead of rebuilding it (its own 8-step recurrence from zero + the row scan of the lane aggregates)
+    float xin[XL ? N : 1];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(x_b), 0, XL ? (int)((int64_t)p.batch * p.dim * p.n_chunks * p.x_chunk_stride * 4) : 0, 0x00020000);
     const int n_c = (L + CH - 1) / CH;
     const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
+    // XL: the states entering this lane's 8 elements of chunk cc, four states (n0 .. n0 + 3) at a time: requested as soon as
+    // the same registers' values for the current chunk have been used = a whole chunk ahead.  Out of range (the row's
+    // first lane, chunks before the row) reads 0 through the buffer resource: no select on loaded data.
+    auto request_x = [&](int cc, int n0) __attribute__((always_inline)) {
+        const int idx8 = cc * (CH / 8) + j - 1;
+        const uint32_t xo = cc >= 0 && idx8 >= 0 && cc * CH + j * K < L   // lanes past the row's end: 0, not unwritten memory
+                                ? (o_x + (uint32_t)((idx8 >> 8) * (int)p.x_chunk_stride + 2 * N + (idx8 & 255) * 4)) * 4u
+                                : 0x80000000u;
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, n0 * 1024, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xin[XL ? n0 + i : 0] = v[i];
+    };
     auto request_row = [&](int cc) __attribute__((always_inline)) {
         const int ll = cc * CH + j * K;
         const bool v = cc >= 0 && ll < L && row_ok;
@@ -687,9 +721,11 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             pout.load_stream(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
             if (q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
         }
-        const int e128 = cc * (CH / 128) - 1;
-        const uint32_t xo = cc > 0 ? o_x + (uint32_t)((e128 >> 4) * (int)p.x_chunk_stride + 2 * N + (e128 & 15) * N + j) : 0u;
-        hck_next = x_b[xo];
+        if constexpr (!XL) {
+            const int e128 = cc * (CH / 128) - 1;
+            const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, j, (int)p.x_chunk_stride, p.x_has_sub == 3) : 0u;
+            hck_next = x_b[xo];
+        }
     };
     const int cps = (n_c + n_seg - 1) / n_seg;
     const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
@@ -706,6 +742,10 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         anx_in = fast_exp2(t * A_mine * kLog2e);
     }
     request_row(c_hi - 1);
+    if constexpr (XL) {
+#pragma unroll
+        for (int n0 = 0; n0 < N; n0 += 4) request_x(c_hi - 1, n0);
+    }
     stage_issue(c_hi - 1);
     stage_commit();
     rec4[j] = f32x4{A_mine, c_hi > 1 ? hck_next : 0.f, anx_in, g_in};
@@ -823,19 +863,25 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                 xs2[k] = dlu2[k] * Bn2[k];  // b_i for now
                 c2[k] = (k == 0 ? f2{c0.x, c0.y} : k == 1 ? f2{c0.z, c0.w} : k == 2 ? f2{c1.x, c1.y} : f2{c1.z, c1.w}) * dy2[k];
             }
-            float px = 0.f;
-#pragma unroll
-            for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
-            float pa = fast_exp2(sdl * An);
             const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);  // lane 15 of the row <- next chunk
             float rg = 0.f;
 #pragma unroll
             for (int i = K - 1; i >= 0; --i) rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));
             float ra = fast_exp2((sdl - dl_first) * An) * a_right;
-            px = fmaf(pa, is_first ? hin : 0.f, px);
             rg = fmaf(ra, is_last ? gin : 0.f, rg);
-            row_scan_pair_b(pa, px, ra, rg);
-            const float xseed = bdpp<DPP_ROW_SHR1>(hin, px);
+            float xseed;
+            if constexpr (XL) {
+                row_scan_suffix_b(ra, rg);
+                xseed = xin[n];
+            } else {
+                float px = 0.f;
+#pragma unroll
+                for (int i = 0; i < K; ++i) px = fmaf(VMS_EL(a2, i), px, VMS_EL(xs2, i));
+                float pa = fast_exp2(sdl * An);
+                px = fmaf(pa, is_first ? hin : 0.f, px);
+                row_scan_pair_b(pa, px, ra, rg);
+                xseed = bdpp<DPP_ROW_SHR1>(hin, px);
+            }
             float grun = bdpp<DPP_ROW_SHL1>(gin, rg);
             if (is_first) *(lds_f2*)(rec1 + 4 * n + 2) = f2{a2[0].x, rg};
             {
@@ -906,12 +952,23 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                 lds_barrier_b();  // pair written by all waves; previous pair's buffer free again
             }
         };
+        if constexpr (XL) {   // unrolled: xin[n] is a register
+#pragma unroll
+            for (int n = 0; n < N; n += 4) {
+                do_state(n, 0);
+                do_state(n + 1, 1);
+                do_state(n + 2, 2);
+                do_state(n + 3, 3);
+                request_x(c - 1, n);
+            }
+        } else {
 #pragma unroll 1
-        for (int n = 0; n < N; n += 4) {
-            do_state(n, 0);
-            do_state(n + 1, 1);
-            do_state(n + 2, 2);
-            do_state(n + 3, 3);
+            for (int n = 0; n < N; n += 4) {
+                do_state(n, 0);
+                do_state(n + 1, 1);
+                do_state(n + 2, 2);
+                do_state(n + 3, 3);
+            }
         }
 #undef VMS_EL
         // u of this chunk before its registers are refilled; the next chunk's row data then travels during the
@@ -967,15 +1024,16 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from).  A workgroup serves one batch
 // entry: the direction is workgroup-uniform, one branch selects the body.
-template <typename T, bool HZ, int RM, int W>
+// XL: x carries the forward's 8-element checkpoints (x_has_sub == 3) and spans < 2 GiB (one buffer resource)
+template <typename T, bool HZ, int RM, int W, bool XL>
 __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
-        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W>(q, n_seg, seg_carry);
-        else scan_bwd_pair4_body<T, HZ, false, W>(q, n_seg, seg_carry);
+        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry);
+        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry);
     } else {
-        scan_bwd_pair4_body<T, HZ, RM == 1, W>(q, n_seg, seg_carry);
+        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry);
     }
 }
 
@@ -1159,10 +1217,19 @@ int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q) {
     return (int64_t)q.f.batch * q.f.dim * 16 * kBN * (int64_t)sizeof(float2);   // up to 16 ranges
 }
 
+// would scan_bwd_pair4_kernel<.., XL = true> serve the backward of this forward?  (the shape conditions of
+// scan_bwd_pair_eligible + whole-vector rows + one buffer resource over x at the 258 * dstate pitch)
+bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p) {
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || p.n_groups < 1 || p.dim % p.n_groups != 0) return false;
+    if ((p.dim / p.n_groups) % kBRows != 0 || p.seqlen % kBK != 0) return false;
+    const int64_t n_chunks = (p.seqlen + 2047) / 2048;
+    return (int64_t)p.batch * p.dim * n_chunks * 258 * kBN * 4 < ((int64_t)1 << 31);
+}
+
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
     const vms_scan_fwd_params& p = q.f;
     (void)vec;  // 16-byte vector accesses need no alignment on gfx950
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || p.x_has_sub != 1) return false;
+    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || (p.x_has_sub != 1 && p.x_has_sub != 3)) return false;
     const int dpg = p.dim / p.n_groups;
     if (dpg % kBRows != 0) return false;     // a workgroup's rows must share one B/C group
     if (p.seqlen % kBK != 0 && p.bc_pad < kBK - p.seqlen % kBK) return false;   // ragged: B / C padding needed
@@ -1229,12 +1296,14 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         static PerDeviceOnce attr4_once;
         const hipError_t arc4 = attr4_once.run([&]() -> hipError_t {
             hipError_t e = hipSuccess;
-#define VMS_A4(Z_, R_)                                                                                                   \
+#define VMS_A4X(Z_, R_, X_)                                                                                              \
             if (e == hipSuccess)                                                                                         \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_kernel<T, Z_, R_, WK>),             \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_kernel<T, Z_, R_, WK, X_>),         \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem4)
+#define VMS_A4(Z_, R_) VMS_A4X(Z_, R_, false); VMS_A4X(Z_, R_, true)
             VMS_A4(true, 0); VMS_A4(true, 1); VMS_A4(true, 2); VMS_A4(false, 0); VMS_A4(false, 1); VMS_A4(false, 2);
 #undef VMS_A4
+#undef VMS_A4X
             return e;
         });
         if (arc4 != hipSuccess) {
@@ -1243,18 +1312,26 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         }
     }
     const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
+    // the forward's 8-element checkpoints (x_has_sub == 3), addressed through one buffer resource
+    const bool xl = p.x_has_sub == 3 && (int64_t)p.batch * p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
+#define VMS_L4(Z_, R_)                                                                                             \
+    do {                                                                                                           \
+        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry); \
+        else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, false>), grid4, block4, smem4, stream, q, n_seg, carry);   \
+    } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, true>), grid, block, smem, stream, q, 1, carry); \
-        else if (four) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_ ? 1 : 0, WK>), grid4, block4, smem4, stream, q, n_seg, carry); \
+        else if (four) VMS_L4(Z_, R_ ? 1 : 0);                                                                     \
         else hipLaunchKernelGGL((scan_bwd_pair_kernel<T, Z_, R_, false>), grid, block, smem, stream, q, n_seg, carry); \
     } while (0)
     if (mixed) {
-        if (p.z) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, true, 2, WK>), grid4, block4, smem4, stream, q, n_seg, carry);
-        else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, false, 2, WK>), grid4, block4, smem4, stream, q, n_seg, carry);
+        if (p.z) VMS_L4(true, 2);
+        else VMS_L4(false, 2);
     } else if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
+#undef VMS_L4
     VMS_LAUNCH_CHECK();
     set_last_kernel(mixed ? (n_seg > 1 ? "scan_bwd_pair4+mixed+split" : "scan_bwd_pair4+mixed") : rag ? "scan_bwd_pair_ragged"
                         : four ? (n_seg > 1 ? "scan_bwd_pair4+split" : "scan_bwd_pair4")

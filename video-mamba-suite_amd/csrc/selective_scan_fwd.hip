@@ -94,16 +94,24 @@ __global__ __launch_bounds__(kRowsPerWG* kWave) void scan_fwd_kernel(const vms_s
             float xs = fmaf(ea, hin, ex);
             const float hout = fmaf(readlane_f(pa, 63), hin, readlane_f(px, 63));
             if (lane == 0) h[n] = hout;
-            if (p.x_has_sub && (lane & 7) == 7) {
+            if (p.x_has_sub == 1 && (lane & 7) == 7) {
                 // 128-element sub-checkpoints for the backward kernel: the state after this lane's
                 // last element, kept by every 8th lane (8 lanes x 16 elements = 128)
                 static_assert(CS == 1024 && K == 16, "sub-checkpoint indexing assumes 64 x 16 wave chunks");
                 xck[(int64_t)(c >> 1) * xpitch + 2 * N + ((c & 1) * 8 + (lane >> 3)) * N + n] = fmaf(pa, hin, px);
             }
+            float x_mid = 0.f;
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 xs = fmaf(a[i], xs, bx[i]);
                 y[i] = fmaf(VC ? Cn[i] : cconst, xs, y[i]);
+                if (i == K / 2 - 1) x_mid = xs;
+            }
+            // 8-element checkpoints (vms_hip.h, x_has_sub == 3): the state after the lane's 8th and 16th element
+            if (p.x_has_sub == 3 && nv > 0) {
+                float* const xq = xck + (int64_t)(c >> 1) * xpitch + 2 * N + (((n >> 2) * 256 + (c & 1) * 128 + 2 * lane) * 4 + (n & 3));
+                xq[0] = x_mid;
+                xq[4] = xs;
             }
         }
         store_dir<T, K, VEC>(out, l0, L, rev, y);
@@ -174,6 +182,11 @@ int validate_scan_common(const vms_scan_fwd_params& p) {
     VMS_CHECK(p.n_groups >= 1 && p.dim % p.n_groups == 0, "dim must be divisible by n_groups");
     VMS_CHECK(p.n_chunks == (p.seqlen + 2047) / 2048, "n_chunks must be ceil(seqlen / 2048)");
     VMS_CHECK(p.u && p.delta && p.A && p.B && p.C, "u, delta, A, B, C are required");
+    VMS_CHECK(p.x_has_sub >= 0 && p.x_has_sub <= 3, "x_has_sub out of range");
+    VMS_CHECK(p.x_has_sub != 1 || p.x_chunk_stride >= 18 * (int64_t)p.dstate, "x_has_sub == 1 needs an x pitch >= 18 * dstate");
+    VMS_CHECK(p.x_has_sub != 3 || (p.x_chunk_stride >= 258 * (int64_t)p.dstate && p.x_chunk_stride % 2 == 0 &&
+                                   (reinterpret_cast<uintptr_t>(p.x) & 7) == 0),
+              "x_has_sub == 3 needs an 8-byte aligned x with an even pitch >= 258 * dstate");
     return VMS_OK;
 }
 
@@ -185,6 +198,7 @@ int64_t scan_rows_fwd_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_rows(const vms_scan_fwd_params& p, hipStream_t stream);
 
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec);
+bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p);   // selective_scan_bwd_pair.hip
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p);
 int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
@@ -313,6 +327,14 @@ extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
         return scan_fwd_pair_ws_bytes(*p);
     return 0;
 }
+extern "C" int64_t vms_scan_x_pitch(const vms_scan_fwd_params* pp, int32_t mode) {
+    if (pp == nullptr || pp->dstate <= 0) return 0;
+    const vms_scan_fwd_params& p = *pp;
+    if (mode == 0) return 2 * (int64_t)p.dstate;
+    if ((mode == 3 || mode == -1) && vms::scan_bwd_pair_lane_ckpt_ok(p)) return 258 * (int64_t)p.dstate;
+    return 18 * (int64_t)p.dstate;
+}
+
 extern "C" int64_t vms_scan_x_elems(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
     const int64_t ref = (int64_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;

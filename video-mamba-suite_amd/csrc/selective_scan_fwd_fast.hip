@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kFRows* kWave, VMS_FWD_MINWAVES) void scan_fwd_fast
 }
 
 bool scan_fwd_fast_eligible(const vms_scan_fwd_params& p, bool vec) {
-    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kFN) return false;
+    if (!vec || !p.is_variable_B || !p.is_variable_C || p.dstate != kFN || p.x_has_sub == 3) return false;
     if (p.seqlen % kFK != 0) return false;
     const int64_t lim = (int64_t)1 << 31;
     auto span = [&](int64_t bs, int64_t ds) { return (p.batch - 1) * bs + (p.dim - 1) * ds + p.seqlen; };

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
             const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
             float xs = fmaf(ea, hin, ex);
             const float hend = fmaf(pa, hin, px);  // state after this lane's last element
-            if (p.x_has_sub && ((lane + 1) * K) % 128 == 0) {  // 128-element sub-checkpoints for the backward kernel
+            if (p.x_has_sub == 1 && ((lane + 1) * K) % 128 == 0) {  // 128-element sub-checkpoints for the backward kernel
                 const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
                 xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
             }
@@ -234,6 +234,12 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
             for (int i = 0; i < K; ++i) {
                 xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
                 VMS_ELP(bx2, i) = xs;  // x_i
+            }
+            // 8-element checkpoints (vms_hip.h, x_has_sub == 3): the state after the lane's 8th and 16th element
+            if (p.x_has_sub == 3 && ok) {
+                float* const xq = xck + (int64_t)(c >> 1) * xpitch + 2 * N + (((n >> 2) * 256 + (c & 1) * 128 + 2 * lane) * 4 + (n & 3));
+                xq[0] = bx2[3].y;
+                xq[4] = bx2[7].y;
             }
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) y2[k] = pk_fma_p(f2{cC.at(2 * k), cC.at(2 * k + 1)}, bx2[k], y2[k]);
@@ -299,6 +305,9 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 // stored as [i / 4][lane][i % 4], so consecutive lanes hit consecutive 16-byte slots).  Per state and wave: 4
 // widening ops + 1 ds_write_b128 instead of 32 widening ops; one workgroup barrier per four states.  64 KB of LDS
 // per workgroup: two workgroups = 16 waves per CU, the same 4 waves per SIMD as before.
+#ifndef VMS_X8_AUX
+#define VMS_X8_AUX 2   /* nt: streaming */
+#endif
 constexpr int kLW = 8;                       // waves (rows) per workgroup
 constexpr int kLG = 4;                       // states per staged group
 constexpr int kLGroupFloats = 2 * kLG * kWave * kPK;   // [tensor][state % 4][1024]
@@ -396,6 +405,12 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             dst[kWave] = hi;
         }
     };
+    const bool lane_ckpt = p.x_has_sub == 3;
+    typedef uint32_t u32x4_p __attribute__((ext_vector_type(4)));
+    // per row (wave-uniform); x rows of >= 2 GiB do not exist (n_chunks * pitch floats)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xck, 0, (int)(p.n_chunks * xpitch * 4), 0x00020000);
+    typedef __attribute__((address_space(3))) float lds_f1p;
+    lds_f1p* const park = (lds_f1p*)(smem + 2 * kLGroupFloats) + wave * (2 * kLG * kWave) + lane;   // [wave][8th | 16th][state % 4][lane]
     int gi = c_lo * 4;
     stage_issue(gi);
     stage_commit(0);
@@ -447,7 +462,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
             float xs = fmaf(ea, hin, ex);
             const float hend = fmaf(pa, hin, px);  // state after this lane's last element
-            if (p.x_has_sub && ((lane + 1) * K) % 128 == 0 && row_ok) {  // 128-element sub-checkpoints for the backward kernel
+            if (p.x_has_sub == 1 && ((lane + 1) * K) % 128 == 0 && row_ok) {  // 128-element sub-checkpoints for the backward kernel
                 const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
                 xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
             }
@@ -458,11 +473,39 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
                 xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
                 VMS_ELP(bx2, i) = xs;  // x_i
             }
+            // 8-element checkpoints (vms_hip.h, x_has_sub == 3): the state after the lane's 8th and 16th element, parked in
+            // a wave-private LDS slot until the group's barrier is behind (see the flush below)
+            if (lane_ckpt) {
+                park[(n & 3) * kWave] = bx2[3].y;
+                park[(kLG + (n & 3)) * kWave] = bx2[7].y;
+            }
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
                 const f4 cq = k < 2 ? c0 : k < 4 ? c1 : k < 6 ? c2 : c3;
                 y2[k] = pk_fma_p((k & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y}, bx2[k], y2[k]);
             }
+        };
+        // 8-element checkpoints of group sg, out of the park: two 16-byte stores per lane.  Issued a barrier AFTER the values
+        // appear: loads and stores share vmcnt and complete out of order with respect to each other, so the wait for the
+        // staged B / C is a vmcnt(0) -- behind stores a few hundred cycles old it stalled every group for their round trip
+        auto flush_park = [&](const int sg) __attribute__((always_inline)) {
+                // the row's x through a buffer resource: uniform offsets in the SGPR operand, lanes past the end dropped.
+                // Layout [state / 4][8-element index][state % 4]; the park doubles as a transposition: lane l stores index l
+                // (source lane l / 2, its 8th or 16th element) and index 64 + l, so that each instruction writes 1 KB of
+                // whole lines (16 bytes at a 32-byte stride -- a lane storing its own two indices -- cost +90 us per launch)
+                const int so = (int)(((c >> 1) * xpitch + 2 * N + (sg * 256 + (c & 1) * 128) * 4) * 4);
+                const lds_f1p* const src = park - lane + (lane & 1) * (kLG * kWave) + (lane >> 1);
+                f4 va, vb;
+#pragma unroll
+                for (int s4 = 0; s4 < kLG; ++s4) {
+                    va[s4] = src[s4 * kWave];
+                    vb[s4] = src[s4 * kWave + 32];
+                }
+                const int la = c * CS + (lane >> 1) * K;
+                const uint32_t voa = la < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
+                const uint32_t vob = la + 32 * K < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, VMS_X8_AUX);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, VMS_X8_AUX);
         };
 #pragma unroll 1
         for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
@@ -474,6 +517,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             do_state(4 * sg + 3, buf);
             stage_commit(buf ^ 1);   // every wave left that buffer at the previous barrier
             __syncthreads();
+            if (lane_ckpt) flush_park(sg);
         }
         float y[K];
 #pragma unroll
@@ -683,7 +727,25 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     const bool lds_ok = !rag && (p.dim / p.n_groups) % kLW == 0;   // a workgroup's rows share one B / C group
 #endif
     const bool mixed = p.reverse_from > 0 && p.reverse_from < p.batch;
-    const size_t smem_l = sizeof(float) * 2 * kLGroupFloats;        // 64 KB
+    // 64 KB of fp32 B / C + (x_has_sub == 3) 16 KB of parked checkpoints: two workgroups fill a CU's 160 KB exactly
+    const size_t smem_l = sizeof(float) * 2 * kLGroupFloats + (p.x_has_sub == 3 ? sizeof(float) * 2 * kLG * kWave * kLW : 0);
+    if (smem_l > 64 * 1024) {
+        static PerDeviceOnce attr_once;
+        const hipError_t arc = attr_once.run([&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+#define VMS_AL(Z_, R_)                                                                                              \
+            if (e == hipSuccess)                                                                                    \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_>),              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+            VMS_AL(true, 0); VMS_AL(true, 1); VMS_AL(true, 2); VMS_AL(false, 0); VMS_AL(false, 1); VMS_AL(false, 2);
+#undef VMS_AL
+            return e;
+        });
+        if (arc != hipSuccess) {
+            set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", 80 * 1024, hipGetErrorString(arc));
+            return VMS_ERR_LAUNCH;
+        }
+    }
     const dim3 grid_l(p.batch * ((p.dim + kLW - 1) / kLW) * n_seg), block_l(kLW * kWave);
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \

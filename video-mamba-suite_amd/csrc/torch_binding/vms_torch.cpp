@@ -158,7 +158,7 @@ void fill_scan(vms_scan_fwd_params& P, const ScanDims& s, const Tensor& u, const
     P.out = mptr(out); P.out_z = mptr(out_z); P.x = mptr(x);
     if (x.has_value()) {
         P.x_chunk_stride = x->stride(2);
-        P.x_has_sub = (x->stride(2) >= 18 * s.dstate && x->stride(3) == 1) ? 1 : 0;
+        P.x_has_sub = x->stride(3) != 1 ? 0 : x->stride(2) >= 258 * s.dstate ? 3 : x->stride(2) >= 18 * s.dstate ? 1 : 0;
     }
     P.u_batch_stride = u.stride(0); P.u_d_stride = u.stride(1);
     P.delta_batch_stride = delta.stride(0); P.delta_d_stride = delta.stride(1);
@@ -175,7 +175,7 @@ void fill_scan(vms_scan_fwd_params& P, const ScanDims& s, const Tensor& u, const
 // -> [out, x, (out_z)]   (selective_scan.cpp:226-336).  B / C must already carry the padding bc_pad promises.
 std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
                              const OptT& z_, const OptT& delta_bias_, bool delta_softplus, bool reverse, const OptT& out_z_into,
-                             int64_t bc_pad, int64_t impl, int64_t segments, int64_t reverse_from = 0) {
+                             int64_t bc_pad, int64_t impl, int64_t segments, int64_t reverse_from = 0, int64_t x_mode = -1) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
     // before the workspace query and the allocations: the split decision reads the CU count of the CURRENT device
     c10::DeviceGuard guard(u.device());
@@ -193,10 +193,13 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
     const int64_t n_chunks = (s.seqlen + 2047) / 2048;
     // the reference-shaped x is a view of a wider buffer whose tail carries 128-element sub-checkpoints for the
     // backward kernel (include/vms_hip.h)
-    Tensor x = at::empty({s.batch, s.dim, n_chunks, s.dstate * 18}, u.options().dtype(at::kFloat)).narrow(3, 0, s.dstate * 2);
+    // (the library picks the pitch: 8-element checkpoints -- x_has_sub == 3 -- when the backward kernel that reads them takes the
+    // problem and x_mode allows, else the 128-element ones; only sizes and flags of the descriptor are read)
     vms_scan_fwd_params P;
+    fill_scan(P, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, OptT(), delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
+    const int64_t pitch = vms_scan_x_pitch(&P, (int32_t)x_mode);
+    Tensor x = at::empty({s.batch, s.dim, n_chunks, pitch}, u.options().dtype(at::kFloat)).narrow(3, 0, s.dstate * 2);
     fill_scan(P, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
-    P.x_has_sub = 1;
     P.out_z_accumulate = out_z_into.has_value();
     Tensor ws;
     const int64_t nws = vms_scan_fwd_workspace_bytes(&P);   // state carries of a sequence-split forward
@@ -534,8 +537,9 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
         else at::matmul_out(delta, dt_proj_w, dt_in);
     }
     const PaddedBC bc = pad_bc(x_dbl.narrow(1, R, N).unsqueeze(1), x_dbl.narrow(1, R + N, N).unsqueeze(1), reverse, reverse_from > 0);
+    // proj_flags bit 4: nothing will run this node's backward (small checkpoint layout); bit 8: keep the 128-element checkpoints
     std::vector<Tensor> r = scan_fwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, delta_softplus, reverse, out_z_into, bc.pad, impl, segments,
-                                     reverse_from);
+                                     reverse_from, (proj_flags & 12) ? 1 : -1);
     return {r[2], conv_out, x_dbl, delta, r[1], r[0]};
 }
 
@@ -648,7 +652,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     namespace py = pybind11;
     m.def("scan_fwd", &scan_fwd, py::arg("u"), py::arg("delta"), py::arg("A"), py::arg("B"), py::arg("C"), py::arg("D"), py::arg("z"),
           py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("bc_pad"), py::arg("impl"),
-          py::arg("segments"), py::arg("reverse_from") = 0);
+          py::arg("segments"), py::arg("reverse_from") = 0, py::arg("x_mode") = -1);
     m.def("scan_bwd", &scan_bwd, py::arg("u"), py::arg("delta"), py::arg("A"), py::arg("B"), py::arg("C"), py::arg("D"), py::arg("z"),
           py::arg("delta_bias"), py::arg("dout"), py::arg("x"), py::arg("out"), py::arg("dz"), py::arg("delta_softplus"),
           py::arg("recompute_out_z"), py::arg("reverse"), py::arg("zeroed"), py::arg("keep_fp32"), py::arg("accumulate_dz"), py::arg("bc_pad"),

@@ -59,7 +59,8 @@ class SelectiveScanFn(torch.autograd.Function):
             B = B.unsqueeze(1)
         if ctx.squeeze_C:
             C = C.unsqueeze(1)
-        out, x, *rest = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus)
+        out, x, *rest = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, delta_bias, delta_softplus,
+                                                for_backward=any(ctx.needs_input_grad))
         ctx.delta_softplus = delta_softplus
         ctx.has_z = z is not None
         ctx.has_D = D is not None
@@ -181,6 +182,19 @@ def _mfma_proj():
     return (1 if os.environ.get("VMS_MFMA_PROJ") == "1" else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2)
 
 
+def _for_backward(ctx):
+    """Will this node's backward run?  (then the forward scan leaves 8-element checkpoints for it, vms_hip.h x_has_sub == 3:
+    537 MB at (8, 1024, 8192) instead of 34; an inference forward keeps the small layout.)  Contexts without the flag -- the
+    per-direction stand-ins of the bidirectional node -- inherit `for_backward` from their parent."""
+    nig = getattr(ctx, "needs_input_grad", None)
+    return getattr(ctx, "for_backward", True) if nig is None else any(nig)
+
+
+def _x_flags(ctx):
+    """inner_fwd proj_flags bits 4 / 8: no backward / VMS_X_LAYOUT=1 (keep the 128-element checkpoints)."""
+    return (0 if _for_backward(ctx) else 4) | (8 if os.environ.get("VMS_X_LAYOUT") == "1" else 0)
+
+
 def _autocast_weights(*ws):
     if not torch.is_autocast_enabled():
         return ws
@@ -287,7 +301,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous() if D is not None else None
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
-            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj())
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx))
         ctx.reverse_from = int(reverse_from)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
         ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
@@ -316,14 +330,15 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
 
     # out_z_into: the gated output is added to that tensor by the kernel (second direction of a bidirectional node)
     out, ckpt, out_z = selective_scan_cuda.fwd(conv_out, delta, A, B, C, D, z, delta_bias, delta_softplus, reverse,
-                                               **({} if out_z_into is None else {"out_z_into": out_z_into}), **rf)
+                                               **({} if out_z_into is None else {"out_z_into": out_z_into}), **rf,
+                                               for_backward=_for_backward(ctx))
     saved_b = (None, None, None)
     if A_b is not None:
         assert not A_b.is_complex(), "A should not be complex!!"
         # the second scan reads the same tensors in the opposite direction (the reference flips copies of
         # all of them, SSI:499-507); its outputs come back in the original order
         out_b, ckpt_b, out_z_b = selective_scan_cuda.fwd(
-            conv_out, delta, A_b, B, C, D, z, delta_bias, delta_softplus, not reverse)
+            conv_out, delta, A_b, B, C, D, z, delta_bias, delta_softplus, not reverse, for_backward=_for_backward(ctx))
         out_z = out_z + out_z_b
         saved_b = (A_b, ckpt_b, out_b)
 
@@ -516,6 +531,7 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
             sub = _SubCtx()
             sub.w_dtype_override = param_dtype   # the PARAMETERS' dtype, not that of the autocast copies made above
+            sub.for_backward = any(ctx.needs_input_grad)
             # the second direction's scan adds its gated output to the first's
             out = _inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
                                  delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out)

@@ -88,20 +88,24 @@ def pad_bc(B, C, reverse=False, both=False):
     return F.pad(B, (0, pad))[..., :seqlen], F.pad(C, (0, pad))[..., :seqlen], pad
 
 
-def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, bc_pad=None, reverse_from=0):
+def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, out_z_into=None, bc_pad=None, reverse_from=0,
+        for_backward=True):
     """-> [out, x, (out_z)]   (selective_scan.cpp:226-336)
     reverse (extension, default off): scan right-to-left == flip(fwd(flip(..))) without copies.
     out_z_into (extension): a (batch, dim, seqlen) tensor the gated output is ADDED to (and that is returned as
     out_z) -- the other direction's output of a bidirectional block.
     bc_pad (extension): None = pad B / C here when the length needs it (pad_bc); an int = the caller already did.
-    reverse_from (extension, vms_hip.h ABI v5): batch entries >= reverse_from run right-to-left, the others left-to-right."""
+    reverse_from (extension, vms_hip.h ABI v5): batch entries >= reverse_from run right-to-left, the others left-to-right.
+    for_backward (extension, ABI v7): False = x will not be handed to bwd (inference): the binding allocates the small
+    checkpoint layout instead of the 8-element checkpoints the backward kernel prefers (vms_hip.h x_has_sub == 3)."""
     ext = _k.ext()
     impl = _k.scan_impl_from_env()
     if ext is not None and impl < _k.IMPL_ROWS:   # compiled binding: same checks / allocations / launch in C++
         if bc_pad is None:
             B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         return ext.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, bool(delta_softplus), bool(reverse), out_z_into,
-                            bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from))
+                            bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from),
+                            _k.x_mode_from_env() if for_backward else 1)
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
@@ -117,7 +121,7 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
     if bc_pad is None:
         B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
     x = _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, None, delta_softplus, reverse,
-                    out_z_into is not None, bc_pad, reverse_from)
+                    out_z_into is not None, bc_pad, reverse_from, for_backward)
     return [out, x] + ([out_z] if z_ is not None else [])
 
 

@@ -135,7 +135,7 @@ EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
     "vms_sizeof_scan_bwd_params", "vms_sizeof_conv_fwd_params", "vms_sizeof_conv_bwd_params",
-    "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems",
+    "vms_scan_fwd_workspace_bytes", "vms_scan_bwd_workspace_bytes", "vms_scan_x_elems", "vms_scan_x_pitch",
     "vms_layer_norm_fwd", "vms_layer_norm_bwd", "vms_layer_norm_bwd_partials", "vms_sizeof_norm_params",
     "vms_sizeof_norm_bwd_params", "vms_selective_state_update", "vms_sizeof_state_update_params",
     "vms_last_kernel", "vms_build_flags",
@@ -190,7 +190,7 @@ def ext():
             lib()
             try:
                 import _vms_torch
-                if _vms_torch.abi_version() == 6:
+                if _vms_torch.abi_version() == 7:
                     _ext = _vms_torch
             except ImportError as e:
                 # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
@@ -242,8 +242,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         L.vms_last_kernel.restype = ctypes.c_char_p
-        if L.vms_abi_version() != 6:
-            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 6: rebuild it")
+        if L.vms_abi_version() != 7:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 7: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
@@ -257,6 +257,8 @@ def lib():
             getattr(L, fn).restype = ctypes.c_int
         for fn in EXPORTS[11:14]:
             getattr(L, fn).restype = ctypes.c_int64
+        L.vms_scan_x_pitch.restype = ctypes.c_int64
+        L.vms_scan_x_pitch.argtypes = [ctypes.c_void_p, ctypes.c_int32]
         _lib = L
     return _lib
 
@@ -302,6 +304,20 @@ def dtype_code(t):
         raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
 
 
+def x_mode_from_env():
+    """vms_scan_x_pitch mode of a forward whose backward will run: VMS_X_LAYOUT=1 keeps the 128-element sub-checkpoints
+    (16x less checkpoint memory, backward scan ~10 % slower); default: the library's choice (8-element checkpoints when
+    the backward kernel that uses them takes the problem)."""
+    return 1 if os.environ.get("VMS_X_LAYOUT") == "1" else -1
+
+
+def x_layout_of(x, dstate):
+    """vms_hip.h x_has_sub of a (batch, dim, n_chunks, 2 * dstate) view: what its pitch has room for."""
+    if x.stride(3) != 1:
+        return 0
+    return 3 if x.stride(2) >= 258 * dstate else (1 if x.stride(2) >= 18 * dstate else 0)
+
+
 def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False, reverse_from=0):
     batch, dim, seqlen = u.shape
     dstate = A.shape[1]
@@ -322,7 +338,7 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
         # sub-checkpoints behind the reference-shaped slots, or the dense tensor followed by the
         # row-major kernels' checkpoint region (see include/vms_hip.h)
         P.x_chunk_stride = x.stride(2)
-        P.x_has_sub = int(x.stride(2) >= 18 * dstate and x.stride(3) == 1)
+        P.x_has_sub = x_layout_of(x, dstate)
     P.u_batch_stride, P.u_d_stride = u.stride(0), u.stride(1)
     P.delta_batch_stride, P.delta_d_stride = delta.stride(0), delta.stride(1)
     if z is not None:
@@ -368,8 +384,9 @@ def _ws_bytes(fn_name, params, ref_tensor):
 
 
 def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse=False,
-             out_z_accumulate=False, bc_pad=0, reverse_from=0):
-    """x is None: this function chooses the checkpoint layout, allocates x and returns it."""
+             out_z_accumulate=False, bc_pad=0, reverse_from=0, for_backward=True):
+    """x is None: this function chooses the checkpoint layout, allocates x and returns it (for_backward = False: the
+    small layout -- nothing will read the 8-element checkpoints)."""
     P = ScanFwdParams()
     fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
     P.out_z_accumulate = int(bool(out_z_accumulate))
@@ -389,9 +406,10 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
         else:
             # the reference-shaped tensor is a view of a wider buffer whose tail carries 128-element
             # sub-checkpoints for the backward kernel (include/vms_hip.h)
-            x = torch.empty(batch, dim, n_chunks, dstate * 18, device=u.device, dtype=torch.float32)[..., :dstate * 2]
+            pitch = lib().vms_scan_x_pitch(ctypes.byref(P), x_mode_from_env() if for_backward else 1)
+            x = torch.empty(batch, dim, n_chunks, pitch, device=u.device, dtype=torch.float32)[..., :dstate * 2]
             P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
-            P.x_has_sub = 1
+            P.x_has_sub = x_layout_of(x, dstate)
     if not P.workspace:
         nws = _ws_bytes("vms_scan_fwd_workspace_bytes", P, u)   # state carries of a sequence-split forward
         if nws > 0:
