@@ -45,8 +45,8 @@ B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
-TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r01h_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03y_traffic.json")
+TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def profiled_traffic(kernel):
@@ -488,7 +488,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                        "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
                        "kernel_timing": "inside the timed region" if inline_timing else f"{kt_steps} extra steps after the timed region",
-                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")), "comm": comm, "host": host},
+                       "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")),
+                       # vms_hip.h x_has_sub: 3 = the forward scan leaves the state after every 8 elements for the backward
+                       # scan (8 B D L more bytes per launch of either, NOT counted in the algorithmic bytes below)
+                       "x_layout": 1 if os.environ.get("VMS_X_LAYOUT") == "1" else 3, "comm": comm, "host": host},
             "kernels": kern,
         }
         if kern:
@@ -500,6 +503,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                                "traffic_source": (f"{src}: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel at this "
                                                   "size, committed profile (not measured in this run)") if src else None,
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
+            if dom.startswith("vms_selective_scan") and res["config"]["x_layout"] == 3:
+                # the design's own extra traffic (8-element checkpoints, fp32): in `traffic`, not in `achieved`
+                res["roofline"]["checkpoint_bytes_per_launch"] = b * d_inner * (l // 8) * D_STATE * 4
             if dom == "vms_selective_scan_bwd":   # SURVEY 8d also counts an out_z rewrite (9 B D L s) the blocks' nodes never ask for
                 ab8 = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l, bwd_out_z=True)[dom]
                 res["roofline"]["algorithmic_bytes_survey_8d"] = ab8
