@@ -693,8 +693,11 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     // XL (x_has_sub == 3): the forward left the state after every 8 elements; a lane takes the one entering its elements
     // instead of rebuilding it (its own 8-step recurrence from zero + the row scan of the lane aggregates)
     float xin[XL ? N : 1];
+    // one buffer resource per batch entry (workgroup-uniform): a batch entry's x stays under 2 GiB (host)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(x_b), 0, XL ? (int)((int64_t)p.batch * p.dim * p.n_chunks * p.x_chunk_stride * 4) : 0, 0x00020000);
+        const_cast<float*>(x_b) + (XL ? (int64_t)b * p.dim * p.n_chunks * p.x_chunk_stride : 0), 0,
+        XL ? (int)((int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4) : 0, 0x00020000);
+    const uint32_t o_xl = static_cast<uint32_t>((int64_t)dc * p.n_chunks * p.x_chunk_stride);   // the row inside its batch entry
     const int n_c = (L + CH - 1) / CH;
     const uint32_t o_x = p.x ? static_cast<uint32_t>(((int64_t)b * p.dim + dc) * p.n_chunks * p.x_chunk_stride) : 0u;
     // XL: the states entering this lane's 8 elements of chunk cc, four states (n0 .. n0 + 3) at a time: requested as soon as
@@ -703,7 +706,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     auto request_x = [&](int cc, int n0) __attribute__((always_inline)) {
         const int idx8 = cc * (CH / 8) + j - 1;
         const uint32_t xo = cc >= 0 && idx8 >= 0 && cc * CH + j * K < L   // lanes past the row's end: 0, not unwritten memory
-                                ? (o_x + (uint32_t)((idx8 >> 8) * (int)p.x_chunk_stride + 2 * N + (idx8 & 255) * 4)) * 4u
+                                ? (o_xl + (uint32_t)((idx8 >> 8) * (int)p.x_chunk_stride + 2 * N + (idx8 & 255) * 4)) * 4u
                                 : 0x80000000u;
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, n0 * 1024, 0));
 #pragma unroll
@@ -1024,7 +1027,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from).  A workgroup serves one batch
 // entry: the direction is workgroup-uniform, one branch selects the body.
-// XL: x carries the forward's 8-element checkpoints (x_has_sub == 3) and spans < 2 GiB (one buffer resource)
+// XL: x carries the forward's 8-element checkpoints (x_has_sub == 3), < 2 GiB per batch entry (one buffer resource each)
 template <typename T, bool HZ, int RM, int W, bool XL>
 __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
     if constexpr (RM == 2) {
@@ -1222,8 +1225,9 @@ int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q) {
 bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p) {
     if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || p.n_groups < 1 || p.dim % p.n_groups != 0) return false;
     if ((p.dim / p.n_groups) % kBRows != 0 || p.seqlen % kBK != 0) return false;
-    const int64_t n_chunks = (p.seqlen + 2047) / 2048;
-    return (int64_t)p.batch * p.dim * n_chunks * 258 * kBN * 4 < ((int64_t)1 << 31);
+    const int64_t n_chunks = (p.seqlen + 2047) / 2048, lim = (int64_t)1 << 31;
+    // a batch entry's x under 2 GiB (one buffer resource per batch entry), all of x under 2^31 elements (scan_bwd_pair_eligible)
+    return (int64_t)p.dim * n_chunks * 258 * kBN * 4 < lim && (int64_t)p.batch * p.dim * n_chunks * 258 * kBN < lim;
 }
 
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
@@ -1313,7 +1317,7 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     }
     const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
     // the forward's 8-element checkpoints (x_has_sub == 3), addressed through one buffer resource
-    const bool xl = p.x_has_sub == 3 && (int64_t)p.batch * p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
+    const bool xl = p.x_has_sub == 3 && (int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
 #define VMS_L4(Z_, R_)                                                                                             \
     do {                                                                                                           \
         if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry); \
