@@ -329,7 +329,8 @@ struct Raw8 {
     }
 };
 
-template <typename T, bool HZ, bool REV>
+// XC: the state after every 8 elements goes to x (vms_hip.h x_has_sub == 3)
+template <typename T, bool HZ, bool REV, bool XC>
 __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, const int n_seg, const float2* __restrict__ seg_carry) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kPK, N = kPN, CS = kWave * K;
@@ -405,12 +406,41 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             dst[kWave] = hi;
         }
     };
-    const bool lane_ckpt = p.x_has_sub == 3;
     typedef uint32_t u32x4_p __attribute__((ext_vector_type(4)));
     // per row (wave-uniform); x rows of >= 2 GiB do not exist (n_chunks * pitch floats)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xck, 0, (int)(p.n_chunks * xpitch * 4), 0x00020000);
     typedef __attribute__((address_space(3))) float lds_f1p;
     lds_f1p* const park = (lds_f1p*)(smem + 2 * kLGroupFloats) + wave * (2 * kLG * kWave) + lane;   // [wave][8th | 16th][state % 4][lane]
+    // 8-element checkpoints of group g of chunk cc, out of the park: two 16-byte stores per lane through the row's buffer
+    // resource (uniform offsets in the SGPR operand; lanes past the end, and everything when !valid, dropped by an out-of-range
+    // offset: no branch, so that the compiler can count what is in flight).  Layout [state / 4][8-element index][state % 4];
+    // the park doubles as a transposition: lane l stores index l (source lane l / 2, its 8th or 16th element) and index
+    // 64 + l, so that each instruction writes 1 KB of whole lines (16 bytes at a 32-byte stride -- a lane storing its own two
+    // indices -- cost +90 us per launch).
+    // WHEN: memory operations complete in issue order, loads and stores alike (one vmcnt).  Stored where the values appear, or
+    // right after the group's barrier, the stores sit in front of the next B / C requests and every wait for those is a wait
+    // for the stores' round trip (+35-50 us per launch).  They go out right BEHIND the next group's B / C requests instead:
+    // the wait for B / C becomes vmcnt(2) and leaves them in flight.
+    auto flush_park = [&](const int cc, const int g, const bool valid) __attribute__((always_inline)) {
+        const int so = (int)(((cc >> 1) * xpitch + 2 * N + (g * 256 + (cc & 1) * 128) * 4) * 4);
+        const lds_f1p* const src = park - lane + (lane & 1) * (kLG * kWave) + (lane >> 1);
+        f4 va, vb;
+#pragma unroll
+        for (int s4 = 0; s4 < kLG; ++s4) {
+            va[s4] = src[s4 * kWave];
+            vb[s4] = src[s4 * kWave + 32];
+        }
+        const int la = cc * CS + (lane >> 1) * K;
+        const uint32_t voa = valid && la < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
+        const uint32_t vob = valid && la + 32 * K < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, VMS_X8_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, VMS_X8_AUX);
+        // the first dword of the second store's data came out overwritten now and then (3-8 values per 65 K) when hipcc put
+        // a VALU write of that register right behind the store (the 16-byte-store write-data hazard, which its hazard
+        // recogniser takes to be absent with an SGPR offset): the data registers stay live up to two wait states behind the
+        // stores (a scheduling barrier here instead spilled 40 registers into the state loop)
+        asm volatile("s_nop 1" ::"v"(va), "v"(vb));
+    };
     int gi = c_lo * 4;
     stage_issue(gi);
     stage_commit(0);
@@ -462,7 +492,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
             float xs = fmaf(ea, hin, ex);
             const float hend = fmaf(pa, hin, px);  // state after this lane's last element
-            if (p.x_has_sub == 1 && ((lane + 1) * K) % 128 == 0 && row_ok) {  // 128-element sub-checkpoints for the backward kernel
+            if (!XC && p.x_has_sub == 1 && ((lane + 1) * K) % 128 == 0 && row_ok) {  // 128-element sub-checkpoints for the backward kernel
                 const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
                 xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
             }
@@ -474,8 +504,8 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
                 VMS_ELP(bx2, i) = xs;  // x_i
             }
             // 8-element checkpoints (vms_hip.h, x_has_sub == 3): the state after the lane's 8th and 16th element, parked in
-            // a wave-private LDS slot until the group's barrier is behind (see the flush below)
-            if (lane_ckpt) {
+            // a wave-private LDS slot until the next group's B / C requests are out (flush_park)
+            if constexpr (XC) {
                 park[(n & 3) * kWave] = bx2[3].y;
                 park[(kLG + (n & 3)) * kWave] = bx2[7].y;
             }
@@ -485,39 +515,17 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
                 y2[k] = pk_fma_p((k & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y}, bx2[k], y2[k]);
             }
         };
-        // 8-element checkpoints of group sg, out of the park: two 16-byte stores per lane.  Issued a barrier AFTER the values
-        // appear: loads and stores share vmcnt and complete out of order with respect to each other, so the wait for the
-        // staged B / C is a vmcnt(0) -- behind stores a few hundred cycles old it stalled every group for their round trip
-        auto flush_park = [&](const int sg) __attribute__((always_inline)) {
-                // the row's x through a buffer resource: uniform offsets in the SGPR operand, lanes past the end dropped.
-                // Layout [state / 4][8-element index][state % 4]; the park doubles as a transposition: lane l stores index l
-                // (source lane l / 2, its 8th or 16th element) and index 64 + l, so that each instruction writes 1 KB of
-                // whole lines (16 bytes at a 32-byte stride -- a lane storing its own two indices -- cost +90 us per launch)
-                const int so = (int)(((c >> 1) * xpitch + 2 * N + (sg * 256 + (c & 1) * 128) * 4) * 4);
-                const lds_f1p* const src = park - lane + (lane & 1) * (kLG * kWave) + (lane >> 1);
-                f4 va, vb;
-#pragma unroll
-                for (int s4 = 0; s4 < kLG; ++s4) {
-                    va[s4] = src[s4 * kWave];
-                    vb[s4] = src[s4 * kWave + 32];
-                }
-                const int la = c * CS + (lane >> 1) * K;
-                const uint32_t voa = la < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
-                const uint32_t vob = la + 32 * K < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, VMS_X8_AUX);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, VMS_X8_AUX);
-        };
 #pragma unroll 1
         for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
             const int buf = gi & 1;
             stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
+            if constexpr (XC) flush_park(sg > 0 ? c : c - 1, (sg + kLG - 1) & (kLG - 1), sg > 0 || c > c_lo);   // the group before this one
             do_state(4 * sg, buf);
             do_state(4 * sg + 1, buf);
             do_state(4 * sg + 2, buf);
             do_state(4 * sg + 3, buf);
             stage_commit(buf ^ 1);   // every wave left that buffer at the previous barrier
             __syncthreads();
-            if (lane_ckpt) flush_park(sg);
         }
         float y[K];
 #pragma unroll
@@ -549,21 +557,22 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             if (r == 2048 || last) xb[2 * lane + 1] = hreg;
         }
     }
+    if constexpr (XC) flush_park(c_hi - 1, kLG - 1, c_hi > c_lo);   // the last group of the last chunk
 }
 
 
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from: entries >= p.reverse_from run
 // right-to-left).  A workgroup serves one batch entry, so the direction is workgroup-uniform: one branch, both bodies.
-template <typename T, bool HZ, int RM>
+template <typename T, bool HZ, int RM, bool XC>
 __global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
                                                                         const float2* __restrict__ seg_carry) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % p.batch;
-        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true>(p, n_seg, seg_carry);
-        else scan_fwd_lds_body<T, HZ, false>(p, n_seg, seg_carry);
+        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true, XC>(p, n_seg, seg_carry);
+        else scan_fwd_lds_body<T, HZ, false, XC>(p, n_seg, seg_carry);
     } else {
-        scan_fwd_lds_body<T, HZ, RM == 1>(p, n_seg, seg_carry);
+        scan_fwd_lds_body<T, HZ, RM == 1, XC>(p, n_seg, seg_carry);
     }
 }
 
@@ -735,7 +744,7 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
             hipError_t e = hipSuccess;
 #define VMS_AL(Z_, R_)                                                                                              \
             if (e == hipSuccess)                                                                                    \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_>),              \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true>),        \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
             VMS_AL(true, 0); VMS_AL(true, 1); VMS_AL(true, 2); VMS_AL(false, 0); VMS_AL(false, 1); VMS_AL(false, 2);
 #undef VMS_AL
@@ -747,18 +756,24 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
         }
     }
     const dim3 grid_l(p.batch * ((p.dim + kLW - 1) / kLW) * n_seg), block_l(kLW * kWave);
+#define VMS_LL(Z_, R_, S_)                                                                                         \
+    do {                                                                                                           \
+        if (p.x_has_sub == 3) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true>), grid_l, block_l, smem_l, stream, p, S_, carry);  \
+        else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false>), grid_l, block_l, smem_l, stream, p, S_, carry);                 \
+    } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
         if (rag) hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, true>), grid, block, 0, stream, p, 1, carry); \
-        else if (lds_ok) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_ ? 1 : 0>), grid_l, block_l, smem_l, stream, p, n_seg, carry); \
+        else if (lds_ok) VMS_LL(Z_, R_ ? 1 : 0, n_seg);                                                            \
         else hipLaunchKernelGGL((scan_fwd_pair_kernel<T, Z_, R_, false>), grid, block, 0, stream, p, n_seg, carry); \
     } while (0)
     if (mixed) {   // reverse_from: only the LDS kernel, unsplit (scan_fwd_pair_native_mixed); everything else is split by the host
-        if (p.z) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, true, 2>), grid_l, block_l, smem_l, stream, p, 1, carry);
-        else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, false, 2>), grid_l, block_l, smem_l, stream, p, 1, carry);
+        if (p.z) VMS_LL(true, 2, 1);
+        else VMS_LL(false, 2, 1);
     } else if (p.reverse) { if (p.z) VMS_L(true, true); else VMS_L(false, true); }
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
+#undef VMS_LL
     VMS_LAUNCH_CHECK();
     // distinct names per kernel: a shape that silently falls off the LDS kernel must be visible to callers and tests
     set_last_kernel(mixed ? "scan_fwd_pair_lds+mixed" : rag ? "scan_fwd_pair_ragged"
