@@ -189,7 +189,8 @@ int64_t vms_scan_x_elems(const vms_scan_fwd_params *p);
 /* the x pitch (floats between x[b,d,c,:] and x[b,d,c+1,:]) to allocate for this problem; only sizes and flags of *p are
  * read.  mode 0: 2*dstate (the reference's tensor, selective_scan.cpp:313: no fast backward); 1: 18*dstate (x_has_sub == 1);
  * 3 or -1 (the library's choice for a forward whose backward will run): 258*dstate (x_has_sub == 3) when the backward
- * kernel that uses it takes the problem and x stays under 2 GiB per batch entry and 2^31 elements in all, else 18*dstate.  The caller sets x_chunk_stride to the
+ * kernel that uses it takes the problem (variable B / C, dstate 16, (dim / n_groups) % 32 == 0), seqlen % 16 == 0 (the
+ * forward kernel that writes the checkpoints as whole lines) and x stays under 2 GiB per batch entry and 2^31 elements in all, else 18*dstate.  The caller sets x_chunk_stride to the
  * pitch and x_has_sub to 3 / 1 / 0 for pitch >= 258*dstate / >= 18*dstate / less. */
 int64_t vms_scan_x_pitch(const vms_scan_fwd_params *p, int32_t mode);
 

