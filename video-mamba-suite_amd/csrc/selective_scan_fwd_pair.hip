@@ -305,9 +305,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 // stored as [i / 4][lane][i % 4], so consecutive lanes hit consecutive 16-byte slots).  Per state and wave: 4
 // widening ops + 1 ds_write_b128 instead of 32 widening ops; one workgroup barrier per four states.  64 KB of LDS
 // per workgroup: two workgroups = 16 waves per CU, the same 4 waves per SIMD as before.
-#ifndef VMS_X8_AUX
-#define VMS_X8_AUX 2   /* nt: streaming */
-#endif
+constexpr int kX8Aux = 2;                    // cache policy of the checkpoint stores: nt (streaming); none of the bits changes their cost
 constexpr int kLW = 8;                       // waves (rows) per workgroup
 constexpr int kLG = 4;                       // states per staged group
 constexpr int kLGroupFloats = 2 * kLG * kWave * kPK;   // [tensor][state % 4][1024]
@@ -433,8 +431,8 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         const int la = cc * CS + (lane >> 1) * K;
         const uint32_t voa = valid && la < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
         const uint32_t vob = valid && la + 32 * K < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, VMS_X8_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, VMS_X8_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, kX8Aux);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, kX8Aux);
         // the first dword of the second store's data came out overwritten now and then (3-8 values per 65 K) when hipcc put
         // a VALU write of that register right behind the store (the 16-byte-store write-data hazard, which its hazard
         // recogniser takes to be absent with an SGPR offset): the data registers stay live up to two wait states behind the
