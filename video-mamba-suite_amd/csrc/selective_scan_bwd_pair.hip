@@ -590,7 +590,10 @@ template <int W> struct B4 {
     static constexpr int kPair = kSG * W * 4 * kWave;   // floats of one group of states: [state][wave][4 lane + k]
     static constexpr int kRows = 4 * W;
     static constexpr int kPPT = 8 / W;                 // B / C pieces and slab outputs per thread (512 per chunk / pair)
-    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kBN * 4);
+    // per-(row, state) records: 16 records of 16 bytes per row + one record of padding -- at a 256-byte pitch the four rows of a
+    // wave sit on the same banks, and the record read every state makes (16 lanes of a row, one address) was a 4-way conflict
+    static constexpr int kRecPitch = kBN + 1;
+    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4);
 };
 
 template <typename T, bool HZ, bool REV, int W, bool XL>
@@ -605,7 +608,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const int lane = threadIdx.x & 63;
     const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, r = lane >> 4;
-    lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * kBN;
+    lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * B4<W>::kRecPitch;
     __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
     const int wg_per_seg = gridDim.x / n_seg;
     const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
