@@ -206,15 +206,17 @@ def ext():
 # Optional per-call device timing (used by bench.py): when a list is installed here every C-ABI
 # call is bracketed by two events on the stream the kernel is launched on.
 _timing = None
+_timing_only = None
 
 
-def start_timing(reserve=0):
+def start_timing(reserve=0, only=None):
     """reserve: launches expected until stop_timing() -- the compiled binding creates that many event pairs now, outside
-    the timed region (it grows the pool on demand if more arrive)."""
-    global _timing
-    _timing = []
+    the timed region (it grows the pool on demand if more arrive).  only: time this entry point alone (e.g.
+    "vms_selective_scan_bwd"): every timed launch puts two event records into the stream, ~6 us of idle GPU around it."""
+    global _timing, _timing_only
+    _timing, _timing_only = [], only
     if ext() is not None:
-        ext().timing_start(int(reserve))
+        ext().timing_start(int(reserve), only or "")
 
 
 def stop_timing():
@@ -271,7 +273,7 @@ def _call(fn_name, params, ref_tensor):
     if idx == torch.cuda.current_device():
         # the common case without the device guard and stream object: ~20 us less host time per call, which is
         # what small problems are bound by.  Timing (bench.py) only adds two event records on the same raw stream.
-        if _timing is None:
+        if _timing is None or (_timing_only and _timing_only != fn_name):
             rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx)))
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -282,11 +284,12 @@ def _call(fn_name, params, ref_tensor):
     else:
         with torch.cuda.device(ref_tensor.device):
             cur = torch.cuda.current_stream()
-            if _timing is not None:
+            timed = _timing is not None and not (_timing_only and _timing_only != fn_name)
+            if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(cur)
             rc = getattr(L, fn_name)(ctypes.byref(params), ctypes.c_void_p(cur.cuda_stream))
-            if _timing is not None:
+            if timed:
                 e1.record(cur)
                 _timing.append((fn_name, e0, e1))
     if rc != 0:
