@@ -45,7 +45,7 @@ B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03z_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03z2_traffic.json")
 TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
