@@ -189,3 +189,65 @@ def state_update(state, x, dt, A, B, C, D=None, z=None, dt_bias=None, dt_softplu
     fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(N), _p(st), _p(x), _p(dt), _p(A), _p(B), _p(C), _p(D),
        _p(z), _p(dt_bias), ctypes.c_int(bool(dt_softplus)), _p(out))
     return out, st
+
+
+# ---- complex A (SSI:111-116, 144-145; selective_scan.cpp:282-287) ------------------------------------------------
+def _cpairs(a):
+    """complex (..,) -> float32 (.., 2) pairs (contiguous)."""
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.complex64))
+    return a.view(np.float32).reshape(*a.shape, 2)
+
+
+def _cscan_args(u, delta, A, B, C):
+    u, delta = _c(u), _c(delta)
+    batch, dim, L = u.shape
+    N = A.shape[1]
+    var_B, var_C = not np.iscomplexobj(B), not np.iscomplexobj(C)   # variable B / C arrive as real (.., 2L) tensors
+    sqB, sqC = var_B and B.ndim == 3, var_C and C.ndim == 3
+    Bp = _c(_bc4(np.asarray(B), True)) if var_B else _cpairs(B)
+    Cp = _c(_bc4(np.asarray(C), True)) if var_C else _cpairs(C)
+    if var_B:
+        assert Bp.shape[-1] == 2 * L, "variable B of a complex scan is (batch, [G,] N, 2L)"
+    if var_C:
+        assert Cp.shape[-1] == 2 * L, "variable C of a complex scan is (batch, [G,] N, 2L)"
+    G = Bp.shape[1] if var_B else (Cp.shape[1] if var_C else 1)
+    return u, delta, _cpairs(A), Bp, Cp, batch, dim, L, N, G, var_B, var_C, sqB, sqC
+
+
+def cscan_fwd(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False, prec="f32"):
+    """Complex A.  -> dict(out, out_z, x=(b,d,n_chunks,2N) complex64 checkpoints, last_state=(b,d,N) complex64)."""
+    u, delta, Ap, Bp, Cp, batch, dim, L, N, G, var_B, var_C, _, _ = _cscan_args(u, delta, A, B, C)
+    D, z, delta_bias = map(_c, (D, z, delta_bias))
+    n_chunks = (L + 2047) // 2048
+    out = np.empty_like(u)
+    out_z = np.empty_like(u) if z is not None else None
+    x = np.zeros((batch, dim, n_chunks, 2 * N, 2), np.float32)
+    last = np.empty((batch, dim, N, 2), np.float32)
+    fn = getattr(lib(), "vms_oracle_cscan_fwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(N), ctypes.c_int(G),
+       _p(u), _p(delta), _p(Ap), _p(Bp), _p(Cp), _p(D), _p(z), _p(delta_bias),
+       ctypes.c_int(var_B), ctypes.c_int(var_C), ctypes.c_int(bool(delta_softplus)),
+       _p(out), _p(out_z), _p(x), _p(last))
+    return dict(out=out, out_z=out_z, x=x.view(np.complex64)[..., 0], last_state=last.view(np.complex64)[..., 0])
+
+
+def cscan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, delta_softplus=False, prec="f32"):
+    """Complex A: gradients in PyTorch's convention; dA and constant dB / dC complex64, variable dB / dC real (.., 2L)."""
+    u, delta, Ap, Bp, Cp, batch, dim, L, N, G, var_B, var_C, sqB, sqC = _cscan_args(u, delta, A, B, C)
+    D, z, delta_bias, dout = map(_c, (D, z, delta_bias, dout))
+    du, ddelta = np.empty_like(u), np.empty_like(u)
+    dA = np.zeros_like(Ap)
+    dB, dC = np.zeros_like(Bp), np.zeros_like(Cp)
+    dD = np.zeros(dim, np.float32) if D is not None else None
+    dz = np.empty_like(u) if z is not None else None
+    dbias = np.zeros(dim, np.float32) if delta_bias is not None else None
+    fn = getattr(lib(), "vms_oracle_cscan_bwd_" + prec)
+    fn.restype = None
+    fn(ctypes.c_int(batch), ctypes.c_int(dim), ctypes.c_int(L), ctypes.c_int(N), ctypes.c_int(G),
+       _p(u), _p(delta), _p(Ap), _p(Bp), _p(Cp), _p(D), _p(z), _p(delta_bias), _p(dout),
+       ctypes.c_int(var_B), ctypes.c_int(var_C), ctypes.c_int(bool(delta_softplus)),
+       _p(du), _p(ddelta), _p(dA), _p(dB), _p(dC), _p(dD), _p(dz), _p(dbias))
+    dB = (dB[:, 0] if sqB else dB) if var_B else dB.view(np.complex64)[..., 0]
+    dC = (dC[:, 0] if sqC else dC) if var_C else dC.view(np.complex64)[..., 0]
+    return dict(du=du, ddelta=ddelta, dA=dA.view(np.complex64)[..., 0], dB=dB, dC=dC, dD=dD, dz=dz, ddelta_bias=dbias)

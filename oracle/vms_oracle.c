@@ -433,3 +433,200 @@ void FN(vms_oracle_state_update)(int batch, int dim, int N, float *state, const 
             out[(size_t)b * dim + d] = (float)acc;
         }
 }
+
+/* ------------------------------------------------------------------------- *
+ * selective scan with COMPLEX A (the reference's weight_t = complex<float> instantiations,
+ * selective_scan.cpp:282-287; semantics = selective_scan_ref's complex branch, SSI:111-116, 144-145):
+ *   a_l = exp(delta_l A_n) (complex), x_l = a_l x_{l-1} + delta_l u_l B_{n,l}, y_l = 2 Re(sum_n C_{n,l} x_{l,n}).
+ * Complex numbers are (re, im) float pairs: A, constant B / C: (dim, N, 2); variable B / C: (batch, G, N, L, 2)
+ * = the reference's real (batch, G, N, 2L) tensors; x_ckpt: (batch, dim, n_chunks, 2N, 2) with the slots of the
+ * real function; last_state (batch, dim, N, 2).
+ * ------------------------------------------------------------------------- */
+typedef struct { real re, im; } cplx;
+static inline cplx c_mul(cplx a, cplx b) { cplx r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; return r; }
+static inline cplx c_conj(cplx a) { cplx r = {a.re, -a.im}; return r; }
+static inline cplx c_exp_scaled(real dl, cplx A) {
+    const real m = (real)exp((double)(dl * A.re));
+    cplx r = {m * (real)cos((double)(dl * A.im)), m * (real)sin((double)(dl * A.im))};
+    return r;
+}
+static inline cplx c_ld(const float *p, size_t i) { cplx r = {(real)p[2 * i], (real)p[2 * i + 1]}; return r; }
+
+void FN(vms_oracle_cscan_fwd)(int batch, int dim, int L, int N, int G,
+                              const float *u, const float *delta, const float *A,
+                              const float *Bm, const float *Cm, const float *Dv,
+                              const float *z, const float *delta_bias,
+                              int var_B, int var_C, int delta_softplus,
+                              float *out, float *out_z, float *x_ckpt, float *last_state) {
+    const int n_chunks = (L + 2047) / 2048;
+    const int dpg = dim / G;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < batch; ++b) {
+        for (int d = 0; d < dim; ++d) {
+            const int g = d / dpg;
+            const size_t row = ((size_t)b * dim + d) * L;
+            cplx *st = (cplx *)calloc((size_t)N, sizeof(cplx));
+            const real bias = delta_bias ? (real)delta_bias[d] : (real)0;
+            const real Dd = Dv ? (real)Dv[d] : (real)0;
+            for (int l = 0; l < L; ++l) {
+                real dl = (real)delta[row + l] + bias;
+                if (delta_softplus) dl = softplus_ref(dl);
+                const real ul = (real)u[row + l];
+                real y = 0;
+                for (int n = 0; n < N; ++n) {
+                    const cplx An = c_ld(A, (size_t)d * N + n);
+                    const cplx Bn = var_B ? c_ld(Bm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Bm, (size_t)d * N + n);
+                    const cplx Cn = var_C ? c_ld(Cm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Cm, (size_t)d * N + n);
+                    const cplx a = c_exp_scaled(dl, An);
+                    cplx s = c_mul(a, st[n]);
+                    s.re += dl * ul * Bn.re;
+                    s.im += dl * ul * Bn.im;
+                    st[n] = s;
+                    y += (real)2 * (s.re * Cn.re - s.im * Cn.im);
+                }
+                const real o = y + ul * Dd;
+                out[row + l] = (float)o;
+                if (z) {
+                    const real zl = (real)z[row + l];
+                    out_z[row + l] = (float)(o * zl * sigmoid_ref(zl));
+                }
+                if (x_ckpt) {
+                    const int c = l / 2048, r = l % 2048;
+                    float *xc = x_ckpt + (((size_t)b * dim + d) * n_chunks + c) * 4 * N;
+                    if (r == 1023 || (l == L - 1 && r < 1023))
+                        for (int n = 0; n < N; ++n) { xc[4 * n] = (float)st[n].re; xc[4 * n + 1] = (float)st[n].im; }
+                    if (r == 2047 || l == L - 1)
+                        for (int n = 0; n < N; ++n) { xc[4 * n + 2] = (float)st[n].re; xc[4 * n + 3] = (float)st[n].im; }
+                }
+            }
+            if (last_state)
+                for (int n = 0; n < N; ++n) {
+                    last_state[(((size_t)b * dim + d) * N + n) * 2] = (float)st[n].re;
+                    last_state[(((size_t)b * dim + d) * N + n) * 2 + 1] = (float)st[n].im;
+                }
+            free(st);
+        }
+    }
+}
+
+/* Backward of the function above; gradients of complex parameters in PyTorch's convention (dL/dRe + i dL/dIm), which is
+ * what the reference's kernels return (selective_scan_bwd_kernel.cuh:330-436) and what torch.autograd gives through
+ * selective_scan_ref (the fixtures):
+ *   g_l = 2 dy_l conj(C_l) + conj(a_{l+1}) g_{l+1};   dC_l = 2 dy_l conj(x_l);   dB_l = delta_l u_l g_l;
+ *   du_l = D dy_l + delta_l sum_n Re(conj(B) g);   ddelta_l = sum_n u_l Re(conj(B) g) + Re(conj(A a_l x_{l-1}) g);
+ *   dA_n = sum_l delta_l conj(a_l x_{l-1}) g_l.
+ * dA, constant dB / dC: (dim, N, 2); variable dB / dC: (batch, G, N, L, 2). */
+void FN(vms_oracle_cscan_bwd)(int batch, int dim, int L, int N, int G,
+                              const float *u, const float *delta, const float *A,
+                              const float *Bm, const float *Cm, const float *Dv,
+                              const float *z, const float *delta_bias, const float *dout,
+                              int var_B, int var_C, int delta_softplus,
+                              float *du, float *ddelta, float *dA, float *dB, float *dC,
+                              float *dD, float *dz, float *ddelta_bias) {
+    const int dpg = dim / G;
+    const size_t nBC = (size_t)batch * G * N * L;
+    cplx *dBs = var_B ? (cplx *)calloc(nBC, sizeof(cplx)) : NULL;
+    cplx *dCs = var_C ? (cplx *)calloc(nBC, sizeof(cplx)) : NULL;
+    cplx *dAs = (cplx *)calloc((size_t)dim * N, sizeof(cplx));
+    cplx *dBc = !var_B ? (cplx *)calloc((size_t)dim * N, sizeof(cplx)) : NULL;
+    cplx *dCc = !var_C ? (cplx *)calloc((size_t)dim * N, sizeof(cplx)) : NULL;
+    real *dDs = (real *)calloc((size_t)dim, sizeof(real));
+    real *dbs = (real *)calloc((size_t)dim, sizeof(real));
+#pragma omp parallel for schedule(static)
+    for (int d = 0; d < dim; ++d) {
+        const int g = d / dpg;
+        cplx *xs = (cplx *)malloc((size_t)L * N * sizeof(cplx));
+        real *dl_ = (real *)malloc((size_t)L * sizeof(real));
+        cplx *gst = (cplx *)malloc((size_t)N * sizeof(cplx));
+        cplx *rowB = var_B ? (cplx *)malloc((size_t)N * L * sizeof(cplx)) : NULL;
+        cplx *rowC = var_C ? (cplx *)malloc((size_t)N * L * sizeof(cplx)) : NULL;
+        for (int b = 0; b < batch; ++b) {
+            const size_t row = ((size_t)b * dim + d) * L;
+            const real bias = delta_bias ? (real)delta_bias[d] : (real)0;
+            const real Dd = Dv ? (real)Dv[d] : (real)0;
+            for (int n = 0; n < N; ++n) { gst[n].re = 0; gst[n].im = 0; }
+            for (int l = 0; l < L; ++l) {
+                real dl = (real)delta[row + l] + bias;
+                if (delta_softplus) dl = softplus_ref(dl);
+                dl_[l] = dl;
+                for (int n = 0; n < N; ++n) {
+                    const cplx An = c_ld(A, (size_t)d * N + n);
+                    const cplx Bn = var_B ? c_ld(Bm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Bm, (size_t)d * N + n);
+                    cplx s = c_mul(c_exp_scaled(dl, An), gst[n]);
+                    s.re += dl * (real)u[row + l] * Bn.re;
+                    s.im += dl * (real)u[row + l] * Bn.im;
+                    gst[n] = s;
+                    xs[(size_t)l * N + n] = s;
+                }
+            }
+            for (int n = 0; n < N; ++n) { gst[n].re = 0; gst[n].im = 0; } /* conj(a_{l+1}) g_{l+1} */
+            for (int l = L - 1; l >= 0; --l) {
+                const real ul = (real)u[row + l], dl = dl_[l];
+                real dy = (real)dout[row + l];
+                if (z) {
+                    real y = ul * Dd;
+                    for (int n = 0; n < N; ++n) {
+                        const cplx Cn = var_C ? c_ld(Cm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Cm, (size_t)d * N + n);
+                        const cplx x = xs[(size_t)l * N + n];
+                        y += (real)2 * (x.re * Cn.re - x.im * Cn.im);
+                    }
+                    const real zl = (real)z[row + l], s = sigmoid_ref(zl);
+                    dz[row + l] = (float)(dy * y * s * ((real)1 + zl * ((real)1 - s)));
+                    dy = dy * zl * s;
+                }
+                real dul = Dd * dy, ddl = 0;
+                dDs[d] += dy * ul;
+                for (int n = 0; n < N; ++n) {
+                    const cplx An = c_ld(A, (size_t)d * N + n);
+                    const cplx Bn = var_B ? c_ld(Bm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Bm, (size_t)d * N + n);
+                    const cplx Cn = var_C ? c_ld(Cm, (((size_t)b * G + g) * N + n) * L + l) : c_ld(Cm, (size_t)d * N + n);
+                    const cplx x = xs[(size_t)l * N + n];
+                    cplx gx = {(real)2 * dy * Cn.re + gst[n].re, -(real)2 * dy * Cn.im + gst[n].im};
+                    const cplx a = c_exp_scaled(dl, An);
+                    const cplx ax = {x.re - dl * ul * Bn.re, x.im - dl * ul * Bn.im}; /* a_l x_{l-1} */
+                    const real bg = Bn.re * gx.re + Bn.im * gx.im;                   /* Re(conj(B) g) */
+                    const cplx Aax = c_mul(An, ax);
+                    dul += dl * bg;
+                    ddl += ul * bg + (Aax.re * gx.re + Aax.im * gx.im);
+                    const cplx cag = c_mul(c_conj(ax), gx);
+                    dAs[(size_t)d * N + n].re += dl * cag.re;
+                    dAs[(size_t)d * N + n].im += dl * cag.im;
+                    const cplx dBv = {dl * ul * gx.re, dl * ul * gx.im};
+                    const cplx dCv = {(real)2 * dy * x.re, -(real)2 * dy * x.im};
+                    if (var_B) rowB[(size_t)n * L + l] = dBv;
+                    else { dBc[(size_t)d * N + n].re += dBv.re; dBc[(size_t)d * N + n].im += dBv.im; }
+                    if (var_C) rowC[(size_t)n * L + l] = dCv;
+                    else { dCc[(size_t)d * N + n].re += dCv.re; dCc[(size_t)d * N + n].im += dCv.im; }
+                    gst[n] = c_mul(c_conj(a), gx);
+                }
+                du[row + l] = (float)dul;
+                if (delta_softplus) {
+                    const real raw = (real)delta[row + l] + bias;
+                    if (raw <= (real)20) ddl = ddl * sigmoid_ref(raw);
+                }
+                ddelta[row + l] = (float)ddl;
+                dbs[d] += ddl;
+            }
+            if (var_B || var_C) {
+#pragma omp critical
+                {
+                    for (int n = 0; n < N; ++n)
+                        for (int l = 0; l < L; ++l) {
+                            const size_t o = (((size_t)b * G + g) * N + n) * L + l;
+                            if (var_B) { dBs[o].re += rowB[(size_t)n * L + l].re; dBs[o].im += rowB[(size_t)n * L + l].im; }
+                            if (var_C) { dCs[o].re += rowC[(size_t)n * L + l].re; dCs[o].im += rowC[(size_t)n * L + l].im; }
+                        }
+                }
+            }
+        }
+        free(xs); free(dl_); free(gst); free(rowB); free(rowC);
+    }
+    for (size_t i = 0; i < (size_t)dim * N; ++i) { dA[2 * i] = (float)dAs[i].re; dA[2 * i + 1] = (float)dAs[i].im; }
+    const size_t nB = var_B ? nBC : (size_t)dim * N, nC = var_C ? nBC : (size_t)dim * N;
+    const cplx *srcB = var_B ? dBs : dBc, *srcC = var_C ? dCs : dCc;
+    for (size_t i = 0; i < nB; ++i) { dB[2 * i] = (float)srcB[i].re; dB[2 * i + 1] = (float)srcB[i].im; }
+    for (size_t i = 0; i < nC; ++i) { dC[2 * i] = (float)srcC[i].re; dC[2 * i + 1] = (float)srcC[i].im; }
+    if (dD) for (int d = 0; d < dim; ++d) dD[d] = (float)dDs[d];
+    if (ddelta_bias) for (int d = 0; d < dim; ++d) ddelta_bias[d] = (float)dbs[d];
+    free(dBs); free(dCs); free(dAs); free(dBc); free(dCc); free(dDs); free(dbs);
+}

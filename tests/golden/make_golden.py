@@ -145,6 +145,53 @@ def gen_scan(ssi, name, batch, dim, dstate, L, groups=1, var_B=True, var_C=True,
          ddelta_bias=npf(bias.grad) if has_bias else None)
 
 
+def gen_cscan(ssi, name, batch, dim, dstate, L, groups=1, var_B=True, var_C=True, has_D=True, has_z=True, has_bias=True,
+              softplus=True, itype=torch.float32, b3=False, seed=0):
+    """Complex A: the recipe of test_selective_scan.py:53-88 with wtype = torch.complex64 (variable B / C are real
+    (.., 2L) tensors of interleaved (re, im) pairs; constant ones are complex (dim, dstate))."""
+    torch.random.manual_seed(seed)
+    A = (-0.5 * torch.rand(dim, dstate, dtype=torch.complex64)).requires_grad_()
+
+    def bc(var):
+        if not var:
+            return torch.randn(dim, dstate, dtype=torch.complex64).requires_grad_()
+        shape = (batch, dstate, 2 * L) if b3 else (batch, groups, dstate, 2 * L)
+        return torch.randn(*shape, dtype=itype).requires_grad_()
+
+    B, C = bc(var_B), bc(var_C)
+    D = torch.randn(dim).requires_grad_() if has_D else None
+    z = torch.randn(batch, dim, L, dtype=itype).requires_grad_() if has_z else None
+    bias = (0.5 * torch.rand(dim)).requires_grad_() if has_bias else None
+    u = torch.randn(batch, dim, L, dtype=itype).requires_grad_()
+    delta = (0.5 * torch.rand(batch, dim, L, dtype=itype)).requires_grad_()
+    out, last = ssi.selective_scan_ref(u, delta, A, B, C, D, z=z, delta_bias=bias, delta_softplus=softplus,
+                                       return_last_state=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+
+    def npc(t):   # complex tensors keep their dtype in the fixture
+        return None if t is None else (t.detach().numpy() if t.is_complex() else t.detach().float().numpy())
+
+    save(name, u=npf(u), delta=npf(delta), A=npc(A), B=npc(B), C=npc(C), D=npf(D), z=npf(z), delta_bias=npf(bias),
+         softplus=np.array(int(softplus)), itype=np.array(str(itype)), out=npf(out), last_state=npc(last), g=npf(g),
+         du=npf(u.grad), ddelta=npf(delta.grad), dA=npc(A.grad), dB=npc(B.grad), dC=npc(C.grad),
+         dD=npf(D.grad) if has_D else None, dz=npf(z.grad) if has_z else None,
+         ddelta_bias=npf(bias.grad) if has_bias else None)
+
+
+def gen_cscan_all(ssi):
+    gen_cscan(ssi, "cscan_L128_g1", 2, 4, 8, 128)
+    gen_cscan(ssi, "cscan_L372_g2", 2, 4, 8, 372, groups=2)
+    gen_cscan(ssi, "cscan_L1134_plain", 2, 4, 8, 1134, has_D=False, has_z=False, has_bias=False, softplus=False)
+    gen_cscan(ssi, "cscan_L2048_b3", 1, 4, 8, 2048, b3=True)
+    gen_cscan(ssi, "cscan_L2600_long", 1, 2, 4, 2600)
+    gen_cscan(ssi, "cscan_constBC", 2, 4, 8, 200, var_B=False, var_C=False)
+    gen_cscan(ssi, "cscan_constB", 2, 4, 8, 200, var_B=False)
+    gen_cscan(ssi, "cscan_constC", 2, 4, 8, 200, var_C=False)
+    gen_cscan(ssi, "cscan_bf16_L300", 2, 4, 16, 300, itype=torch.bfloat16)
+    gen_cscan(ssi, "cscan_f16_L130", 2, 4, 8, 130, itype=torch.float16)
+
+
 def gen_conv(cci, name, batch, dim, L, W, has_bias, silu, itype=torch.float32, seed=0):
     """Input recipe = test_causal_conv1d.py:36-50 (dim reduced)."""
     torch.random.manual_seed(seed)
@@ -344,6 +391,10 @@ def main():
         gen_state_update(ref, "ssu_N64_noz", 2, 40, 64, True, False, True, True, seed=3)
         gen_state_update(ref, "ssu_N5_odd", 1, 9, 5, True, True, False, False, seed=4)
         return
+    if os.environ.get("GOLDEN_ONLY") == "cscan":  # add the complex-A scan fixtures without touching the others
+        cci, ssi = load_reference()
+        gen_cscan_all(ssi)
+        return
     if os.environ.get("GOLDEN_ONLY") == "stack":  # add the Block-stack fixtures without touching the others
         cci, ssi = load_reference()
         mods = load_reference_modules(ssi)
@@ -375,6 +426,8 @@ def main():
     gen_scan(ssi, "scan_constC", 2, 4, 8, 200, var_C=False)
     gen_scan(ssi, "scan_bf16_L300", 2, 4, 16, 300, itype=torch.bfloat16)
     gen_scan(ssi, "scan_f16_L130", 2, 4, 8, 130, itype=torch.float16)
+    print("scan, complex A:")
+    gen_cscan_all(ssi)
     print("conv:")
     for L in (8, 151, 372):
         for W in (2, 3, 4):
