@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 7
+#define VMS_ABI_VERSION 8
 
 typedef enum {
     VMS_OK = 0,
@@ -74,7 +74,7 @@ typedef enum {
 
 /* ---- selective scan ------------------------------------------------------------------
  * u, delta, z, out, out_z : (batch, dim, seqlen), unit seqlen stride, free batch/dim strides
- * A                       : (dim, dstate) fp32 (real A only; complex -> VMS_ERR_UNSUPPORTED)
+ * A                       : (dim, dstate) fp32; with is_complex (ABI v8) complex64, see the field below
  * B, C variable           : (batch, n_groups, dstate, seqlen) in `dtype`, unit seqlen stride
  * B, C constant           : (dim, dstate) fp32
  * D, delta_bias           : (dim) fp32 or NULL
@@ -149,7 +149,18 @@ typedef struct {
      * stacks the flipped half on the batch axis: here the second half of the batch is simply scanned the other way, no
      * copies).  Results per entry are exactly those of two calls on the two sub-batches.  0 = `reverse` decides. */
     int32_t reverse_from;
-    int32_t reserved1;
+    /* ABI v8: is_complex != 0 = the reference's weight_t = complex<float> instantiations (selective_scan.cpp:47, 282-287;
+     * semantics of selective_scan_ref's complex branch, SSI:111-116, 144-145: y = 2 Re(sum_n C x) + D u).  A, constant B / C
+     * (and dA, constant dB / dC) are complex64 = (re, im) float pairs, their strides counted in COMPLEX elements; variable
+     * B / C are the reference's real (batch, n_groups, dstate, 2*seqlen) tensors of interleaved pairs in `dtype` (strides
+     * in elements of `dtype`, dB / dC fp32 of the same shape); x is complex64 (batch, dim, n_chunks, 2*dstate) with the slots
+     * of the real case, x_chunk_stride in complex elements (0 = 2*dstate).  x_has_sub == 1: the pitch is >= 6*dstate and
+     * x[b,d,c, 2*dstate + s*dstate + n], s = 0..3, holds state n after the first 512*(s+1) elements of chunk c -- what the
+     * backward starts its 512-element chunks from (required by vms_selective_scan_bwd when seqlen > 512); other x_has_sub
+     * values, reverse_from and bc_pad do not apply.  Gradients of complex parameters follow PyTorch's convention
+     * (dL/dRe + i dL/dIm), as the reference's kernels return them.  Served by its own kernels (selective_scan_complex.hip,
+     * built like the generic real ones: no suite model has a complex A). */
+    int32_t is_complex;
 } vms_scan_fwd_params;
 
 /* backward.  dout is the gradient of the final output (out_z when z != NULL, else out).

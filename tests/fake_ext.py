@@ -15,6 +15,9 @@ def make_fakes(oracle):
         a = t.detach().float().cpu().numpy()
         return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
 
+    def npc(t):   # complex tensors keep their dtype (the oracle's complex entry points tell constant from variable B / C by it)
+        return t.detach().cpu().numpy() if t.is_complex() else np_(t)
+
     def un(a, rev):
         return np.ascontiguousarray(a[..., ::-1]) if (rev and a.ndim >= 3) else a
 
@@ -39,6 +42,14 @@ def make_fakes(oracle):
                     res.append(oz)
             return res
         rv = reverse
+        if A.is_complex():   # the complex kernels' stand-in (no right-to-left mode in this fake)
+            assert not rv and out_z_into is None
+            r = oracle.cscan_fwd(np_(u), np_(delta), npc(A), npc(B), npc(C), np_(D_), np_(z_), np_(delta_bias_), delta_softplus,
+                                 prec="f64")
+            res = [torch.empty_like(delta).copy_(torch.from_numpy(r["out"])), torch.from_numpy(r["x"])]
+            if z_ is not None:
+                res.append(torch.empty_like(z_).copy_(torch.from_numpy(r["out_z"])))
+            return res
         r = oracle.scan_fwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
                             np_(delta_bias_), delta_softplus, prec="f64")
         out = torch.empty_like(delta).copy_(torch.from_numpy(un(r["out"], rv)))
@@ -71,8 +82,13 @@ def make_fakes(oracle):
                 res.append(cat(len(lo) - 1))
             return res
         rv = reverse
-        r = oracle.scan_bwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
-                            np_(delta_bias_), np_(dout, rv), delta_softplus, prec="f64")
+        if A.is_complex():
+            assert not rv and not recompute_out_z
+            r = oracle.cscan_bwd(np_(u), np_(delta), npc(A), npc(B), npc(C), np_(D_), np_(z_), np_(delta_bias_), np_(dout),
+                                 delta_softplus, prec="f64")
+        else:
+            r = oracle.scan_bwd(np_(u, rv), np_(delta, rv), np_(A), np_(B, rv), np_(C, rv), np_(D_), np_(z_, rv),
+                                np_(delta_bias_), np_(dout, rv), delta_softplus, prec="f64")
         r = {k: (un(v, rv) if v is not None else None) for k, v in r.items()}
         tt = lambda a, like: torch.from_numpy(a).to(like.dtype)
         res = [tt(r["du"], u), torch.empty_like(delta).copy_(tt(r["ddelta"], delta)), tt(r["dA"], A),

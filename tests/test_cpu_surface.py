@@ -12,6 +12,7 @@ import types
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import ROOT, load_golden
 
@@ -36,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(vms_hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert vms_hip.lib().vms_abi_version() == 7
+    assert vms_hip.lib().vms_abi_version() == 8
 
 
 def test_no_cpu_fallback():
@@ -281,19 +282,69 @@ def test_block_stack_host_logic(fake_extensions, name, fused_add_norm):
             assert err <= 3e-3 * max(1.0, rg.abs().max().item()), (prefix + k, err, rg.abs().max().item())
 
 
-def test_complex_A_is_served_by_the_reference_statement():
-    """SURVEY.md 8a a-excl: complex A has no HIP kernel; selective_scan_fn routes it to selective_scan_ref with a
-    warning (any device, differentiable), the raw extension raises."""
+def test_complex_A_has_no_cpu_fallback():
+    """Complex A runs on its own HIP kernels (csrc/selective_scan_complex.hip): like the real case, CPU tensors raise."""
     torch.manual_seed(0)
     b, d, n, L = 2, 4, 8, 24
-    u, delta = torch.randn(b, d, L, requires_grad=True), torch.rand(b, d, L)
+    u, delta = torch.randn(b, d, L), torch.rand(b, d, L)
     A = torch.complex(-torch.rand(d, n), torch.randn(d, n))
     B, C = torch.randn(b, n, 2 * L), torch.randn(b, n, 2 * L)   # interleaved (re, im) along L (SSI:100-104)
-    with pytest.warns(RuntimeWarning):
-        out = ssi.selective_scan_fn(u, delta, A, B, C, delta_softplus=True)
-    ref = ssi.selective_scan_ref(u, delta, A, B, C, delta_softplus=True)
-    assert torch.equal(out, ref) and out.dtype == u.dtype
-    out.sum().backward()
-    assert u.grad is not None and torch.isfinite(u.grad).all()
     with pytest.raises(RuntimeError):
-        selective_scan_cuda.fwd(u.detach(), delta, A, B, C, None, None, None, True)
+        ssi.selective_scan_fn(u, delta, A, B, C, delta_softplus=True)
+    with pytest.raises(RuntimeError):
+        selective_scan_cuda.fwd(u, delta, A, B.unsqueeze(1), C.unsqueeze(1), None, None, None, True)
+
+
+@pytest.mark.parametrize("var_B,var_C", [(True, True), (False, True), (True, False), (False, False)])
+def test_complex_A_host_logic(fake_extensions, var_B, var_C):
+    """selective_scan_fn / mamba_inner_fn with a complex A over the extension stand-ins (the oracle's complex scan):
+    values and every gradient against autograd through the PyTorch statement of the op."""
+    torch.manual_seed(1)
+    b, d, n, L = 2, 4, 4, 40
+    mk = lambda *s, **k: torch.randn(*s, **k).requires_grad_()
+    u, delta = mk(b, d, L), torch.rand(b, d, L).requires_grad_()
+    A = (-0.5 * torch.rand(d, n, dtype=torch.complex64)).requires_grad_()
+    B = mk(b, n, 2 * L) if var_B else mk(d, n, dtype=torch.complex64)
+    C = mk(b, 1, n, 2 * L) if var_C else mk(d, n, dtype=torch.complex64)
+    D, z, bias = mk(d), mk(b, d, L), torch.rand(d).requires_grad_()
+    ins = (u, delta, A, B, C, D, z, bias)
+    out, last = ssi.selective_scan_fn(u, delta, A, B, C, D, z, bias, delta_softplus=True, return_last_state=True)
+    g = torch.randn_like(out)
+    grads = torch.autograd.grad(out, ins, g)
+    ref, last_ref = ssi.selective_scan_ref(u, delta, A, B, C, D, z, bias, delta_softplus=True, return_last_state=True)
+    grads_ref = torch.autograd.grad(ref, ins, g)
+    assert last.dtype == torch.complex64 and (last - last_ref).abs().max().item() < 1e-4
+    assert (out - ref).abs().max().item() < 1e-4
+    for a, r_, name in zip(grads, grads_ref, "u delta A B C D z bias".split()):
+        assert a.dtype == r_.dtype and a.shape == r_.shape, name
+        assert (a - r_).abs().max().item() < 2e-4 * max(1.0, r_.abs().max().item()), name
+
+
+def test_complex_A_inner_fn_host_logic(fake_extensions):
+    """mamba_inner_fn with a complex A = the composition of the ops (the reference tests it: test_selective_scan.py:152-250)."""
+    torch.manual_seed(2)
+    b, d, n, R, L, W = 2, 8, 4, 3, 24, 3
+    xz = torch.randn(b, 2 * d, L, requires_grad=True)
+    conv_w, conv_b = torch.randn(d, 1, W, requires_grad=True), torch.randn(d, requires_grad=True)
+    x_proj_w = torch.randn(R + 4 * n, d, requires_grad=True)     # d_state = 2 n for a complex A (SSI:168)
+    dt_w = torch.randn(d, R, requires_grad=True)
+    out_w = torch.randn(5, d, requires_grad=True)
+    A = (-0.5 * torch.rand(d, n, dtype=torch.complex64)).requires_grad_()
+    D, bias = torch.randn(d, requires_grad=True), torch.rand(d, requires_grad=True)
+    ins = (xz, conv_w, conv_b, x_proj_w, dt_w, out_w, A, D, bias)
+    out = ssi.mamba_inner_fn(xz, conv_w, conv_b, x_proj_w, dt_w, out_w, None, A, None, None, D, bias)
+    g = torch.randn_like(out)
+    grads = torch.autograd.grad(out, ins, g)
+    # the same composition with the scan stated in PyTorch
+    x, zz = xz.chunk(2, dim=1)
+    x = ssi.causal_conv1d_fn(x, conv_w.squeeze(1), conv_b, "silu")
+    x_dbl = F.linear(x.transpose(1, 2).reshape(b * L, -1), x_proj_w)
+    dl = (dt_w @ x_dbl[:, :R].t()).view(d, b, L).permute(1, 0, 2)
+    Bm = x_dbl[:, R:R + 2 * n].view(b, L, n, 2).permute(0, 2, 1, 3).reshape(b, n, 2 * L)
+    Cm = x_dbl[:, -2 * n:].view(b, L, n, 2).permute(0, 2, 1, 3).reshape(b, n, 2 * L)
+    y = ssi.selective_scan_ref(x, dl, A, Bm, Cm, D, zz, bias, delta_softplus=True)
+    ref = F.linear(y.transpose(1, 2), out_w)
+    grads_ref = torch.autograd.grad(ref, ins, g)
+    assert (out - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
+    for a, r_ in zip(grads, grads_ref):
+        assert (a - r_).abs().max().item() < 1e-3 * max(1.0, r_.abs().max().item())

@@ -137,6 +137,155 @@ def test_scan_random_vs_oracle(oracle, shape, itype, has_z):
         check(got[k], want[k], tol * 5, k)
 
 
+# ---- complex A (csrc/selective_scan_complex.hip; selective_scan.cpp:282-287, SSI:111-116, 144-145) ----------------------
+def _cnp(t):
+    """tensor -> numpy; complex tensors keep their dtype (the oracle tells constant from variable B / C by it)"""
+    if t is None:
+        return None
+    t = t.detach().cpu()
+    return t.numpy() if t.is_complex() else t.float().numpy()
+
+
+def crel_err(a, ref):
+    a = _cnp(a) if torch.is_tensor(a) else np.asarray(a)
+    ref = _cnp(ref) if torch.is_tensor(ref) else np.asarray(ref)
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    return np.abs(a.astype(np.complex128) - ref.astype(np.complex128)).max() / max(np.abs(ref).max(), 1e-6)
+
+
+def run_cscan(g, itype, oracle, reverse=False):
+    """selective_scan_fn with a complex A on the GPU + the f64 oracle on the (rounded) values the kernel saw"""
+    import vms_hip
+    from mamba_ssm.ops.selective_scan_interface import selective_scan_fn
+    var_B, var_C = not np.iscomplexobj(g["B"]), not np.iscomplexobj(g["C"])
+    u, delta = G(g["u"], itype, True), G(g["delta"], itype, True)
+    A = G(g["A"], torch.complex64, True)
+    B = G(g["B"], itype if var_B else torch.complex64, True)
+    C = G(g["C"], itype if var_C else torch.complex64, True)
+    D = G(g["D"], grad=True) if "D" in g else None
+    z = G(g["z"], itype, True) if "z" in g else None
+    bias = G(g["delta_bias"], grad=True) if "delta_bias" in g else None
+    sp = bool(g["softplus"])
+    out, last = selective_scan_fn(u, delta, A, B, C, D, z=z, delta_bias=bias, delta_softplus=sp, return_last_state=True)
+    assert vms_hip.last_kernel() == "scan_fwd_complex"
+    out.backward(G(g["g"], itype))   # on an autograd thread: its kernel name is asserted where bwd is called directly
+    got = dict(out=out, last_state=last, du=u.grad, ddelta=delta.grad, dA=A.grad, dB=B.grad, dC=C.grad,
+               dD=D.grad if D is not None else None, dz=z.grad if z is not None else None,
+               ddelta_bias=bias.grad if bias is not None else None)
+    o = oracle.cscan_fwd(_cnp(u), _cnp(delta), _cnp(A), _cnp(B), _cnp(C), _cnp(D), _cnp(z), _cnp(bias), sp, prec="f64")
+    ob = oracle.cscan_bwd(_cnp(u), _cnp(delta), _cnp(A), _cnp(B), _cnp(C), _cnp(D), _cnp(z), _cnp(bias), g["g"], sp, prec="f64")
+    want = dict(out=o["out_z"] if z is not None else o["out"], last_state=o["last_state"], **ob)
+    return got, want
+
+
+def ccheck(got, want, itype, vs, name, var_B=True, var_C=True, scale=1.0):
+    for k in KIND:
+        if want.get(k) is None:
+            continue
+        kind = KIND[k]
+        if (k == "dB" and not var_B) or (k == "dC" and not var_C):
+            kind = "batch_sum"   # constant B / C: sums over batch x L like dA
+        tol = TOL[itype] * FACTOR[kind][vs] * scale
+        e = crel_err(got[k], want[k])
+        assert e <= tol, f"{name}:{k} vs {vs}: rel err {e:.3e} > {tol:.1e}"
+
+
+@pytest.mark.parametrize("name", golden_names("cscan_"))
+def test_complex_scan_vs_oracle_and_golden(oracle, name):
+    """The reference's complex-A recipe (test_selective_scan.py:53-88 with wtype = complex64): the HIP kernels against the
+    f64 oracle and against the fixtures the reference's selective_scan_ref + autograd produced."""
+    g = load_golden(name)
+    itype = itype_of(g)
+    var_B, var_C = not np.iscomplexobj(g["B"]), not np.iscomplexobj(g["C"])
+    got, want = run_cscan(g, itype, oracle)
+    ccheck(got, want, itype, "oracle", name, var_B, var_C)
+    # 16-bit fixtures: the reference evaluated silu(z) in the input dtype (tests/test_oracle_golden.py): 2x
+    ccheck(got, {k: g.get(k) for k in KIND}, itype, "golden", name, var_B, var_C, scale=2.0 if itype != torch.float32 else 1.0)
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 8, 16, 64, 1), (1, 6, 16, 512, 1), (2, 12, 4, 513, 2), (1, 4, 8, 2048, 1),
+                                   (2, 4, 16, 3001, 1), (1, 5, 3, 5000, 1), (1, 3, 33, 777, 3), (1, 2, 256, 96, 1), (1, 1, 1, 1, 1)])
+@pytest.mark.parametrize("has_z", [True, False])
+def test_complex_scan_random_vs_oracle(oracle, shape, itype, has_z):
+    """every chunk (512) / checkpoint (1024, 2048) boundary case, odd lengths (element-wise I/O), groups, large dstate"""
+    batch, dim, N, L, groups = shape
+    torch.manual_seed(0)
+    g = dict(u=torch.randn(batch, dim, L), delta=0.5 * torch.rand(batch, dim, L),
+             A=torch.complex(-0.5 * torch.rand(dim, N), 3.0 * torch.randn(dim, N)),
+             B=torch.randn(batch, groups, N, 2 * L), C=torch.randn(batch, groups, N, 2 * L), D=torch.randn(dim),
+             delta_bias=0.5 * torch.rand(dim), g=torch.randn(batch, dim, L), softplus=1)
+    if has_z:
+        g["z"] = torch.randn(batch, dim, L)
+    g = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in g.items()}
+    got, want = run_cscan(g, itype, oracle)
+    ccheck(got, want, itype, "oracle", str(shape))
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [300, 1536, 2055])
+def test_complex_scan_reverse_and_accumulate(oracle, L, itype):
+    """the extension flags the complex kernels keep: reverse == the op on flipped copies; out_z += / dz +="""
+    import selective_scan_cuda
+    torch.manual_seed(3)
+    b, d, n = 2, 6, 8
+    u, delta = torch.randn(b, d, L, device=DEV, dtype=itype), (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
+    z, dout = torch.randn(b, d, L, device=DEV, dtype=itype), torch.randn(b, d, L, device=DEV, dtype=itype)
+    A = torch.complex(-0.5 * torch.rand(d, n, device=DEV), torch.randn(d, n, device=DEV))
+    B, C = torch.randn(b, 1, n, 2 * L, device=DEV, dtype=itype), torch.randn(b, 1, n, 2 * L, device=DEV, dtype=itype)
+    D, bias = torch.randn(d, device=DEV), torch.rand(d, device=DEV)
+
+    def flipc(t):   # flip the positions of interleaved (re, im) pairs
+        return t.view(*t.shape[:-1], L, 2).flip(-2).reshape(t.shape).contiguous()
+
+    fl = lambda t: t.flip(-1).contiguous()
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=True)
+    out_f, x_f, out_z_f = selective_scan_cuda.fwd(fl(u), fl(delta), A, flipc(B), flipc(C), D, fl(z), bias, True)
+    assert torch.equal(out, fl(out_f)) and torch.equal(out_z, fl(out_z_f)) and torch.equal(x, x_f)
+    r = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse=True)
+    import vms_hip
+    assert vms_hip.last_kernel() == "scan_bwd_complex"
+    rf = selective_scan_cuda.bwd(fl(u), fl(delta), A, flipc(B), flipc(C), D, fl(z), bias, fl(dout), x_f, out_f, None, True, False)
+    tol = TOL[itype]
+    for i, name in enumerate(("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz")):
+        want = rf[i] if name in ("dA", "dD", "ddelta_bias") else (flipc(rf[i]) if name in ("dB", "dC") else fl(rf[i]))
+        # identical arithmetic per row; the atomics' order differs for the sums
+        assert crel_err(r[i], want) <= (0 if name in ("du", "ddelta", "dz") else tol), name
+    # accumulate flags
+    base = torch.randn_like(out_z)
+    acc = base.clone()
+    selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, out_z_into=acc)
+    out2, _, oz2 = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
+    assert crel_err(acc, base.float() + oz2.float()) <= tol
+    dzb = torch.randn_like(z)
+    dz_acc = dzb.clone()
+    x2 = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)[1]
+    selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x2, out2, dz_acc, True, False, accumulate_dz=True)
+    r2 = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x2, out2, None, True, False)
+    assert crel_err(dz_acc, dzb.float() + r2[7].float()) <= tol
+
+
+def test_complex_scan_extension_checks():
+    """shape / dtype checks of the complex instantiations (selective_scan.cpp:240, 270, 276) and what this build declines"""
+    import selective_scan_cuda
+    u = torch.randn(1, 4, 16, device=DEV)
+    A = torch.randn(4, 8, device=DEV, dtype=torch.complex64)
+    B = torch.randn(1, 1, 8, 32, device=DEV)
+    out, x = selective_scan_cuda.fwd(u, u, A, B, B, None, None, None, False)
+    assert x.dtype == torch.complex64 and tuple(x.shape) == (1, 4, 1, 16) and out.shape == u.shape
+    with pytest.raises(RuntimeError):   # variable B of a complex A must be (.., 2 * seqlen)
+        selective_scan_cuda.fwd(u, u, A, B[..., :16].contiguous(), B, None, None, None, False)
+    with pytest.raises(RuntimeError):   # constant B in the weight type
+        selective_scan_cuda.fwd(u, u, A, torch.randn(4, 8, device=DEV), B, None, None, None, False)
+    with pytest.raises(RuntimeError):   # per-batch-entry directions are real-A only
+        selective_scan_cuda.fwd(u, u, A, B, B, None, None, None, False, reverse_from=1)
+    L = 1024
+    u2, B2 = torch.randn(1, 4, L, device=DEV), torch.randn(1, 1, 8, 2 * L, device=DEV)
+    with pytest.raises(RuntimeError):   # the backward needs the forward's checkpoints beyond one 512-element chunk
+        selective_scan_cuda.bwd(u2, u2, A, B2, B2, None, None, None, u2, None, None, None, False, False)
+
+
+
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 64, 128, 1), (1, 128, 136, 2), (2, 64, 1024, 1), (1, 64, 2056, 1),
                                    (1, 192, 4096, 1), (1, 70, 1160, 1)])
@@ -621,8 +770,6 @@ def test_scan_extension_error_behaviour():
     with pytest.raises(RuntimeError):  # dstate > 256 (:265)
         selective_scan_cuda.fwd(u, u, -torch.rand(4, 300, device=DEV), torch.randn(1, 1, 300, 16, device=DEV),
                                 torch.randn(1, 1, 300, 16, device=DEV), None, None, None, False)
-    with pytest.raises(RuntimeError):  # complex A is a declared non-goal: loud error, no fallback
-        selective_scan_cuda.fwd(u, u, torch.randn(4, 8, device=DEV, dtype=torch.complex64), B, B, None, None, None, False)
     with pytest.raises(RuntimeError):  # x required when n_chunks > 1 (:449)
         L = 4096
         u2 = torch.randn(1, 4, L, device=DEV)

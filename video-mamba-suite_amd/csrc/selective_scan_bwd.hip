@@ -29,6 +29,8 @@ int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q);
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
+int launch_scan_bwd_complex(const vms_scan_bwd_params& q, bool vec, hipStream_t stream);   // selective_scan_complex.hip
+
 constexpr int kBwdRows = 4;
 constexpr int kTilePad = 65;  // tile index = i * 65 + lane : conflict-free ds_add, 2-way flush
 
@@ -351,6 +353,7 @@ static void scan_bwd_sub_batches(const vms_scan_bwd_params& q, vms_scan_bwd_para
 }
 
 extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
+    if (q != nullptr && q->f.is_complex) return 0;
     if (q != nullptr && q->f.reverse_from > 0 && q->f.reverse_from < q->f.batch &&
         !(scan_impl_level(q->f) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(*q, true) && scan_bwd_pair_native_mixed(*q))) {
         vms_scan_bwd_params lo, hi;
@@ -368,6 +371,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     const vms_scan_fwd_params& p = q.f;
     if (int rc = validate_scan_common(p)) return rc;
     VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
+    VMS_CHECK(!p.is_complex || p.reverse_from == 0, "complex A: reverse_from is not available");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
         const bool native = scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q);
@@ -383,7 +387,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
             return vms_selective_scan_bwd(&hi, stream);
         }
     }
-    VMS_CHECK(p.x != nullptr || p.seqlen <= 1024, "x (scan checkpoints) is required when seqlen > 1024");
+    VMS_CHECK(p.is_complex || p.x != nullptr || p.seqlen <= 1024, "x (scan checkpoints) is required when seqlen > 1024");
     if (p.z) {
         VMS_CHECK(p.out != nullptr, "out is required when z is given");
         VMS_CHECK(q.dz != nullptr, "dz is required when z is given");
@@ -397,6 +401,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
     VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
+    if (p.is_complex) return launch_scan_bwd_complex(q, vec, s);
     const int level = scan_impl_level(p);
     if (level >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
 #ifdef VMS_EXPERIMENTAL

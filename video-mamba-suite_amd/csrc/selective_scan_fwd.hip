@@ -183,6 +183,7 @@ int validate_scan_common(const vms_scan_fwd_params& p) {
     VMS_CHECK(p.n_chunks == (p.seqlen + 2047) / 2048, "n_chunks must be ceil(seqlen / 2048)");
     VMS_CHECK(p.u && p.delta && p.A && p.B && p.C, "u, delta, A, B, C are required");
     VMS_CHECK(p.x_has_sub >= 0 && p.x_has_sub <= 3, "x_has_sub out of range");
+    if (p.is_complex) return VMS_OK;   // the complex layouts: validate_complex, selective_scan_complex.hip
     VMS_CHECK(p.x_has_sub != 1 || p.x_chunk_stride >= 18 * (int64_t)p.dstate, "x_has_sub == 1 needs an x pitch >= 18 * dstate");
     VMS_CHECK(p.x_has_sub != 3 || (p.x_chunk_stride >= 258 * (int64_t)p.dstate && p.x_chunk_stride % 2 == 0 &&
                                    (reinterpret_cast<uintptr_t>(p.x) & 7) == 0),
@@ -202,6 +203,8 @@ bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p);   // selective_sc
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p);
 int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
+
+int launch_scan_fwd_complex(const vms_scan_fwd_params& p, bool vec, hipStream_t stream);   // selective_scan_complex.hip
 
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
     const int es = p.dtype == VMS_F32 ? 4 : 2;
@@ -264,6 +267,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     VMS_CHECK(pp != nullptr, "null params");
     const vms_scan_fwd_params& p = *pp;
     if (int rc = validate_scan_common(p)) return rc;
+    VMS_CHECK(!p.is_complex || p.reverse_from == 0, "complex A: reverse_from is not available");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
         VMS_CHECK(p.x_has_sub != 2, "reverse_from is not available with the rows layout");
@@ -279,6 +283,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     VMS_CHECK(!p.out_z_accumulate || p.z != nullptr, "out_z_accumulate needs z / out_z");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
+    if (p.is_complex) return launch_scan_fwd_complex(p, vec, s);
     VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
     const int level = scan_impl_level(p);
 #ifdef VMS_EXPERIMENTAL
@@ -310,7 +315,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 }
 
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
-    if (p == nullptr) return 0;
+    if (p == nullptr || p->is_complex) return 0;
     if (p->reverse_from > 0 && p->reverse_from < p->batch) {
         if (scan_impl_level(*p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_native_mixed(*p)) return 0;
         vms_scan_fwd_params lo, hi;
@@ -330,6 +335,7 @@ extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
 extern "C" int64_t vms_scan_x_pitch(const vms_scan_fwd_params* pp, int32_t mode) {
     if (pp == nullptr || pp->dstate <= 0) return 0;
     const vms_scan_fwd_params& p = *pp;
+    if (p.is_complex) return (mode == 0 ? 2 : 6) * (int64_t)p.dstate;   // complex elements (vms_hip.h is_complex)
     if (mode == 0) return 2 * (int64_t)p.dstate;
     if ((mode == 3 || mode == -1) && vms::scan_bwd_pair_lane_ckpt_ok(p)) return 258 * (int64_t)p.dstate;
     return 18 * (int64_t)p.dstate;

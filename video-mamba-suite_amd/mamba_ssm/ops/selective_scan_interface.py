@@ -94,13 +94,8 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     last_state has shape (batch, dim, dstate). Note that the gradient of the last state is
     not considered in the backward pass.
     """
-    if A.is_complex():
-        # complex A (the reference's weight_t = complex<float> instantiations, selective_scan.cpp:282-287) has no HIP
-        # kernel here: no model of the suite uses it (SURVEY.md 8a a-excl).  The PyTorch statement of the op serves it,
-        # differentiable and on any device, with a warning; the raw extension (selective_scan_cuda.fwd) raises.
-        warnings.warn("selective_scan_fn: complex A runs on the pure-PyTorch selective_scan_ref path (no HIP kernel)",
-                      RuntimeWarning, stacklevel=2)
-        return selective_scan_ref(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    # complex A (the reference's weight_t = complex<float> instantiations, selective_scan.cpp:282-287): its own HIP kernels
+    # behind the same extension entry points (csrc/selective_scan_complex.hip)
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
 
 
@@ -290,8 +285,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
     conv_b = conv1d_bias.contiguous() if conv1d_bias is not None else None
     d_inner = conv_w.shape[0]
     z = xz[:, d_inner:]
-    if is_complex:
-        raise RuntimeError("selective_scan: complex A is not supported by the MI355X HIP path")
+    if is_complex:   # the public functions route a complex A to the composition of the ops (_complex_inner)
+        raise RuntimeError("the fused inner node is built for a real A")
     ctx.is_variable_B, ctx.is_variable_C = B is None, C is None
     ctx.has_B_proj_bias, ctx.has_C_proj_bias = B_proj_bias is not None, C_proj_bias is not None
     ext = _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias)
@@ -615,6 +610,12 @@ def mamba_inner_fn(
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
     C_proj_bias=None, delta_softplus=True
 ):
+    if A.is_complex():
+        # complex A (tested by the reference, tests/ops/test_selective_scan.py:152-250; no suite model has one): the node as
+        # the composition of the differentiable HIP ops -- conv1d, the projections, the complex scan -- instead of the
+        # one-call node built for the real case
+        return mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                               out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
     return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               out_proj_weight, out_proj_bias,
                               A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
@@ -642,6 +643,12 @@ def mamba_inner_fn_no_out_proj(
     two halves (shared weights) as ONE node on a batch of 2 B (mamba_new.py:192-213 stacks a flipped copy instead).
     checkpoint_lvl (extension; the reference hard-wires its default 1 here): 0 keeps conv_out and delta for the
     backward instead of rebuilding them."""
+    if A.is_complex():   # as mamba_inner_fn: the composition of the ops, without the output projection
+        if reverse or reverse_from:
+            raise RuntimeError("reverse / reverse_from are not available with a complex A")
+        x, z, delta, B, C = _inner_ref_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                                                   B_proj_bias, C_proj_bias)
+        return selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                        A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
                                        checkpoint_lvl, reverse, reverse_from)

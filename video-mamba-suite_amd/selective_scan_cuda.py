@@ -4,7 +4,9 @@ order, same returned tensor lists, same checks (raised as RuntimeError, as TORCH
 The work is done by the gfx950 kernels behind the C ABI in include/vms_hip.h.
 
 Differences that are visible only to someone poking at the raw extension:
-  * complex A (weight_t = complex<float>) is not built: RuntimeError (SURVEY.md 8a a-excl).
+  * complex A (weight_t = complex<float>, selective_scan.cpp:47, 282-287) runs on its own HIP kernels
+    (csrc/selective_scan_complex.hip, vms_hip.h is_complex) through the ctypes binding; the extensions of this
+    module (reverse, out_z_into, ...) beyond `reverse` are real-A only.
   * x[b, d, c, 2n] holds the state after the first 1024 elements of chunk c instead of the
     running product of exp(delta A); x[b, d, c, 2n+1] (what `last_state` slices) is unchanged.
   * 64-bit strides: no 2^32-element limit on batch_stride * batch.
@@ -27,9 +29,8 @@ def _check(cond, msg):
 def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     """selective_scan.cpp:233-305."""
     _check(u.dtype in _ITYPES, f"selective_scan: input dtype {u.dtype} not supported")
-    if A.is_complex():
-        raise RuntimeError("selective_scan: complex A is not supported by the MI355X HIP path")
-    _check(A.dtype == torch.float32, "selective_scan: A must be float32")
+    _check(A.dtype in (torch.float32, torch.complex64), f"selective_scan: weight dtype {A.dtype} not supported")
+    cl = 2 if A.is_complex() else 1   # variable B / C of a complex A: (.., 2 * seqlen) interleaved pairs (:270, 276)
     var_B, var_C = B.dim() >= 3, C.dim() >= 3
     _check(delta.dtype == u.dtype, "delta.scalar_type() == input_type")
     _check(B.dtype == (u.dtype if var_B else A.dtype), "B.scalar_type() == (!is_variable_B ? weight_type : input_type)")
@@ -48,15 +49,15 @@ def _common_checks(u, delta, A, B, C, D_, z_, delta_bias_):
     if not var_B:
         _check(tuple(B.shape) == (dim, dstate), "B must have shape (dim, dstate)")
     else:
-        _check(B.dim() == 4 and tuple(B.shape) == (batch, n_groups, dstate, seqlen),
-               "B must have shape (batch, n_groups, dstate, seqlen)")
+        _check(B.dim() == 4 and tuple(B.shape) == (batch, n_groups, dstate, seqlen * cl),
+               "B must have shape (batch, n_groups, dstate, seqlen)" + (" with seqlen * 2 for a complex A" if cl == 2 else ""))
         _check(B.stride(-1) == 1, "B.stride(-1) == 1")
     if not var_C:
         _check(tuple(C.shape) == (dim, dstate), "C must have shape (dim, dstate)")
     else:
-        _check(C.dim() == 4 and tuple(C.shape) == (batch, C.shape[1], dstate, seqlen) and
+        _check(C.dim() == 4 and tuple(C.shape) == (batch, C.shape[1], dstate, seqlen * cl) and
                C.shape[1] == (n_groups if var_B else C.shape[1]),
-               "C must have shape (batch, n_groups, dstate, seqlen)")
+               "C must have shape (batch, n_groups, dstate, seqlen)" + (" with seqlen * 2 for a complex A" if cl == 2 else ""))
         _check(C.stride(-1) == 1, "C.stride(-1) == 1")
     for name, t in (("D", D_), ("delta_bias", delta_bias_)):
         if t is not None:
@@ -98,6 +99,8 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
     reverse_from (extension, vms_hip.h ABI v5): batch entries >= reverse_from run right-to-left, the others left-to-right.
     for_backward (extension, ABI v7): False = x will not be handed to bwd (inference): the binding allocates the small
     checkpoint layout instead of the 8-element checkpoints the backward kernel prefers (vms_hip.h x_has_sub == 3)."""
+    if A.is_complex():
+        return _fwd_complex(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse, out_z_into, reverse_from)
     ext = _k.ext()
     impl = _k.scan_impl_from_env()
     if ext is not None and impl < _k.IMPL_ROWS:   # compiled binding: same checks / allocations / launch in C++
@@ -125,6 +128,25 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
+def _fwd_complex(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse, out_z_into, reverse_from):
+    """complex A (selective_scan.cpp:282-287): x is complex64 (batch, dim, n_chunks, 2 * dstate) as the reference allocates it
+    (:313), here the view of a (.., 6 * dstate) buffer whose tail holds the state after every 512 elements for bwd."""
+    _check(reverse_from == 0, "reverse_from is not available with a complex A")
+    batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    n_chunks = (seqlen + 2047) // 2048
+    out = torch.empty_like(delta)
+    out_z = torch.empty_like(z_) if z_ is not None else None
+    if out_z_into is not None:
+        _check(z_ is not None, "out_z_into needs z")
+        _check(out_z_into.dtype == u.dtype and out_z_into.is_cuda and out_z_into.stride(-1) == 1 and
+               tuple(out_z_into.shape) == (batch, dim, seqlen),
+               "out_z_into must be (batch, dim, seqlen), input dtype, unit last stride")
+        out_z = out_z_into
+    x = torch.empty(batch, dim, n_chunks, 6 * dstate, device=u.device, dtype=torch.complex64)[..., :2 * dstate]
+    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, out_z_into is not None, 0, 0)
+    return [out, x] + ([out_z] if z_ is not None else [])
+
+
 def bwd_accumulator_elems(A, B, C, D_, delta_bias_):
     """fp32 elements of zeroed scratch bwd(..., zeroed=) carves its atomics targets from."""
     return A.numel() + B.numel() + C.numel() + (D_.numel() if D_ is not None else 0) + (
@@ -142,8 +164,11 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
     ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
     accumulate_dz: dz_ += instead of dz_ = (dz_ must be given)."""
-    ext = _k.ext()
+    ext = _k.ext() if not A.is_complex() else None   # complex A: the checks / allocations below, launch through ctypes
     impl = _k.scan_impl_from_env()
+    if A.is_complex():
+        _check(reverse_from == 0, "reverse_from is not available with a complex A")
+        bc_pad = 0
     if ext is not None and impl < _k.IMPL_ROWS:
         if bc_pad is None:
             Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
@@ -181,7 +206,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
                and x_.stride(0) == dim * x_.stride(1),
                "x must be the (batch, dim, n_chunks, 2*dstate) checkpoint tensor returned by fwd")
     else:
-        _check(seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024")
+        _check(seqlen <= (512 if A.is_complex() else 1024), "x (the forward's checkpoints) is required for this seqlen")
     du = torch.empty_like(u)
     ddelta = torch.empty_like(delta)
     if bc_pad is None:
@@ -202,8 +227,9 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
             ddelta_bias, o = _carve(zeroed, o, delta_bias_)
     else:
         dA = torch.zeros_like(A)
-        dB = torch.zeros_like(B, dtype=torch.float32)
-        dC = torch.zeros_like(C, dtype=torch.float32)
+        # variable B / C: fp32 accumulators cast on return (:461-462, 488); constant ones in the weight type
+        dB = torch.zeros_like(B, dtype=torch.float32 if B.dim() >= 3 else A.dtype)
+        dC = torch.zeros_like(C, dtype=torch.float32 if C.dim() >= 3 else A.dtype)
         dD = torch.zeros_like(D_) if D_ is not None else None
         ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     _k.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,

@@ -32,7 +32,7 @@ class ScanFwdParams(ctypes.Structure):
             "C_batch_stride", "C_group_stride", "C_d_stride", "C_dstate_stride", "x_chunk_stride")]
         + [("x_has_sub", _i32), ("reverse", _i32), ("out_z_accumulate", _i32), ("bc_pad", _i32),
            ("workspace", _vp), ("workspace_bytes", _i64), ("impl", _i32), ("segments", _i32),
-           ("reverse_from", _i32), ("reserved1", _i32)]
+           ("reverse_from", _i32), ("is_complex", _i32)]
     )
 
 
@@ -190,7 +190,7 @@ def ext():
             lib()
             try:
                 import _vms_torch
-                if _vms_torch.abi_version() == 7:
+                if _vms_torch.abi_version() == 8:
                     _ext = _vms_torch
             except ImportError as e:
                 # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
@@ -244,8 +244,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         L.vms_last_kernel.restype = ctypes.c_char_p
-        if L.vms_abi_version() != 7:
-            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 7: rebuild it")
+        if L.vms_abi_version() != 8:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 8: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
@@ -318,6 +318,8 @@ def x_layout_of(x, dstate):
     """vms_hip.h x_has_sub of a (batch, dim, n_chunks, 2 * dstate) view: what its pitch has room for."""
     if x.stride(3) != 1:
         return 0
+    if x.is_complex():   # vms_hip.h is_complex: the state after every 512 elements behind the reference-shaped slots
+        return 1 if x.stride(2) >= 6 * dstate else 0
     return 3 if x.stride(2) >= 258 * dstate else (1 if x.stride(2) >= 18 * dstate else 0)
 
 
@@ -332,6 +334,7 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
     P.is_variable_B, P.is_variable_C, P.delta_softplus = int(var_B), int(var_C), int(bool(delta_softplus))
     P.reverse = int(bool(reverse))
     P.reverse_from = int(reverse_from)
+    P.is_complex = int(A.is_complex())
     P.impl = scan_impl_from_env()
     P.u, P.delta, P.A, P.B, P.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
     P.D, P.z, P.delta_bias = _ptr(D), _ptr(z), _ptr(delta_bias)
