@@ -92,7 +92,7 @@ struct ScanDims { int64_t batch, dim, seqlen, dstate; bool var_B, var_C; };
 ScanDims scan_checks(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
                      const OptT& z_, const OptT& delta_bias_) {   // selective_scan.cpp:233-305
     TORCH_CHECK(is_itype(u), "selective_scan: input dtype ", u.scalar_type(), " not supported");
-    TORCH_CHECK(!A.is_complex(), "selective_scan: complex A is not supported by the MI355X HIP path");
+    TORCH_CHECK(!A.is_complex(), "selective_scan: complex A runs through the ctypes binding (selective_scan_cuda.py routes it there)");
     TORCH_CHECK(A.scalar_type() == at::kFloat, "selective_scan: A must be float32");
     const bool var_B = B.dim() >= 3, var_C = C.dim() >= 3;
     TORCH_CHECK(delta.scalar_type() == u.scalar_type(), "delta.scalar_type() == input_type");
