@@ -382,6 +382,32 @@ typedef struct {
 int vms_proj_conv_bwd(const vms_proj_conv_bwd_params *p, void *stream);
 
 /* ---- misc ---------------------------------------------------------------------------- */
+/* ---- per-step parameter preparation (ABI v8) -------------------------------------------------------------
+ * What a block does to its PARAMETERS at the top of every training step, as one launch instead of one small kernel per
+ * tensor: autocast's casts of the projection weights (selective_scan_interface.py:169-171 and F.linear's own), this build's
+ * K-contiguous copy of in_proj's weight (a cast + transpose), A = -exp(A_log.float()) (mamba_simple.py:230, 246).
+ * A job reads a (rows, cols) matrix with unit column stride and writes
+ *   VMS_PREP_CAST     dst (rows, cols) = src converted to dst_dtype
+ *   VMS_PREP_CAST_T   dst (cols, rows) = src^T converted to dst_dtype
+ *   VMS_PREP_NEG_EXP  dst (rows, cols) = -exp(src) (fp32 arithmetic)
+ * Row strides in elements; src and dst of different jobs may not overlap a job's dst. */
+enum { VMS_PREP_CAST = 0, VMS_PREP_CAST_T = 1, VMS_PREP_NEG_EXP = 2 };
+#define VMS_PREP_MAX_JOBS 8
+typedef struct {
+    const void *src;
+    void *dst;
+    int32_t rows, cols;
+    int64_t src_row_stride, dst_row_stride;
+    int32_t src_dtype, dst_dtype;   /* vms_dtype */
+    int32_t op, reserved;
+} vms_prep_job;
+typedef struct {
+    int32_t n_jobs, reserved;
+    vms_prep_job job[VMS_PREP_MAX_JOBS];
+} vms_prep_params;
+int vms_param_prep(const vms_prep_params *p, void *stream);
+int vms_sizeof_prep_params(void);
+
 int vms_abi_version(void);
 const char *vms_last_error(void);       /* thread-local, valid until the next failing call */
 /* thread-local: the kernel family the last successful launch call of this thread enqueued, e.g. "scan_fwd_pair",

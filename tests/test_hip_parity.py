@@ -1935,3 +1935,67 @@ def test_block_step_is_hip_graph_capturable(seqlen):
     torch.cuda.synchronize()
     for i, (a, b_) in enumerate(zip(outs, eager)):
         check(a, b_.float().cpu().numpy(), 2e-2, f"graph output {i}")
+
+
+# =================================================================================================
+# per-step parameter preparation (vms_param_prep, csrc/param_prep.hip)
+# =================================================================================================
+@pytest.mark.parametrize("dst_dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_param_prep_jobs_vs_torch(dst_dtype):
+    """cast / cast + transpose / -exp of up to 8 matrices in one launch: bit-exact against torch's copies (round to nearest
+    even), exp within 2 ulp; ragged tile edges, one-row jobs, strided rows."""
+    import vms_hip
+    torch.manual_seed(0)
+    mk = lambda *s: torch.randn(*s, device=DEV)
+    wide = mk(70, 200)
+    srcs = [mk(2048, 1024), mk(96, 1024), mk(1024, 64), mk(33, 65), mk(1, 130), wide[:, 3:190], mk(1024, 16), mk(5, 7)]
+    ops = [vms_hip.PREP_CAST_T, vms_hip.PREP_CAST, vms_hip.PREP_CAST, vms_hip.PREP_CAST_T, vms_hip.PREP_CAST,
+           vms_hip.PREP_CAST_T, vms_hip.PREP_NEG_EXP, vms_hip.PREP_NEG_EXP]
+    dsts = []
+    for s, op in zip(srcs, ops):
+        shape = tuple(s.shape[::-1]) if op == vms_hip.PREP_CAST_T else tuple(s.shape)
+        dsts.append(torch.full(shape, float("nan"), device=DEV, dtype=torch.float32 if op == vms_hip.PREP_NEG_EXP else dst_dtype))
+    vms_hip.param_prep(list(zip(srcs, dsts, ops)))
+    assert vms_hip.last_kernel() == "param_prep"
+    for s, d, op in zip(srcs, dsts, ops):
+        if op == vms_hip.PREP_NEG_EXP:
+            want = -torch.exp(s)
+            assert ((d - want).abs() <= 3e-7 * want.abs()).all()
+        else:
+            want = (s.t() if op == vms_hip.PREP_CAST_T else s).to(dst_dtype)
+            assert torch.equal(d, want)
+    with pytest.raises(RuntimeError):   # shapes must match the op
+        vms_hip.param_prep([(srcs[0], dsts[1], vms_hip.PREP_CAST)])
+
+
+@pytest.mark.parametrize("d_model,b,L,kw", [(64, 2, 257, {}), (192, 1, 512, {"if_devide_out": True}), (1024, 2, 1024, {})])
+def test_block_param_prep_equals_per_node_casts(monkeypatch, d_model, b, L, kw):
+    """The ViM block with its parameters prepared by one launch (default) against the same block with every node casting
+    its own (VMS_NO_PARAM_PREP=1): the casts are bit-identical, -exp differs by at most an ulp of A."""
+    import mamba_ssm.modules._core as core
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(d_model, expand=1, bimamba_type="v2", **kw).to(DEV)
+    h = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+
+    def step():
+        h.grad = None
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(h)
+            out.float().square().mean().backward()
+        return [out.detach().clone(), h.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    assert core._PARAM_PREP
+    got = step()
+    monkeypatch.setattr(core, "_PARAM_PREP", False)
+    want = step()
+    names = ["out", "dh"] + [n for n, _ in m.named_parameters()]
+    for n, a, w in zip(names, got, want):
+        assert a.dtype == w.dtype and a.shape == w.shape, n
+        check(a, w, 2e-3, f"param prep vs per-node casts: {n}")
+    # fp32 (no autocast): the preparation does not apply, the block runs as before
+    monkeypatch.setattr(core, "_PARAM_PREP", True)
+    h32 = h.detach().float().requires_grad_()
+    m(h32).square().mean().backward()
+    assert torch.isfinite(h32.grad).all()

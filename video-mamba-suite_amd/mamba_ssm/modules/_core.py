@@ -40,6 +40,9 @@ _CHECKPOINT_LVL = int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))
 # The DBM block as ONE node on a batch of 2 B whose second half is scanned right-to-left (vms_hip.h reverse_from), with
 # the stacking and un-stacking folded into the projections' weight layouts.  VMS_DBM_TWO_NODES=1: one node per direction.
 _DBM_STACKED = os.environ.get("VMS_DBM_TWO_NODES", "0") != "1"
+# The block's per-step parameter preparation (weight casts, in_proj's transposed copy, -exp(A_log)) as one launch
+# (vms_param_prep).  VMS_NO_PARAM_PREP=1: every node prepares its own, one small kernel per tensor.
+_PARAM_PREP = os.environ.get("VMS_NO_PARAM_PREP", "0") != "1"
 
 
 def _s4d_real_log(d_inner, d_state, device):
@@ -117,9 +120,38 @@ class MambaCore(nn.Module):
                          kernel_size=self.d_conv, groups=self.d_inner, padding=self.d_conv - 1, **factory_kwargs)
 
     # ---- pieces ---------------------------------------------------------------------------------
-    def _in_projection(self, hidden_states):
+    def _in_projection(self, hidden_states, wt_prepared=None):
         """(B, L, d_model) -> xz (B, C, L): GEMM and BLH->HBL transpose in one step."""
-        return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias)
+        return in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, wt_prepared=wt_prepared)
+
+    def _prepare_params(self, hidden_states):
+        """The per-step preparation of this block's parameters as ONE launch (vms_hip.h vms_param_prep): in_proj's weight as
+        a K-contiguous (d_model, channels) matrix in the compute dtype, the four small projection weights and out_proj's
+        weight in the compute dtype, A = -exp(A_log) of both directions -- six small kernels per step otherwise
+        (61 us of the 4.13 ms (8, 8192, 1024) step).  Under autocast on a GPU only; None = the nodes prepare their own."""
+        if not (_PARAM_PREP and hidden_states.is_cuda and torch.is_autocast_enabled()):
+            return None
+        dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+        ws = (self.in_proj.weight, self.x_proj.weight, self.dt_proj.weight, self.x_proj_b.weight, self.dt_proj_b.weight,
+              self.out_proj.weight)
+        if dt not in (torch.bfloat16, torch.float16) or any(w.dtype != torch.float32 or not w.is_contiguous() for w in ws) \
+                or self.A_log.dtype != torch.float32 or self.A_b_log.dtype != torch.float32:
+            return None
+        import vms_hip
+        dev = hidden_states.device
+        # one allocation for the low-precision copies, one for the two A
+        sizes = [w.numel() for w in ws]
+        flat = torch.empty(sum(sizes), dtype=dt, device=dev)
+        lows, o = [], 0
+        for w, n in zip(ws, sizes):
+            lows.append(flat[o:o + n].view(w.shape if w is not self.in_proj.weight else (w.shape[1], w.shape[0])))
+            o += n
+        A2 = torch.empty((2,) + tuple(self.A_log.shape), dtype=torch.float32, device=dev)
+        jobs = [(self.in_proj.weight.detach(), lows[0], vms_hip.PREP_CAST_T)]
+        jobs += [(w.detach(), l, vms_hip.PREP_CAST) for w, l in zip(ws[1:], lows[1:])]
+        jobs += [(self.A_log.detach(), A2[0], vms_hip.PREP_NEG_EXP), (self.A_b_log.detach(), A2[1], vms_hip.PREP_NEG_EXP)]
+        vms_hip.param_prep(jobs)
+        return dict(wt_in=lows[0], small=tuple(lows[1:5]), w_out=lows[5], A=A2[0], A_b=A2[1])
 
     def python_mamba_inner_fn_no_out_proj(self, xz, A, conv_state, ssm_state, seqlen, conv1d, x_proj, dt_proj, D,
                                           use_pytorch_conv=False):
@@ -163,14 +195,14 @@ class MambaCore(nn.Module):
         return (g("conv1d").weight, g("conv1d").bias, g("x_proj").weight, g("dt_proj").weight, A, g("D").float(),
                 g("dt_proj").bias.float())
 
-    def _merge_and_project(self, out, out_b):
+    def _merge_and_project(self, out, out_b, w_prepared=None):
         """out_b: the backward direction's output, already in the original sequence order (None: out is the sum)."""
         y = out if out_b is None else out + out_b  # (B, d_inner, L)
         if self.if_devide_out:
             if self.variant == "vim_norm":
                 return F.linear(self.norm(y.transpose(1, 2)), self.out_proj.weight, self.out_proj.bias)
             y = y / 2
-        return out_proj_fn(y, self.out_proj.weight, self.out_proj.bias)
+        return out_proj_fn(y, self.out_proj.weight, self.out_proj.bias, w_prepared=w_prepared)
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, hidden_states, inference_params=None):
@@ -184,18 +216,27 @@ class MambaCore(nn.Module):
                 return out
         if self.variant == "dbm":
             return self._forward_dbm(hidden_states, inference_params)
-        xz = self._in_projection(hidden_states)
         fast = self.use_fast_path and inference_params is None
-        if self.bimamba_type == "v2":
-            if fast and _USE_REVERSE_KERNELS:
-                # the reference flips xz, runs the same causal node and flips the result back
-                # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values without the
-                # four full-tensor copies (two here, two in autograd), and both directions form one autograd
-                # node, whose backward accumulates the two dxz in the kernels
+        if self.bimamba_type == "v2" and fast and _USE_REVERSE_KERNELS:
+            # the reference flips xz, runs the same causal node and flips the result back
+            # (mamba_simple.py:244, 258); the kernels' right-to-left mode gives the same values without the
+            # four full-tensor copies (two here, two in autograd), and both directions form one autograd
+            # node, whose backward accumulates the two dxz in the kernels
+            prep = self._prepare_params(hidden_states)
+            if prep is None:
+                xz = self._in_projection(hidden_states)
                 A, A_b = NegExpPairFn.apply(self.A_log, self.A_b_log)
                 return self._merge_and_project(
                     bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                                  checkpoint_lvl=_CHECKPOINT_LVL), None)
+            xz = self._in_projection(hidden_states, prep["wt_in"])
+            A, A_b = NegExpPairFn.apply(self.A_log, self.A_b_log, prep["A"], prep["A_b"])
+            return self._merge_and_project(
+                bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
+                                             checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"]), None,
+                w_prepared=None if self.if_devide_out and self.variant == "vim_norm" else prep["w_out"])
+        xz = self._in_projection(hidden_states)
+        if self.bimamba_type == "v2":
             if fast:
                 out = self._direction(xz, "")
                 out_b = self._direction(xz.flip([-1]), "_b").flip([-1])

@@ -55,7 +55,9 @@ class InProjFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd
-    def forward(ctx, hidden, weight, bias, stack_halves=False):
+    def forward(ctx, hidden, weight, bias, stack_halves=False, wt_prepared=None):
+        """wt_prepared: weight^T already in the compute dtype, (d_model, channels) -- made by the block's one-launch parameter
+        preparation (modules/_core.py, vms_param_prep); not differentiated (the gradient goes to `weight`)."""
         batch, seqlen, d_model = hidden.shape
         channels = weight.shape[0]
         x2 = hidden.reshape(batch * seqlen, d_model)
@@ -63,9 +65,15 @@ class InProjFn(torch.autograd.Function):
             assert channels % 2 == 0
         if hidden.is_cuda:
             dt = _autocast_dtype() or weight.dtype
-            # W^T as its own (d_model, channels) matrix in the compute dtype: cast and transpose in one copy kernel
-            wt = torch.empty(d_model, channels, dtype=dt, device=weight.device)
-            if stack_halves:   # column c * 2 + half of wt <- row half * (C / 2) + c of the weight
+            if wt_prepared is not None:
+                assert not stack_halves and wt_prepared.dtype == dt and tuple(wt_prepared.shape) == (d_model, channels)
+                wt = wt_prepared
+            else:
+                # W^T as its own (d_model, channels) matrix in the compute dtype: cast and transpose in one copy kernel
+                wt = torch.empty(d_model, channels, dtype=dt, device=weight.device)
+            if wt_prepared is not None:
+                pass
+            elif stack_halves:   # column c * 2 + half of wt <- row half * (C / 2) + c of the weight
                 wt.view(d_model, channels // 2, 2).copy_(weight.view(2, channels // 2, d_model).permute(2, 1, 0))
             else:
                 wt.copy_(weight.t())
@@ -115,7 +123,7 @@ class InProjFn(torch.autograd.Function):
                               .sum(0, dtype=ctx.w_dtype))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = unstack(g2.sum(dim=1))
-        return dhidden, dweight, dbias, None
+        return dhidden, dweight, dbias, None, None
 
 
 class OutProjFn(torch.autograd.Function):
@@ -128,13 +136,16 @@ class OutProjFn(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd
-    def forward(ctx, y, weight, bias, stacked_halves=False):
+    def forward(ctx, y, weight, bias, stacked_halves=False, w_prepared=None):
+        """w_prepared: weight already in the compute dtype (the block's one-launch parameter preparation); used by the forward
+        and the input-gradient GEMM instead of autocast's two casts of `weight`, not differentiated."""
         ctx.has_bias = bias is not None
         ctx.stacked_halves = stacked_halves
         ctx.w_dtype = weight.dtype
         if not stacked_halves:
-            ctx.save_for_backward(y, weight)
-            return F.linear(y.transpose(1, 2), weight, bias)
+            w = weight if w_prepared is None else w_prepared
+            ctx.save_for_backward(y, w)
+            return F.linear(y.transpose(1, 2), w, bias)
         b2, half_c, seqlen = y.shape
         batch, d_model = b2 // 2, weight.shape[0]
         dt = (_autocast_dtype() or weight.dtype) if y.is_cuda else weight.dtype
@@ -162,7 +173,7 @@ class OutProjFn(torch.autograd.Function):
                 dweight = torch.bmm(y, dout).sum(0, dtype=ctx.w_dtype).t()   # one K slice per batch entry, summed in the parameter's dtype
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 dbias = dout.sum(dim=(0, 1))
-            return dy, dweight, dbias, None
+            return dy, dweight, dbias, None, None
         y2, wp = ctx.saved_tensors
         batch, half_c, seqlen = ctx.dims
         d_model = wp.shape[0]
@@ -176,12 +187,12 @@ class OutProjFn(torch.autograd.Function):
             dweight = dwp.view(d_model, half_c, 2).transpose(1, 2).reshape(d_model, 2 * half_c)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dout.sum(dim=(0, 1))
-        return dy, dweight, dbias, None
+        return dy, dweight, dbias, None, None
 
 
-def in_proj_fn(hidden, weight, bias=None, stack_halves=False):
-    return InProjFn.apply(hidden, weight, bias, stack_halves)
+def in_proj_fn(hidden, weight, bias=None, stack_halves=False, wt_prepared=None):
+    return InProjFn.apply(hidden, weight, bias, stack_halves, wt_prepared)
 
 
-def out_proj_fn(y, weight, bias=None, stacked_halves=False):
-    return OutProjFn.apply(y, weight, bias, stacked_halves)
+def out_proj_fn(y, weight, bias=None, stacked_halves=False, w_prepared=None):
+    return OutProjFn.apply(y, weight, bias, stacked_halves, w_prepared)

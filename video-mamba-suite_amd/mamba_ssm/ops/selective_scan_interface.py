@@ -478,17 +478,22 @@ class NegExpPairFn(torch.autograd.Function):
     otherwise idle GPU queue: they sit between the big kernels of every step)."""
 
     @staticmethod
-    def forward(ctx, a_log, b_log):
-        outs = torch._foreach_exp([a_log.float(), b_log.float()])
-        torch._foreach_neg_(outs)
+    def forward(ctx, a_log, b_log, a_prepared=None, b_prepared=None):
+        """a_prepared, b_prepared: the two results, already computed by the block's one-launch parameter preparation
+        (vms_param_prep VMS_PREP_NEG_EXP); this node then only routes the gradient."""
+        if a_prepared is not None:
+            outs = [a_prepared, b_prepared]
+        else:
+            outs = torch._foreach_exp([a_log.float(), b_log.float()])
+            torch._foreach_neg_(outs)
         ctx.save_for_backward(*outs)
-        return tuple(outs)
+        return tuple(o.view_as(o) for o in outs) if a_prepared is not None else tuple(outs)
 
     @staticmethod
     def backward(ctx, ga, gb):
         a, b = ctx.saved_tensors
         da, db = torch._foreach_mul([ga, gb], [a, b])   # d(-exp(x)) = -exp(x) dx
-        return da, db
+        return da, db, None, None
 
 
 class _SubCtx:
@@ -509,10 +514,20 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
     @staticmethod
     @custom_fwd
     def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
+        """params: the 2 x 7 parameters, optionally followed by the four small projection weights (x_proj, dt_proj of both
+        directions) already in the autocast dtype -- the block's one-launch parameter preparation -- which are used instead of
+        casting here and receive no gradient."""
         n = BiMambaInnerFnNoOutProj.N_PER_DIR
-        assert len(params) == 2 * n
+        assert len(params) in (2 * n, 2 * n + 4)
+        low_given = params[2 * n:]
+        params = params[:2 * n]
+        ctx.n_extra = len(low_given)
         param_dtype = params[2].dtype
-        if torch.is_autocast_enabled():  # the four small projection weights of both directions: one cast kernel
+        if low_given:
+            params = list(params)
+            for i, t in zip([2, 3, n + 2, n + 3], low_given):
+                params[i] = t
+        elif torch.is_autocast_enabled():  # the four small projection weights of both directions: one cast kernel
             params = list(params)
             idx = [2, 3, n + 2, n + 3]
             dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
@@ -549,13 +564,14 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         first.saved_tensors = second.saved_tensors = None
         per_dir = lambda g: (g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"], g["dA"], g["dD"],
                              g["ddelta_bias"])
-        return (g1["dxz"], None, None) + per_dir(g1) + per_dir(g2)
+        return (g1["dxz"], None, None) + per_dir(g1) + per_dir(g2) + (None,) * ctx.n_extra
 
 
-def bimamba_inner_fn_no_out_proj(xz, params, params_b, delta_softplus=True, checkpoint_lvl=1):
+def bimamba_inner_fn_no_out_proj(xz, params, params_b, delta_softplus=True, checkpoint_lvl=1, prepared=None):
     """params / params_b: (conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias) of the
-    left-to-right and of the right-to-left direction -> out_z_fwd + out_z_bwd, (batch, dim, seqlen)."""
-    return BiMambaInnerFnNoOutProj.apply(xz, delta_softplus, checkpoint_lvl, *params, *params_b)
+    left-to-right and of the right-to-left direction -> out_z_fwd + out_z_bwd, (batch, dim, seqlen).
+    prepared: None, or (x_proj_weight, delta_proj_weight, x_proj_weight_b, delta_proj_weight_b) already in the autocast dtype."""
+    return BiMambaInnerFnNoOutProj.apply(xz, delta_softplus, checkpoint_lvl, *params, *params_b, *(prepared or ()))
 
 
 class MambaInnerFn(torch.autograd.Function):

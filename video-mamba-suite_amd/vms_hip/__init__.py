@@ -131,6 +131,19 @@ class ProjConvBwdParams(ctypes.Structure):
     )
 
 
+class PrepJob(ctypes.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("src_row_stride", _i64), ("dst_row_stride", _i64),
+                ("src_dtype", _i32), ("dst_dtype", _i32), ("op", _i32), ("reserved", _i32)]
+
+
+PREP_MAX_JOBS = 8
+PREP_CAST, PREP_CAST_T, PREP_NEG_EXP = 0, 1, 2
+
+
+class PrepParams(ctypes.Structure):
+    _fields_ = [("n_jobs", _i32), ("reserved", _i32), ("job", PrepJob * PREP_MAX_JOBS)]
+
+
 EXPORTS = (
     "vms_selective_scan_fwd", "vms_selective_scan_bwd", "vms_causal_conv1d_fwd", "vms_causal_conv1d_bwd",
     "vms_causal_conv1d_update", "vms_abi_version", "vms_last_error", "vms_sizeof_scan_fwd_params",
@@ -141,6 +154,7 @@ EXPORTS = (
     "vms_last_kernel", "vms_build_flags",
     "vms_proj_apply", "vms_proj_wgrad", "vms_sizeof_proj_apply_params", "vms_sizeof_proj_wgrad_params",
     "vms_proj_conv_bwd", "vms_sizeof_proj_conv_bwd_params",
+    "vms_param_prep", "vms_sizeof_prep_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -250,7 +264,7 @@ def lib():
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
                          ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams),
-                         ("proj_conv_bwd", ProjConvBwdParams)):
+                         ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -632,3 +646,20 @@ def state_update(state, x, dt, A, B, C, D, z, dt_bias, out, dt_softplus):
     P.B_batch_stride, P.B_n_stride = B.stride()
     P.C_batch_stride, P.C_n_stride = C.stride()
     _call("vms_selective_state_update", P, x)
+
+
+def param_prep(jobs):
+    """jobs: up to PREP_MAX_JOBS triples (src, dst, op) of 2-D tensors with unit column stride (1-D ones count as one row):
+    PREP_CAST dst = src in dst's dtype, PREP_CAST_T dst = src^T, PREP_NEG_EXP dst = -exp(src); one launch (vms_hip.h)."""
+    P = PrepParams()
+    assert 0 < len(jobs) <= PREP_MAX_JOBS
+    P.n_jobs = len(jobs)
+    for j, (src, dst, op) in zip(P.job, jobs):
+        s2 = src if src.dim() == 2 else src.reshape(1, -1)
+        d2 = dst if dst.dim() == 2 else dst.reshape(1, -1)
+        if s2.stride(1) != 1 or d2.stride(1) != 1 or tuple(d2.shape) != (tuple(s2.shape) if op != PREP_CAST_T else tuple(s2.shape[::-1])):
+            raise RuntimeError("param_prep: jobs are (rows, cols) matrices with unit column stride and matching shapes")
+        j.src, j.dst, j.rows, j.cols = _ptr(s2), _ptr(d2), s2.shape[0], s2.shape[1]
+        j.src_row_stride, j.dst_row_stride = s2.stride(0) if s2.shape[0] > 1 else s2.shape[1], d2.stride(0) if d2.shape[0] > 1 else d2.shape[1]
+        j.src_dtype, j.dst_dtype, j.op = dtype_code(s2), dtype_code(d2), op
+    _call("vms_param_prep", P, jobs[0][0])
