@@ -1,0 +1,95 @@
+// param_prep.hip -- the per-step preparation of a block's parameters as ONE launch (vms_hip.h vms_param_prep).
+//
+// Under autocast every step of the reference's block casts its projection weights to the compute dtype and evaluates
+// A = -exp(A_log) (mamba_simple.py:230, 246; selective_scan_interface.py:169-171: one small kernel each); this build also
+// keeps in_proj's weight as a K-contiguous (d_model, channels) copy (ops/projections.py).  In the step trace of the
+// (8, 8192, 1024) block those were six launches = 61 us between the large kernels (profiles/r03z2_step_trace.txt: a 16.7 us
+// strided transpose-copy, 20 us of multi-tensor casts, 12.6 us for the two A, 2 x 5.7 us for out_proj's weight).  Here: up to 8
+// jobs -- cast, cast + transpose, -exp -- as one grid; a workgroup owns one 64 x 64 tile of one job; transposes go through
+// a padded LDS tile so that both sides move whole 128 / 256-byte runs.
+#include "vms_common.h"
+
+namespace vms {
+
+namespace {
+
+constexpr int kTile = 64;
+
+template <typename T>
+__device__ __forceinline__ float ld_as_float(const void* p, int64_t i) { return static_cast<float>(static_cast<const T*>(p)[i]); }
+
+__device__ __forceinline__ float ld_f(const void* p, int64_t i, int dt) {
+    return dt == VMS_F32 ? ld_as_float<float>(p, i) : dt == VMS_F16 ? ld_as_float<f16_t>(p, i) : ld_as_float<bf16_t>(p, i);
+}
+__device__ __forceinline__ void st_f(void* p, int64_t i, int dt, float v) {
+    if (dt == VMS_F32) static_cast<float*>(p)[i] = v;
+    else if (dt == VMS_F16) static_cast<f16_t*>(p)[i] = static_cast<f16_t>(v);
+    else static_cast<bf16_t*>(p)[i] = static_cast<bf16_t>(v);
+}
+
+__global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p) {
+    __shared__ float tile[kTile][kTile + 1];
+    // which job, which tile of it (n_jobs <= 8: a scan over kernel arguments)
+    int j = 0, t = blockIdx.x;
+    for (; j < p.n_jobs; ++j) {
+        const int nt = ((p.job[j].rows + kTile - 1) / kTile) * ((p.job[j].cols + kTile - 1) / kTile);
+        if (t < nt) break;
+        t -= nt;
+    }
+    if (j >= p.n_jobs) return;
+    const vms_prep_job& q = p.job[j];
+    const int tc = (q.cols + kTile - 1) / kTile;
+    const int r0 = (t / tc) * kTile, c0 = (t % tc) * kTile;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row groups
+    if (q.op != VMS_PREP_CAST_T) {
+#pragma unroll 4
+        for (int k = 0; k < kTile / 4; ++k) {
+            const int r = r0 + ty + 4 * k, c = c0 + tx;
+            if (r < q.rows && c < q.cols) {
+                float v = ld_f(q.src, (int64_t)r * q.src_row_stride + c, q.src_dtype);
+                if (q.op == VMS_PREP_NEG_EXP) v = -expf(v);
+                st_f(q.dst, (int64_t)r * q.dst_row_stride + c, q.dst_dtype, v);
+            }
+        }
+        return;
+    }
+    // dst (cols, rows) <- src (rows, cols)
+#pragma unroll 4
+    for (int k = 0; k < kTile / 4; ++k) {
+        const int r = r0 + ty + 4 * k, c = c0 + tx;
+        tile[ty + 4 * k][tx] = (r < q.rows && c < q.cols) ? ld_f(q.src, (int64_t)r * q.src_row_stride + c, q.src_dtype) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < kTile / 4; ++k) {
+        const int c = c0 + ty + 4 * k, r = r0 + tx;   // dst row c, dst column r
+        if (r < q.rows && c < q.cols) st_f(q.dst, (int64_t)c * q.dst_row_stride + r, q.dst_dtype, tile[tx][ty + 4 * k]);
+    }
+}
+
+}  // namespace
+}  // namespace vms
+
+using namespace vms;
+
+extern "C" int vms_param_prep(const vms_prep_params* pp, void* stream) {
+    VMS_CHECK(pp != nullptr, "null params");
+    const vms_prep_params& p = *pp;
+    VMS_CHECK(p.n_jobs >= 0 && p.n_jobs <= VMS_PREP_MAX_JOBS, "n_jobs out of range");
+    int64_t tiles = 0;
+    for (int j = 0; j < p.n_jobs; ++j) {
+        const vms_prep_job& q = p.job[j];
+        VMS_CHECK(q.src && q.dst && q.rows > 0 && q.cols > 0, "job: src, dst and a non-empty shape are required");
+        VMS_CHECK(q.op >= VMS_PREP_CAST && q.op <= VMS_PREP_NEG_EXP, "job: unknown op");
+        VMS_CHECK(q.src_dtype >= VMS_F32 && q.src_dtype <= VMS_BF16 && q.dst_dtype >= VMS_F32 && q.dst_dtype <= VMS_BF16, "job: dtype");
+        VMS_CHECK(q.src_row_stride >= q.cols && q.dst_row_stride >= (q.op == VMS_PREP_CAST_T ? q.rows : q.cols), "job: row strides");
+        tiles += (int64_t)((q.rows + kTile - 1) / kTile) * ((q.cols + kTile - 1) / kTile);
+    }
+    if (tiles == 0) return VMS_OK;
+    VMS_CHECK(tiles < (1 << 30), "too many tiles");
+    set_last_kernel("param_prep");
+    hipLaunchKernelGGL(param_prep_kernel, dim3((unsigned)tiles), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+extern "C" int vms_sizeof_prep_params(void) { return (int)sizeof(vms_prep_params); }
