@@ -40,6 +40,44 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p
     const vms_prep_job& q = p.job[j];
     const int tc = (q.cols + kTile - 1) / kTile;
     const int r0 = (t / tc) * kTile, c0 = (t % tc) * kTile;
+    // whole tiles of an fp32 matrix going to a 16-bit one (every job of a ViM block but the two A): 16 consecutive values
+    // per thread, 16-byte accesses on both sides
+    if (q.op != VMS_PREP_NEG_EXP && q.src_dtype == VMS_F32 && q.dst_dtype != VMS_F32 && r0 + kTile <= q.rows && c0 + kTile <= q.cols &&
+        (q.src_row_stride & 3) == 0 && (q.dst_row_stride & 7) == 0 && ((uintptr_t)q.src & 15) == 0 && ((uintptr_t)q.dst & 15) == 0) {
+        const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
+        const float4* sp = reinterpret_cast<const float4*>(static_cast<const float*>(q.src) + (int64_t)(r0 + row) * q.src_row_stride + c0 + seg);
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 f = sp[k];
+            v[4 * k] = f.x; v[4 * k + 1] = f.y; v[4 * k + 2] = f.z; v[4 * k + 3] = f.w;
+        }
+        int64_t o = (int64_t)(r0 + row) * q.dst_row_stride + c0 + seg;
+        if (q.op == VMS_PREP_CAST_T) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tile[row][seg + k] = v[k];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v[k] = tile[seg + k][row];   // dst row c0 + row, dst columns r0 + seg ..
+            o = (int64_t)(c0 + row) * q.dst_row_stride + r0 + seg;
+        }
+        using V8 = __attribute__((ext_vector_type(8))) unsigned short;
+        V8 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (q.dst_dtype == VMS_BF16) {
+                lo[k] = __builtin_bit_cast(unsigned short, static_cast<bf16_t>(v[k]));
+                hi[k] = __builtin_bit_cast(unsigned short, static_cast<bf16_t>(v[8 + k]));
+            } else {
+                lo[k] = __builtin_bit_cast(unsigned short, static_cast<f16_t>(v[k]));
+                hi[k] = __builtin_bit_cast(unsigned short, static_cast<f16_t>(v[8 + k]));
+            }
+        }
+        V8* dp = reinterpret_cast<V8*>(static_cast<unsigned short*>(q.dst) + o);
+        dp[0] = lo;
+        dp[1] = hi;
+        return;
+    }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row groups
     if (q.op != VMS_PREP_CAST_T) {
 #pragma unroll 4
