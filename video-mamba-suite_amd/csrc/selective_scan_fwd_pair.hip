@@ -93,6 +93,28 @@ __device__ __forceinline__ f2 pk_fma_p(f2 a, f2 b, f2 c) {
 }
 #define VMS_ELP(arr, i) arr[(i) / 2][(i) % 2]
 
+// softplusf_ (vms_common.h) on a pair of elements: the same operations, the non-transcendental ones as packed fp32 (next to
+// transcendentals a scalar VALU op costs 3.8 cycles of the SIMD, a packed one 4.0 for two lane-ops: DESIGN.md 4.0)
+__device__ __forceinline__ f2 softplus2_p(f2 x) {
+    const f2 arg = x * f2{kLog2e, kLog2e};
+    const f2 t = f2{fast_exp2(arg.x), fast_exp2(arg.y)};
+    const f2 one = f2{1.f, 1.f};
+    const f2 w = one + t;
+    const f2 d = t - (w - one);
+    const f2 rw = f2{fast_rcp(w.x), fast_rcp(w.y)};
+    const f2 lg = f2{__builtin_amdgcn_logf(w.x), __builtin_amdgcn_logf(w.y)} * f2{0.6931471805599453f, 0.6931471805599453f};
+    f2 r = pk_fma_p(d, rw, lg);
+    r.x = x.x <= 20.f ? r.x : x.x;
+    r.y = x.y <= 20.f ? r.y : x.y;
+    return r;
+}
+// z * sigmoid(z) on a pair
+__device__ __forceinline__ f2 silu2_p(f2 z) {
+    const f2 arg = z * f2{-kLog2e, -kLog2e};
+    const f2 w = f2{1.f, 1.f} + f2{fast_exp2(arg.x), fast_exp2(arg.y)};
+    return z * f2{fast_rcp(w.x), fast_rcp(w.y)};
+}
+
 
 #ifndef VMS_PAIR_MINWAVES
 #define VMS_PAIR_MINWAVES 3
@@ -453,17 +475,21 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             RawP<T, REV> t0, t1;
             t0.load(u_b, o_u + pl0, ok);
             t1.load(dt_b, o_dt + pl0, ok);
+            // per element-PAIR (round 3): packed adds / multiplies around the transcendentals
+            const f2 bias2 = f2{bias, bias}, Dd2 = f2{Dd, Dd};
+            f2 sd2 = f2{0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                float t = t1.at(i) + bias;
-                if (p.delta_softplus) t = softplusf_(t);
-                t = ok ? t : 0.f;  // past the end: delta = 0 -> a = 1, b = 0 (identity)
-                const float uv = t0.at(i);
-                dl2[i / 2][i % 2] = t;
-                du2[i / 2][i % 2] = t * uv;
-                y2[i / 2][i % 2] = Dd * uv;
-                sdl += t;
+            for (int k = 0; k < K / 2; ++k) {
+                f2 t = f2{t1.at(2 * k), t1.at(2 * k + 1)} + bias2;
+                if (p.delta_softplus) t = softplus2_p(t);
+                t = ok ? t : f2{0.f, 0.f};  // past the end: delta = 0 -> a = 1, b = 0 (identity)
+                const f2 uv = f2{t0.at(2 * k), t0.at(2 * k + 1)};
+                dl2[k] = t;
+                du2[k] = t * uv;
+                y2[k] = Dd2 * uv;
+                sd2 = sd2 + t;
             }
+            sdl = sd2.x + sd2.y;
         }
         auto do_state = [&](const int n, const int buf) __attribute__((always_inline)) {
             const lds_f4p* bsrc = (const lds_f4p*)(smem + buf * kLGroupFloats + (n & 3) * (kWave * K)) + lane;
@@ -533,9 +559,10 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             RawP<T, REV> tz;
             tz.load(z_b, o_z + pl0, ok);
 #pragma unroll
-            for (int i = 0; i < K; ++i) {
-                const float zv = tz.at(i);
-                y[i] *= zv * sigmoidf_(zv);
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 g = y2[k] * silu2_p(f2{tz.at(2 * k), tz.at(2 * k + 1)});
+                y[2 * k] = g.x;
+                y[2 * k + 1] = g.y;
             }
             if (p.out_z_accumulate) {
                 RawP<T, REV> told;
