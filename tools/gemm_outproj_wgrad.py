@@ -1,4 +1,4 @@
-import torch, time
+import torch
 torch.manual_seed(0)
 B,C,L,D=8,1024,8192,1024
 y=torch.randn(B,C,L,device="cuda",dtype=torch.bfloat16)

@@ -15,7 +15,6 @@ SSI:218-219, 238-241) and its layout contract (delta and the scan output are "d-
 dx/dz are written straight into the halves of one dxz buffer, SSI:244-248, 281-283).
 """
 import os
-import warnings
 
 import torch
 import torch.nn.functional as F
