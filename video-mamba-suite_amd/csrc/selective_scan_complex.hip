@@ -13,7 +13,8 @@
 //     the same way from the right;
 //   * layouts (vms_hip.h, is_complex): A, constant B / C and their gradients are (re, im) float pairs with strides in
 //     complex elements; variable B / C are the reference's real (batch, groups, dstate, 2 seqlen) tensors of interleaved
-//     pairs (their gradients fp32 of the same shape, accumulated with one atomic per value as the reference does);
+//     pairs (their gradients fp32 of the same shape: the products of a backward workgroup's 8 rows are summed in LDS, then
+//     one atomic per value and workgroup);
 //     x is complex (batch, dim, n_chunks, 2 dstate) with the slots of the real kernels, optionally followed by the
 //     state after every 512 elements (x_has_sub == 1: the backward's chunk seeds).
 #include "vms_common.h"
@@ -24,7 +25,8 @@ namespace {
 
 constexpr int kCK = 8;               // elements per lane
 constexpr int kCCS = kWave * kCK;    // elements per wave chunk (512)
-constexpr int kCRows = 4;            // rows (waves) per workgroup
+constexpr int kCRows = 4;            // rows (waves) per forward workgroup
+constexpr int kCBRows = 8;           // rows (waves) per backward workgroup: their dB / dC products are summed in LDS first
 
 struct cf {
     float re, im;
@@ -229,21 +231,33 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_fwd_kernel(const vms_scan
 }
 
 template <typename T, bool VB, bool VC, bool HZ, bool VEC>
-__global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan_bwd_params q) {
+__global__ __launch_bounds__(kCBRows* kWave) void cscan_bwd_kernel(const vms_scan_bwd_params q) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ float smem[];
     constexpr int K = kCK, CS = kCCS;
+    constexpr int kSlab = 2 * kCBRows * K * kWave * 2;   // floats: [tensor][wave][element][lane] (re, im) pairs = 64 KB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int tiles = (p.dim + kCRows - 1) / kCRows;
+    const int tiles = (p.dim + kCBRows - 1) / kCBRows;
     const int b = blockIdx.x / tiles;
-    const int d = (blockIdx.x - b * tiles) * kCRows + wave;
-    if (d >= p.dim) return;
-    const int g = d / (p.dim / p.n_groups);
+    const int d0 = (blockIdx.x - b * tiles) * kCBRows;
+    const bool row_ok = d0 + wave < p.dim;      // rows past the end read nothing, contribute zeros and meet the barriers
+    const int d = row_ok ? d0 + wave : p.dim - 1;
+    const int dpg = p.dim / p.n_groups;
+    const int g = d / dpg;
+    // variable dB / dC are sums over the rows of a group: when the workgroup's rows share one (the usual case) their products are
+    // summed in LDS (plain stores, one slot per wave) and leave as ONE pair of atomics per position and workgroup -- one atomic per
+    // (row, state, value) as the reference issues them met 1024-way contention per address here: 189 ms at (8, 1024, 8192)
+    const int d_last = (d0 + kCBRows < p.dim ? d0 + kCBRows : p.dim) - 1;
+    const bool same_group = (d0 / dpg) == (d_last / dpg);
+    const int Lr = row_ok ? p.seqlen : 0;
     const int L = p.seqlen, N = p.dstate;
     const bool rev = p.reverse != 0;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) v2f lds_c2;
+    lds_c2* const slab = (lds_c2*)smem;
     // per wave: adjoint entering from the right, a of the first element of the chunk to the right, dA / constant dB / dC
-    volatile lds_f32* wv = (lds_f32*)smem + wave * (10 * N);
+    volatile lds_f32* wv = (lds_f32*)smem + kSlab + wave * (10 * N);
     volatile lds_f32 *gcarry = wv, *anext = wv + 2 * N, *dA_acc = wv + 4 * N, *dBc_acc = wv + 6 * N, *dCc_acc = wv + 8 * N;
     for (int n = lane; n < 2 * N; n += kWave) {
         gcarry[n] = 0.f;
@@ -277,11 +291,11 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
     const int n_kchunks = (L + CS - 1) / CS;
     for (int c = n_kchunks - 1; c >= 0; --c) {
         const int l0 = c * CS + lane * K;
-        const int nv = L - l0;
+        const int nv = Lr - l0;
         float uv[K], dl[K], dy[K], duv[K], ddl[K];
-        load_dir<T, K, VEC>(u, l0, L, rev, uv);
-        load_dir<T, K, VEC>(dt, l0, L, rev, dl);
-        load_dir<T, K, VEC>(dout, l0, L, rev, dy);
+        load_dir<T, K, VEC>(u, l0, Lr, rev, uv);
+        load_dir<T, K, VEC>(dt, l0, Lr, rev, dl);
+        load_dir<T, K, VEC>(dout, l0, Lr, rev, dy);
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             float t = dl[i] + bias;
@@ -290,8 +304,8 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
         }
         if (HZ) {
             float zv[K], ov[K], dzv[K];
-            load_dir<T, K, VEC>(z, l0, L, rev, zv);
-            load_dir<T, K, VEC>(outp, l0, L, rev, ov);
+            load_dir<T, K, VEC>(z, l0, Lr, rev, zv);
+            load_dir<T, K, VEC>(outp, l0, Lr, rev, ov);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float s = sigmoidf_(zv[i]);
@@ -302,12 +316,12 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
             }
             if (q.dz_accumulate) {
                 float old[K];
-                load_dir<T, K, VEC>(dz, l0, L, rev, old);
+                load_dir<T, K, VEC>(dz, l0, Lr, rev, old);
 #pragma unroll
                 for (int i = 0; i < K; ++i) dzv[i] += old[i];
             }
-            store_dir<T, K, VEC>(dz, l0, L, rev, dzv);
-            if (out_z) store_dir<T, K, VEC>(out_z, l0, L, rev, ov);
+            store_dir<T, K, VEC>(dz, l0, Lr, rev, dzv);
+            if (out_z) store_dir<T, K, VEC>(out_z, l0, Lr, rev, ov);
         }
 #pragma unroll
         for (int i = 0; i < K; ++i) {
@@ -320,8 +334,8 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
         for (int n = 0; n < N; ++n) {
             const cf An = ldc(A, n * p.A_dstate_stride);
             cf Bn[K], Cn[K];
-            if (VB) load_pairs<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride, l0, L, rev, Bn);
-            if (VC) load_pairs<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride, l0, L, rev, Cn);
+            if (VB) load_pairs<T, K, VEC>(Bv + (int64_t)n * p.B_dstate_stride, l0, Lr, rev, Bn);
+            if (VC) load_pairs<T, K, VEC>(Cv + (int64_t)n * p.C_dstate_stride, l0, Lr, rev, Cn);
             const cf bconst = VB ? cf{1.f, 0.f} : ldc(Bc, n * p.B_dstate_stride);
             const cf cconst = VC ? cf{1.f, 0.f} : ldc(Cc, n * p.C_dstate_stride);
             // ---- forward re-scan: x_i of the lane's elements ----
@@ -389,7 +403,9 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
                 const cf dCi = cf{2.f * dy[i] * xs[i].re, -2.f * dy[i] * xs[i].im};
                 const int64_t ph = rev ? L - 1 - (l0 + i) : l0 + i;
                 if (VB) {
-                    if (i < nv) {
+                    if (same_group) {
+                        slab[((0 * kCBRows + wave) * K + i) * kWave + lane] = i < nv ? v2f{dBi.re, dBi.im} : v2f{0.f, 0.f};
+                    } else if (i < nv) {
                         float* t = dBg + (int64_t)n * q.dB_dstate_stride + 2 * ph;
                         atomicAdd(t, dBi.re);
                         atomicAdd(t + 1, dBi.im);
@@ -399,7 +415,9 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
                     dBc_loc.im += dBi.im;
                 }
                 if (VC) {
-                    if (i < nv) {
+                    if (same_group) {
+                        slab[((1 * kCBRows + wave) * K + i) * kWave + lane] = i < nv ? v2f{dCi.re, dCi.im} : v2f{0.f, 0.f};
+                    } else if (i < nv) {
                         float* t = dCg + (int64_t)n * q.dC_dstate_stride + 2 * ph;
                         atomicAdd(t, dCi.re);
                         atomicAdd(t + 1, dCi.im);
@@ -430,11 +448,33 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
                     dCc_acc[2 * n + 1] += ti;
                 }
             }
+            if ((VB || VC) && same_group) {   // workgroup-uniform: every wave walks the same chunks and states
+                __syncthreads();
+                const int j = threadIdx.x;    // position j of the chunk = element j % K of lane j / K (blockDim == CS)
+                if (c * CS + j < L) {
+                    const int64_t ph = rev ? L - 1 - (c * CS + j) : c * CS + j;
+                    const int src = (j % K) * kWave + j / K;
+#pragma unroll
+                    for (int ten = 0; ten < 2; ++ten) {
+                        if (ten == 0 ? !VB : !VC) continue;
+                        v2f acc = v2f{0.f, 0.f};
+#pragma unroll
+                        for (int w = 0; w < kCBRows; ++w) {
+                            acc += slab[(ten * kCBRows + w) * K * kWave + src];
+                        }
+                        float* t = (ten == 0 ? q.dB + (int64_t)b * q.dB_batch_stride + (int64_t)(d0 / dpg) * q.dB_group_stride + (int64_t)n * q.dB_dstate_stride
+                                             : q.dC + (int64_t)b * q.dC_batch_stride + (int64_t)(d0 / dpg) * q.dC_group_stride + (int64_t)n * q.dC_dstate_stride) + 2 * ph;
+                        atomicAdd(t, acc.x);
+                        atomicAdd(t + 1, acc.y);
+                    }
+                }
+                __syncthreads();
+            }
         }
         // softplus chain (selective_scan_bwd_kernel.cuh:439-452) and stores
         {
             float raw[K];
-            load_dir<T, K, VEC>(dt, l0, L, rev, raw);
+            load_dir<T, K, VEC>(dt, l0, Lr, rev, raw);
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 if (p.delta_softplus) {
@@ -444,18 +484,18 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_bwd_kernel(const vms_scan
                 if (i < nv) dbias_acc += ddl[i];
             }
         }
-        store_dir<T, K, VEC>(du, l0, L, rev, duv);
-        store_dir<T, K, VEC>(ddelta, l0, L, rev, ddl);
+        store_dir<T, K, VEC>(du, l0, Lr, rev, duv);
+        store_dir<T, K, VEC>(ddelta, l0, Lr, rev, ddl);
     }
     if (q.dD) {
         const float t = wave_sum(dD_acc);
-        if (lane == 0) atomicAdd(q.dD + d, t);
+        if (lane == 0 && row_ok) atomicAdd(q.dD + d, t);
     }
     if (q.ddelta_bias) {
         const float t = wave_sum(dbias_acc);
-        if (lane == 0) atomicAdd(q.ddelta_bias + d, t);
+        if (lane == 0 && row_ok) atomicAdd(q.ddelta_bias + d, t);
     }
-    for (int n = lane; n < 2 * N; n += kWave) {
+    for (int n = lane; n < 2 * N && row_ok; n += kWave) {
         const int st = n >> 1, ri = n & 1;
         atomicAdd(q.dA + 2 * ((int64_t)d * q.dA_d_stride + (int64_t)st * q.dA_dstate_stride) + ri, dA_acc[n]);
         if (!VB) atomicAdd(q.dB + 2 * ((int64_t)d * q.dB_d_stride + (int64_t)st * q.dB_dstate_stride) + ri, dBc_acc[n]);
@@ -479,9 +519,17 @@ int launch_cfwd(const vms_scan_fwd_params& p, bool vec, hipStream_t stream) {
 template <typename T, bool VB, bool VC, bool HZ>
 int launch_cbwd(const vms_scan_bwd_params& q, bool vec, hipStream_t stream) {
     const vms_scan_fwd_params& p = q.f;
-    const int tiles = (p.dim + kCRows - 1) / kCRows;
-    dim3 grid(p.batch * tiles), block(kCRows * kWave);
-    const size_t smem = sizeof(float) * kCRows * 10 * p.dstate;
+    const int tiles = (p.dim + kCBRows - 1) / kCBRows;
+    dim3 grid(p.batch * tiles), block(kCBRows * kWave);
+    static_assert(kCBRows * kWave == kCCS, "the slab flush maps one thread to one position of a chunk");
+    const size_t smem = sizeof(float) * (2 * kCBRows * kCK * kWave * 2 + kCBRows * 10 * p.dstate);   // 64 KB slab + per-wave state arrays
+    // more than 64 KB of dynamic LDS needs the attribute on each device the kernel runs on (cheap; this is not a hot path)
+    const void* fn = vec ? reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, true>)
+                         : reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        return VMS_ERR_LAUNCH;
+    }
     if (vec)
         hipLaunchKernelGGL((cscan_bwd_kernel<T, VB, VC, HZ, true>), grid, block, smem, stream, q);
     else
