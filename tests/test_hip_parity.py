@@ -265,6 +265,31 @@ def test_complex_scan_reverse_and_accumulate(oracle, L, itype):
     assert crel_err(dz_acc, dzb.float() + r2[7].float()) <= tol
 
 
+@pytest.mark.parametrize("L", [1024, 2600, 4096 + 512])
+def test_complex_scan_checkpoint_slots(oracle, L):
+    """x of a complex scan: slot [c][2n + 1] = the state after 2048-chunk c (the reference's slot, last_state = x[:, :, -1, 1::2]),
+    slot [c][2n] = the state after the chunk's first 1024 elements, and behind the reference-shaped view the state after every
+    512 elements (what bwd starts from) -- all against the oracle run on truncated sequences."""
+    import selective_scan_cuda
+    torch.manual_seed(5)
+    b, d, n = 1, 3, 4
+    u, delta = torch.randn(b, d, L, device=DEV), 0.5 * torch.rand(b, d, L, device=DEV)
+    A = torch.complex(-0.5 * torch.rand(d, n, device=DEV), torch.randn(d, n, device=DEV))
+    B, C = torch.randn(b, 1, n, 2 * L, device=DEV), torch.randn(b, 1, n, 2 * L, device=DEV)
+    out, x = selective_scan_cuda.fwd(u, delta, A, B, C, None, None, None, True)
+    o = oracle.cscan_fwd(_cnp(u), _cnp(delta), _cnp(A), _cnp(B), _cnp(C), None, None, None, True, prec="f64")
+    assert crel_err(out, o["out"]) <= 1e-3
+    assert crel_err(x, o["x"]) <= 1e-3          # both reference-shaped slots of every chunk
+    # the 512-element checkpoints: x is the (.., 2n) view of a (.., 6n) buffer
+    full = torch.as_strided(x, (b, d, x.shape[2], 6 * n), x.stride())
+    for k in range((L + 511) // 512):
+        cut = min(L, 512 * (k + 1))
+        t = oracle.cscan_fwd(_cnp(u[..., :cut]), _cnp(delta[..., :cut]), _cnp(A), _cnp(B[..., :2 * cut]), _cnp(C[..., :2 * cut]),
+                             None, None, None, True, prec="f64")
+        got = full[:, :, k // 4, 2 * n + (k % 4) * n: 2 * n + (k % 4 + 1) * n]
+        assert crel_err(got, t["last_state"]) <= 1e-3, k
+
+
 def test_complex_scan_extension_checks():
     """shape / dtype checks of the complex instantiations (selective_scan.cpp:240, 270, 276) and what this build declines"""
     import selective_scan_cuda
