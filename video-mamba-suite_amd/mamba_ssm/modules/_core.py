@@ -139,12 +139,12 @@ class MambaCore(nn.Module):
             return None
         import vms_hip
         dev = hidden_states.device
-        # one allocation for the low-precision copies, one for the two A
-        sizes = [w.numel() for w in ws]
+        # one allocation for the low-precision copies (each starting on a 256-byte boundary: GEMM operands), one for the two A
+        sizes = [(w.numel() + 127) // 128 * 128 for w in ws]
         flat = torch.empty(sum(sizes), dtype=dt, device=dev)
         lows, o = [], 0
         for w, n in zip(ws, sizes):
-            lows.append(flat[o:o + n].view(w.shape if w is not self.in_proj.weight else (w.shape[1], w.shape[0])))
+            lows.append(flat[o:o + w.numel()].view(w.shape if w is not self.in_proj.weight else (w.shape[1], w.shape[0])))
             o += n
         A2 = torch.empty((2,) + tuple(self.A_log.shape), dtype=torch.float32, device=dev)
         jobs = [(self.in_proj.weight.detach(), lows[0], vms_hip.PREP_CAST_T)]
