@@ -246,6 +246,21 @@ typedef struct {
 } vms_conv_bwd_params;
 
 int vms_causal_conv1d_fwd(const vms_conv_fwd_params *p, void *stream);
+/* ABI v8 (an extension): both directions of a bidirectional block in ONE pass over x -- out = the causal filter (f.weight, f.bias),
+ * out_b = the anti-causal filter (weight_b, bias_b) of the same rows, i.e. what vms_causal_conv1d_fwd gives for f and for
+ * {f with reverse = 1, weight_b, bias_b, out_b} (same tap order: bit for bit for bf16 / fp32 I/O); the reference computes conv(x) and flip(conv_b(flip(x)))
+ * (mamba_simple.py:244-258).  Seqlen-contiguous layout; f.reverse, f.reverse_from, f.conv_state must be 0; weight_b / bias_b
+ * in f.wdtype with f.width taps. */
+typedef struct {
+    vms_conv_fwd_params f;
+    const void *weight_b, *bias_b;
+    void *out_b;
+    int64_t weight_b_c_stride, weight_b_width_stride;
+    int64_t out_b_batch_stride, out_b_c_stride;
+} vms_conv_fwd_dual_params;
+int vms_causal_conv1d_fwd_dual(const vms_conv_fwd_dual_params *p, void *stream);
+int vms_sizeof_conv_fwd_dual_params(void);
+
 int vms_causal_conv1d_bwd(const vms_conv_bwd_params *p, void *stream);
 int vms_causal_conv1d_update(const vms_conv_fwd_params *p, void *stream);
 

@@ -2024,3 +2024,40 @@ def test_block_param_prep_equals_per_node_casts(monkeypatch, d_model, b, L, kw):
     h32 = h.detach().float().requires_grad_()
     m(h32).square().mean().backward()
     assert torch.isfinite(h32.grad).all()
+
+
+# =================================================================================================
+# both conv directions in one pass (vms_causal_conv1d_fwd_dual)
+# =================================================================================================
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(2, 6, 8), (2, 5, 151), (1, 3, 1569), (2, 4, 6144), (1, 2, 8191), (1, 3, 8192), (1, 2, 65536)])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("bias,silu", [(True, True), (False, False)])
+def test_conv_fwd_dual_equals_two_calls(shape, width, itype, bias, silu):
+    """out == the causal call, out_b == the `reverse` call, bit for bit (same tap order); rows as channel halves of an xz
+    buffer, ragged / unaligned lengths, one strip and four strips per wave"""
+    import vms_hip
+    b, d, L = shape
+    torch.manual_seed(0)
+    xz = torch.randn(b, 2 * d, L, device=DEV).to(itype)
+    x = xz[:, :d]
+    w, wb = torch.randn(d, width, device=DEV), torch.randn(d, width, device=DEV)
+    cb, cbb = (torch.randn(d, device=DEV), torch.randn(d, device=DEV)) if bias else (None, None)
+    o1, o2 = torch.empty(b, d, L, device=DEV, dtype=itype), torch.empty(b, d, L, device=DEV, dtype=itype)
+    vms_hip.conv_fwd(x, w, cb, o1, silu)
+    vms_hip.conv_fwd(x, wb, cbb, o2, silu, reverse=True)
+    d1 = torch.full_like(o1, float("nan"))
+    d2full = torch.full((b, d + 1, L), float("nan"), device=DEV, dtype=itype)   # out_b as a strided view
+    d2 = d2full[:, :d]
+    vms_hip.conv_fwd_dual(x, w, cb, d1, wb, cbb, d2, silu)
+    assert vms_hip.last_kernel().startswith("conv_fwd_dual")
+    if itype == torch.float16 and not silu:
+        # hipcc may fold the last fma's rounding into the fp16 conversion (v_fma_mixlo_f16) in one kernel and not in the other:
+        # a handful of last-bit differences per 100 K elements
+        assert (d1.float() - o1.float()).abs().max() <= 2e-3 * o1.float().abs().max()
+        assert (d2.float() - o2.float()).abs().max() <= 2e-3 * o2.float().abs().max()
+        assert ((d1 != o1).sum() + (d2 != o2).sum()).item() <= 1e-3 * o1.numel()
+    else:
+        assert torch.equal(d1, o1) and torch.equal(d2, o2)
+    assert torch.isnan(d2full[:, d]).all()
+

@@ -189,6 +189,80 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
     }
 }
 
+// Both directions of a bidirectional block in one pass over x (vms_hip.h vms_causal_conv1d_fwd_dual): out = the causal filter
+// (weight, bias) and out_b = the ANTI-causal filter (weight_b, bias_b) of the same rows -- what the reference computes as
+// conv(x) and flip(conv_b(flip(x))) (mamba_simple.py:244-258).  x is read once (402 instead of 537 MB at (8, 1024, 8192)); both
+// outputs are in physical order.  The anti-causal taps run in the order of the right-to-left kernel (DIR = 2 above), so that
+// out_b is bit-identical to a `reverse` call: out_b[p] = bias_b + sum_k taps_b[k] x[p + 3 - k].
+template <typename T, bool SILU, bool VEC, int NV>
+__global__ __launch_bounds__(kConvThreads) void conv_fwd_dual_kernel(const vms_conv_fwd_dual_params q) {
+    const vms_conv_fwd_params& p = q.f;
+    constexpr int E = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int c = blockIdx.y, b = blockIdx.z;
+    const int L = p.seqlen;
+    const int base = (blockIdx.x * (kConvThreads / 64) + wave) * (64 * E * NV) + lane * E;
+    const RowIO<T, 1, !VEC> x(static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride + (int64_t)c * p.x_c_stride, L);
+    const RowIO<T, 1, !VEC> out(static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)c * p.out_c_stride, L);
+    const RowIO<T, 1, !VEC> out_b(static_cast<T*>(q.out_b) + (int64_t)b * q.out_b_batch_stride + (int64_t)c * q.out_b_c_stride, L);
+    float taps[kTaps], bias, taps_b[kTaps], bias_b;
+    load_taps(p, c, taps, bias);
+#pragma unroll
+    for (int k = 0; k < kTaps; ++k) {
+        const int w = k - (kTaps - p.width);
+        taps_b[k] = w >= 0 ? load_w(q.weight_b, (int64_t)c * q.weight_b_c_stride + (int64_t)w * q.weight_b_width_stride, p.wdtype) : 0.f;
+    }
+    bias_b = q.bias_b ? load_w(q.bias_b, c, p.wdtype) : 0.f;
+
+    float xv[NV][E + 6];  // xv[s][3 + i] = x[l0_s + i]; [0..2] = the 3 elements before, [E + 3 .. E + 5] = the 3 after
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        float cur[E];
+        x.load(base + s * 64 * E, cur);
+#pragma unroll
+        for (int i = 0; i < E; ++i) xv[s][3 + i] = cur[i];
+    }
+    const int lend = base + (NV - 1) * 64 * E + E;   // what follows this lane's last vector (used by lane 63: the wave's end)
+    float edge[3], edge_r[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        edge[j] = x.elem(base - 1 - j, lane == 0);
+        edge_r[j] = x.elem(lend + j, lane == 63);
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float own = xv[s][3 + E - 1 - j];
+            const float prev = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, own);
+            const float left = s == 0 ? edge[j] : lane_value(xv[s - 1][3 + E - 1 - j], 63);
+            xv[s][2 - j] = lane == 0 ? left : prev;
+            const float own_r = xv[s][3 + j];
+            const float next = dpp_mov<DPP_WAVE_SHL1, 0xf>(0.f, own_r);
+            const float right = s == NV - 1 ? edge_r[j] : lane_value(xv[s + 1 < NV ? s + 1 : s][3 + j], 0);
+            xv[s][E + 3 + j] = lane == 63 ? right : next;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        float o[E], ob[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            float acc = bias, acc_b = bias_b;
+#pragma unroll
+            for (int k = 0; k < kTaps; ++k) {
+                acc = fmaf(taps[k], xv[s][i + k], acc);
+                acc_b = fmaf(taps_b[k], xv[s][i + 6 - k], acc_b);
+            }
+            o[i] = SILU ? acc * sigmoidf_(acc) : acc;
+            ob[i] = SILU ? acc_b * sigmoidf_(acc_b) : acc_b;
+        }
+        out.store(base + s * 64 * E, o);
+        out_b.store(base + s * 64 * E, ob);
+    }
+}
+
 template <typename T, bool SILU, bool VEC, int NV, int DIR>
 __global__ __launch_bounds__(kConvThreads) void conv_bwd_kernel(const vms_conv_bwd_params q) {
     const vms_conv_fwd_params& p = q.f;
@@ -601,6 +675,57 @@ extern "C" int vms_causal_conv1d_fwd(const vms_conv_fwd_params* pp, void* stream
         default: return conv_fwd_dispatch<bf16_t>(*pp, s);
     }
 }
+
+template <typename T>
+static int conv_fwd_dual_dispatch(const vms_conv_fwd_dual_params& q, hipStream_t s) {
+    const vms_conv_fwd_params& p = q.f;
+    constexpr int E = 16 / sizeof(T);
+    const int es = sizeof(T);
+    const bool vec = aligned16(p.x) && aligned16(p.out) && aligned16(q.out_b) && mult16(p.x_batch_stride, es) && mult16(p.x_c_stride, es) &&
+                     mult16(p.out_batch_stride, es) && mult16(p.out_c_stride, es) && mult16(q.out_b_batch_stride, es) &&
+                     mult16(q.out_b_c_stride, es);
+    const bool even = vec && p.seqlen % E == 0;
+    const int nv = p.seqlen >= 12 * 64 * E ? 4 : 1;
+    const int per_wg = kConvThreads * E * nv;
+    dim3 grid((p.seqlen + per_wg - 1) / per_wg, p.dim, p.batch), block(kConvThreads);
+#define VMS_K(S_, V_, N_) hipLaunchKernelGGL((conv_fwd_dual_kernel<T, S_, V_, N_>), grid, block, 0, s, q)
+#define VMS_D(S_, N_) do { if (even) VMS_K(S_, true, N_); else VMS_K(S_, false, N_); } while (0)
+#define VMS_L(S_) do { if (nv == 4) VMS_D(S_, 4); else VMS_D(S_, 1); } while (0)
+    if (p.silu_activation) VMS_L(true); else VMS_L(false);
+#undef VMS_L
+#undef VMS_D
+#undef VMS_K
+    set_last_kernel(nv == 4 ? "conv_fwd_dual_strips4" : "conv_fwd_dual_strips1");
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+
+extern "C" int vms_causal_conv1d_fwd_dual(const vms_conv_fwd_dual_params* qq, void* stream) {
+    VMS_CHECK(qq != nullptr, "null params");
+    const vms_conv_fwd_params& p = qq->f;
+    if (int rc = validate_conv(p)) return rc;
+    VMS_CHECK(p.out && qq->out_b && qq->weight_b, "out, out_b and weight_b are required");
+    VMS_CHECK(p.reverse == 0 && p.reverse_from == 0 && !p.conv_state, "the dual forward takes no direction flags");
+    VMS_CHECK(p.x_l_stride == 1 && p.out_l_stride == 1, "x, out and out_b need a unit seqlen stride");
+    VMS_CHECK((p.bias == nullptr) == (qq->bias_b == nullptr), "bias_b must be given iff bias is given");
+    const int es = p.dtype == VMS_F32 ? 4 : 2;
+    if ((int64_t)p.seqlen * es >= ((int64_t)1 << 31)) {   // rows beyond 31-bit byte offsets: the two single-direction launches
+        vms_conv_fwd_params lo = p, hi = p;
+        hi.reverse = 1;
+        hi.weight = qq->weight_b; hi.bias = qq->bias_b; hi.out = qq->out_b;
+        hi.weight_c_stride = qq->weight_b_c_stride; hi.weight_width_stride = qq->weight_b_width_stride;
+        hi.out_batch_stride = qq->out_b_batch_stride; hi.out_c_stride = qq->out_b_c_stride;
+        if (int rc = vms_causal_conv1d_fwd(&lo, stream)) return rc;
+        return vms_causal_conv1d_fwd(&hi, stream);
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (p.dtype) {
+        case VMS_F32: return conv_fwd_dual_dispatch<float>(*qq, s);
+        case VMS_F16: return conv_fwd_dual_dispatch<f16_t>(*qq, s);
+        default: return conv_fwd_dual_dispatch<bf16_t>(*qq, s);
+    }
+}
+extern "C" int vms_sizeof_conv_fwd_dual_params(void) { return (int)sizeof(vms_conv_fwd_dual_params); }
 
 extern "C" int vms_causal_conv1d_bwd(const vms_conv_bwd_params* qq, void* stream) {
     VMS_CHECK(qq != nullptr, "null params");

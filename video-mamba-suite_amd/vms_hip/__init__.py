@@ -72,6 +72,11 @@ class ConvBwdParams(ctypes.Structure):
     )
 
 
+class ConvFwdDualParams(ctypes.Structure):
+    _fields_ = ([("f", ConvFwdParams)] + [(n, _vp) for n in ("weight_b", "bias_b", "out_b")]
+                + [(n, _i64) for n in ("weight_b_c_stride", "weight_b_width_stride", "out_b_batch_stride", "out_b_c_stride")])
+
+
 class NormParams(ctypes.Structure):
     _fields_ = (
         [(n, _i32) for n in ("rows", "cols", "x_dtype", "res_dtype", "is_rms")] + [("eps", ctypes.c_float)]
@@ -155,6 +160,7 @@ EXPORTS = (
     "vms_proj_apply", "vms_proj_wgrad", "vms_sizeof_proj_apply_params", "vms_sizeof_proj_wgrad_params",
     "vms_proj_conv_bwd", "vms_sizeof_proj_conv_bwd_params",
     "vms_param_prep", "vms_sizeof_prep_params",
+    "vms_causal_conv1d_fwd_dual", "vms_sizeof_conv_fwd_dual_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -264,7 +270,7 @@ def lib():
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
                          ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams),
-                         ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams)):
+                         ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams), ("conv_fwd_dual", ConvFwdDualParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -489,6 +495,20 @@ def conv_fwd(x, weight, bias, out, silu, reverse=False, reverse_from=0):
     P = ConvFwdParams()
     fill_conv_fwd(P, x, weight, bias, out, silu, reverse, reverse_from)
     _call("vms_causal_conv1d_fwd", P, x)
+
+
+def conv_fwd_dual(x, weight, bias, out, weight_b, bias_b, out_b, silu):
+    """out = the causal filter (weight, bias), out_b = the anti-causal one (weight_b, bias_b) of the same x, one pass (vms_hip.h)"""
+    Q = ConvFwdDualParams()
+    fill_conv_fwd(Q.f, x, weight, bias, out, silu)
+    if weight_b.dtype != weight.dtype or weight_b.shape != weight.shape or (bias is None) != (bias_b is None):
+        raise RuntimeError("conv_fwd_dual: the two filters need the same dtype, shape and bias presence")
+    Q.weight_b, Q.bias_b, Q.out_b = _ptr(weight_b), _ptr(bias_b), _ptr(out_b)
+    Q.weight_b_c_stride, Q.weight_b_width_stride = weight_b.stride()
+    if out_b.stride(2) != 1 or out_b.shape != x.shape:
+        raise RuntimeError("conv_fwd_dual: out_b must be (batch, dim, seqlen) with a unit seqlen stride")
+    Q.out_b_batch_stride, Q.out_b_c_stride = out_b.stride(0), out_b.stride(1)
+    _call("vms_causal_conv1d_fwd_dual", Q, x)
 
 
 def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False, dx_accumulate=False, reverse_from=0):
