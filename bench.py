@@ -73,6 +73,8 @@ def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, g
         "vms_selective_scan_bwd": (9 if bwd_out_z else 8) * bdl * s + bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4,
         "vms_causal_conv1d_fwd": 2 * bdl * s + dim * (w + 1) * 4,
         "vms_causal_conv1d_bwd": 3 * bdl * s + 2 * dim * (w + 1) * 4,
+        # both directions' conv1d of a bidirectional block in one pass: x read once, two outputs written
+        "vms_causal_conv1d_fwd_dual": 3 * bdl * s + 2 * dim * (w + 1) * 4,
         # the fused backward tail (SSI:278-283 in one pass): x and du read, dx written (+ dx read when it
         # accumulates the other direction's gradient: not counted), dx_dbl (R + 2N rows) read, the weights and fp32 accumulators
         "vms_proj_conv_bwd": 3 * bdl * s + batch * (-(-dim // 16) + 2 * n) * seqlen * s + (dim * (w + 1) + (-(-dim // 16) + 2 * n) * dim) * 4,

@@ -2061,3 +2061,31 @@ def test_conv_fwd_dual_equals_two_calls(shape, width, itype, bias, silu):
         assert torch.equal(d1, o1) and torch.equal(d2, o2)
     assert torch.isnan(d2full[:, d]).all()
 
+
+@pytest.mark.parametrize("d_model,b,L", [(64, 2, 257), (256, 1, 1569), (512, 2, 2048)])
+def test_block_dual_conv_equals_one_conv_per_direction(monkeypatch, d_model, b, L):
+    """The ViM block with both directions' conv1d from one pass over x (default) against one conv1d launch per direction
+    (VMS_NO_DUAL_CONV=1): the conv outputs are bit-identical, so the block output is; gradients differ by the order of the
+    kernels' atomics only."""
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(d_model, expand=1, bimamba_type="v2").to(DEV)
+    h = torch.randn(b, L, d_model, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+
+    def step():
+        h.grad = None
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(h)
+            out.float().square().mean().backward()
+        return [out.detach().clone(), h.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+
+    assert ssi._DUAL_CONV
+    got = step()
+    monkeypatch.setattr(ssi, "_DUAL_CONV", False)
+    want = step()
+    assert torch.equal(got[0], want[0])
+    for n, a, w in zip(["dh"] + [n for n, _ in m.named_parameters()], got[1:], want[1:]):
+        check(a, w, 2e-3, f"dual conv vs one conv per direction: {n}")
+

@@ -351,6 +351,24 @@ Tensor conv_fwd(const Tensor& x, const Tensor& weight, const OptT& bias_, bool s
     return out;
 }
 
+// both directions of a bidirectional block in one pass over x (vms_hip.h vms_causal_conv1d_fwd_dual): -> {conv(x; weight, bias),
+// the anti-causal conv(x; weight_b, bias_b)}, both (batch, dim, seqlen) in physical order
+std::vector<Tensor> conv_fwd_dual(const Tensor& x, const Tensor& weight, const OptT& bias_, const Tensor& weight_b, const OptT& bias_b_, bool silu) {
+    TORCH_CHECK(x.dim() == 3 && x.stride(2) == 1, "x must be (batch, dim, seqlen) with a unit seqlen stride");
+    conv_common(x, weight, bias_);
+    conv_common(x, weight_b, bias_b_);
+    TORCH_CHECK(weight.sizes() == weight_b.sizes() && weight.scalar_type() == weight_b.scalar_type() && bias_.has_value() == bias_b_.has_value(),
+                "the two filters need the same shape, dtype and bias presence");
+    Tensor out = at::empty(x.sizes(), x.options()), out_b = at::empty(x.sizes(), x.options());
+    vms_conv_fwd_dual_params Q{};
+    fill_conv(Q.f, x, weight, bias_, out, silu, false, 0);
+    Q.weight_b = weight_b.data_ptr(); Q.bias_b = cptr(bias_b_); Q.out_b = out_b.data_ptr();
+    Q.weight_b_c_stride = weight_b.stride(0); Q.weight_b_width_stride = weight_b.stride(1);
+    Q.out_b_batch_stride = out_b.stride(0); Q.out_b_c_stride = out_b.stride(1);
+    call("vms_causal_conv1d_fwd_dual", vms_causal_conv1d_fwd_dual, Q, x);
+    return {out, out_b};
+}
+
 std::vector<OptT> conv_bwd(const Tensor& x, const Tensor& weight, const OptT& bias_, Tensor dout, const OptT& dx_, bool silu,
                            bool reverse, const OptT& zeroed, bool accumulate_dx, int64_t reverse_from = 0) {   // causal_conv1d.cpp:191-268
     TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
@@ -521,14 +539,16 @@ void proj_conv_bwd(const Tensor& x, const Tensor& du, const Tensor& dx_dbl, cons
 // -> [out_z, conv_out, x_dbl, delta, ckpt, out]
 std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                               const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
-                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, int64_t proj_flags) {
+                              const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, int64_t proj_flags,
+                              const OptT& conv_out_given) {
     TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
     c10::DeviceGuard guard(xz.device());
     const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
     TORCH_CHECK(xz.size(1) == 2 * d && x_proj_w.size(0) == R + 2 * N && x_proj_w.size(1) == d && dt_proj_w.size(0) == d,
                 "inner_fwd: xz (b, 2d, l), x_proj (R + 2N, d), dt_proj (d, R), A (d, N) expected");
     const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
-    Tensor conv_out = conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
+    // conv_out_given: this direction's conv1d output, already computed (both directions of a block by one conv_fwd_dual)
+    Tensor conv_out = conv_out_given.has_value() ? *conv_out_given : conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
     Tensor x_dbl = at::matmul(x_proj_w, conv_out);                       // (b, R + 2N, l): rows R.. are B, the last N are C
     Tensor delta;                                                        // (b, d, l) = dt_proj_w @ x_dbl[:, :R]
     {
@@ -665,7 +685,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_bwd", &conv_bwd, py::arg("x"), py::arg("weight"), py::arg("bias"), py::arg("dout"), py::arg("dx"), py::arg("silu"),
           py::arg("reverse"), py::arg("zeroed"), py::arg("accumulate_dx"), py::arg("reverse_from") = 0);
     m.def("conv_update", &conv_update);
-    m.def("inner_fwd", &inner_fwd);
+    m.def("conv_fwd_dual", &conv_fwd_dual);
+    m.def("inner_fwd", &inner_fwd, py::arg("xz"), py::arg("conv_w"), py::arg("conv_b"), py::arg("x_proj_w"), py::arg("dt_proj_w"), py::arg("A"),
+          py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
+          py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none());
     m.def("inner_bwd", &inner_bwd);
     m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0, pybind11::arg("only") = "");
     m.def("timing_stop", &timing_stop);

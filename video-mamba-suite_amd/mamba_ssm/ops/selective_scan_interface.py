@@ -261,10 +261,12 @@ def _bc_from_x_dblT(x_dblT, lo, hi, bias):
 
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                   checkpoint_lvl, reverse=False, out_z_into=None, reverse_from=0):
+                   checkpoint_lvl, reverse=False, out_z_into=None, reverse_from=0, conv_out=None):
     """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A.
     reverse: the whole node runs right-to-left (== flip o node o flip, without the copies).
-    reverse_from > 0: the batch entries >= reverse_from run right-to-left, the others left-to-right (vms_hip.h ABI v5)."""
+    reverse_from > 0: the batch entries >= reverse_from run right-to-left, the others left-to-right (vms_hip.h ABI v5).
+    conv_out: this direction's conv1d + SiLU output when the caller already has it (both directions of a block from one pass
+    over x: vms_causal_conv1d_fwd_dual)."""
     assert checkpoint_lvl in (0, 1)
     batch, _, L = xz.shape
     R = delta_proj_weight.shape[1]
@@ -295,7 +297,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous() if D is not None else None
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
-            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx))
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx),
+            conv_out)
         ctx.reverse_from = int(reverse_from)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
         ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
@@ -308,7 +311,8 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         return out_z
     ctx.reverse_from = int(reverse_from)
     rf = {"reverse_from": int(reverse_from)} if reverse_from else {}
-    conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse, **rf)
+    if conv_out is None:
+        conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse, **rf)
     x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
 
     if B is None:
@@ -495,6 +499,29 @@ class NegExpPairFn(torch.autograd.Function):
         return da, db, None, None
 
 
+_DUAL_CONV = os.environ.get("VMS_NO_DUAL_CONV", "0") != "1"   # =1: one conv1d launch per direction (A/B, tests)
+
+
+def _dual_conv(xz, conv_w, conv_b, conv_w_b, conv_b_b):
+    """-> (conv_out forward direction, conv_out backward direction) or (None, None) when the one-pass kernel does not apply
+    (then each direction's node runs its own conv1d)."""
+    if not (_DUAL_CONV and xz.is_cuda and xz.stride(-1) == 1 and conv_w.dtype == conv_w_b.dtype and conv_w.shape == conv_w_b.shape
+            and (conv_b is None) == (conv_b_b is None)):
+        return None, None
+    d_inner = conv_w.shape[0]
+    x = xz[:, :d_inner]
+    w, wb = conv_w.squeeze(1), conv_w_b.squeeze(1)
+    cb = conv_b.contiguous() if conv_b is not None else None
+    cbb = conv_b_b.contiguous() if conv_b_b is not None else None
+    ext = _vms.ext()
+    if ext is not None:
+        o, ob = ext.conv_fwd_dual(x, w, cb, wb, cbb, True)
+        return o, ob
+    o, ob = torch.empty(x.shape, dtype=x.dtype, device=x.device), torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _vms.conv_fwd_dual(x, w, cb, o, wb, cbb, ob, True)
+    return o, ob
+
+
 class _SubCtx:
     """What _inner_forward / _inner_backward need from an autograd ctx, for nodes that run them more than once."""
 
@@ -536,6 +563,9 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
                 for i, t in zip(idx, low):
                     params[i] = t
         subs, out = [], None
+        # conv1d of both directions from ONE pass over x (vms_causal_conv1d_fwd_dual): the second direction's filter runs
+        # anti-causally over the same rows
+        conv_outs = _dual_conv(xz, params[0], params[1], params[n], params[n + 1])
         for i in range(2):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
             sub = _SubCtx()
@@ -543,7 +573,7 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
             sub.for_backward = any(ctx.needs_input_grad)
             # the second direction's scan adds its gated output to the first's
             out = _inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
-                                 delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out)
+                                 delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out, conv_out=conv_outs[i])
             subs.append(sub)
         ctx.counts = [len(sub.saved_tensors) for sub in subs]
         ctx.save_for_backward(*subs[0].saved_tensors, *subs[1].saved_tensors)
