@@ -540,7 +540,7 @@ void proj_conv_bwd(const Tensor& x, const Tensor& du, const Tensor& dx_dbl, cons
 std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                               const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
                               const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, int64_t proj_flags,
-                              const OptT& conv_out_given) {
+                              const OptT& conv_out_given, const OptT& x_dbl_given) {
     TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
     c10::DeviceGuard guard(xz.device());
     const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
@@ -549,7 +549,8 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
     // conv_out_given: this direction's conv1d output, already computed (both directions of a block by one conv_fwd_dual)
     Tensor conv_out = conv_out_given.has_value() ? *conv_out_given : conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
-    Tensor x_dbl = at::matmul(x_proj_w, conv_out);                       // (b, R + 2N, l): rows R.. are B, the last N are C
+    // x_dbl_given: x_proj_w @ conv_out, already computed (right behind the conv1d that wrote conv_out, while it is in the Infinity Cache)
+    Tensor x_dbl = x_dbl_given.has_value() ? *x_dbl_given : at::matmul(x_proj_w, conv_out);   // (b, R + 2N, l): rows R.. are B, the last N are C
     Tensor delta;                                                        // (b, d, l) = dt_proj_w @ x_dbl[:, :R]
     {
         const Tensor dt_in = x_dbl.narrow(1, 0, R);
@@ -688,7 +689,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_fwd_dual", &conv_fwd_dual);
     m.def("inner_fwd", &inner_fwd, py::arg("xz"), py::arg("conv_w"), py::arg("conv_b"), py::arg("x_proj_w"), py::arg("dt_proj_w"), py::arg("A"),
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
-          py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none());
+          py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());
     m.def("inner_bwd", &inner_bwd);
     m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0, pybind11::arg("only") = "");
     m.def("timing_stop", &timing_stop);
