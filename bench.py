@@ -369,7 +369,7 @@ def make_workload(config, device, dims=None):
 
 
 def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=None, autocast=True,
-        cpu_base=True, projections=True):
+        cpu_base=True, projections=True, graph=False):
     """The timed loop.  device=None: cuda:LOCAL_RANK; a CPU device (tests: gloo + checker-backed fake extensions)
     runs the same DDP / timing / reporting code on tiny sizes and skips the GPU-only instrumentation.
     Returns the result dict on rank 0, None elsewhere."""
@@ -414,6 +414,15 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             out = model(hidden)
         out.backward(gout)
 
+    # --graph (one GPU only): the same step recorded once as a HIP graph and replayed with one launch per step
+    # (mamba_ssm/utils/hip_graph.py) -- what the launch-bound shapes (configs[3]) need; kernels are then timed in eager steps
+    use_graph = bool(graph) and on_gpu and not distributed
+    if use_graph:
+        from mamba_ssm.utils.hip_graph import GraphedStep
+        gs = GraphedStep(block, hidden, autocast_dtype=torch.bfloat16 if autocast else None)
+        gs.gout.copy_(gout)
+        eager_step, step = step, gs.replay
+
     # the GPU's clocks need ~20 steps (0.1 s) to settle: with fewer the first timed steps run 1-2 % slow.  The extra
     # untimed steps below are reported as config.clock_ramp_steps; the timed region is exactly --steps steps.
     ramp = max(0, 20 - warmup) if on_gpu else 0
@@ -424,7 +433,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     # dominant kernel from that, and inside the timed region times only that one (the contract's live roofline measurement:
     # 2 launches per step).  The other configs are launch-bound on the host (configs[3]: ~50 launches in < 1 ms): their kernels
     # are timed in `kt_steps` extra steps AFTER the timed region (reported as config.kernel_timing).
-    inline_timing = on_gpu and config == "block"
+    inline_timing = on_gpu and config == "block" and not use_graph
     kt_pre = min(5, warmup + ramp) if inline_timing else 0
     for _ in range(warmup + ramp - kt_pre):
         step()
@@ -461,6 +470,8 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                 kernel_ms[dom_pre], kernel_steps[dom_pre] = live[dom_pre], steps
     if on_gpu and not inline_timing:
         kt_steps = min(steps, 10)
+        if use_graph:
+            step = eager_step   # event records cannot be replayed: the kernels are timed in eager steps
         vms_hip.start_timing(reserve=kt_steps * 16 * WORKLOADS[config][5])
         for _ in range(kt_steps):
             step()
@@ -512,6 +523,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                        "step": "fwd+bwd" + (" + DDP all-reduce" if distributed else ""),
                        "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
+                       "hip_graph": use_graph,   # --graph: the timed steps are replays of one captured graph (one GPU only)
                        "kernel_timing": (f"{dom_pre} inside the timed region (every launch of it), the other entry points in {kt_pre} of the "
                                          "untimed warm-up steps" if inline_timing else f"{kt_steps} extra steps after the timed region"),
                        "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")),
@@ -551,9 +563,10 @@ def main():
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-projections", action="store_true", help="skip the separate projection GEMM timing (profiling runs)")
+    ap.add_argument("--graph", action="store_true", help="one GPU only: replay the step as one HIP graph (launch-bound shapes)")
     args = ap.parse_args()
     res = run(args.config, args.steps, args.warmup, cpu_base=not args.no_cpu_baseline,
-              projections=not args.no_projections)
+              projections=not args.no_projections, graph=args.graph)
     if res is not None:
         print(json.dumps(res))
     if dist.is_initialized():
