@@ -2,9 +2,11 @@
 (B, L, D, d_state) = (8, 8192, 1024, 16) on N GPUs of one node, with the roofline of the dominant
 hot-path kernel and the CPU baseline (the reference's selective_scan_ref path on the host cores) beside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config block|stack|dbm|long]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config block|stack|dbm|long] [--graph]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W
+--gpus N must be the job's world size: under torch.distributed.run a mismatch is an error; `python bench.py --gpus N` with
+N > 1 and no launcher re-launches itself under torch.distributed.run (ensure_world below).
 
 A step = one pass of the hot path over one synthetic batch.  --config (default block = the judged line):
   block  configs[1]: the ViM ("v2") Mamba block exactly as the suite instantiates it (timemamba.py:115,
@@ -43,6 +45,11 @@ WORKLOADS = {
 }
 B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# DDP bucket cap (MB).  A bucket closes once it HOLDS >= the cap, in the order the gradients become ready: out_proj's weight
+# gradient (4 MB at d_model 1024) closes the first bucket by itself and its all-reduce runs under the inner node's backward; the
+# inner node's small parameters and in_proj's weight gradient (8 MB) follow in the last.  (32 MB, the earlier setting, put the
+# block's ~14 MB into ONE bucket: the all-reduce started after the last gradient -- VERDICT r3.)  VMS_DDP_BUCKET_MB overrides.
+DDP_BUCKET_MB = 4
 # HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
 # separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
 TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03z2_traffic.json")
@@ -285,6 +292,16 @@ def cpu_baseline(threads_restore=None):
     }
 
 
+def ddp_buckets(model, cap_mb):
+    """What the reducer really built (after its first-iteration rebuild in gradient-ready order): count and sizes."""
+    try:
+        d = model._get_ddp_logging_data()
+        sizes = [int(v) for v in str(d.get("rebuilt_bucket_sizes") or d.get("bucket_sizes") or "").replace(",", " ").split()]
+    except Exception:  # noqa: BLE001
+        sizes = []
+    return {"bucket_cap_mb": cap_mb, "n_buckets": len(sizes) or None, "bucket_bytes": sizes or None}
+
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md
 
 
@@ -376,7 +393,8 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # VMS_BENCH_DDP_WORLD1=1 (tests, one-GPU boxes): the DDP / RCCL path also at world size 1
+    distributed = world > 1 or os.environ.get("VMS_BENCH_DDP_WORLD1") == "1"
     on_gpu = device is None or torch.device(device).type == "cuda"
     if on_gpu:
         assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no CPU fallback)"
@@ -386,6 +404,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         dev = torch.device(device)
     if distributed and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if on_gpu:
             dist.init_process_group(backend=backend, device_id=dev)  # "nccl" = RCCL over xGMI
         else:
@@ -398,9 +419,13 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     torch.manual_seed(0 + rank)
     block, b, l, d_model = make_workload(config, dev, dims)
     model = block
-    if distributed:
+    # --graph under torch.distributed: the BARE module is captured and the gradients leave as one flat all-reduce per replay
+    # (mamba_ssm/utils/hip_graph.py); DDP's hooks are host callbacks and cannot be replayed
+    use_graph = bool(graph) and on_gpu
+    bucket_mb = float(os.environ.get("VMS_DDP_BUCKET_MB", DDP_BUCKET_MB))
+    if distributed and not use_graph:
         kw = dict(device_ids=[local_rank]) if on_gpu else {}
-        model = torch.nn.parallel.DistributedDataParallel(block, bucket_cap_mb=32, gradient_as_bucket_view=True, **kw)
+        model = torch.nn.parallel.DistributedDataParallel(block, bucket_cap_mb=bucket_mb, gradient_as_bucket_view=True, **kw)
     act_dtype = torch.bfloat16 if autocast else torch.float32
     # the block sits inside a network: its input gradient is part of the backward
     hidden = torch.randn(b, l, d_model, device=dev, dtype=act_dtype, requires_grad=True)
@@ -414,12 +439,13 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             out = model(hidden)
         out.backward(gout)
 
-    # --graph (one GPU only): the same step recorded once as a HIP graph and replayed with one launch per step
-    # (mamba_ssm/utils/hip_graph.py) -- what the launch-bound shapes (configs[3]) need; kernels are then timed in eager steps
-    use_graph = bool(graph) and on_gpu and not distributed
+    # --graph: the same step recorded once as a HIP graph and replayed with one launch per step (+ one flat all-reduce per
+    # replay when distributed) -- what the launch-bound shapes (configs[3]) need; kernels are then timed in eager steps
     if use_graph:
         from mamba_ssm.utils.hip_graph import GraphedStep
-        gs = GraphedStep(block, hidden, autocast_dtype=torch.bfloat16 if autocast else None)
+        gs = GraphedStep(block, hidden, autocast_dtype=torch.bfloat16 if autocast else None,
+                         process_group=dist.group.WORLD if distributed else None,
+                         allreduce=os.environ.get("VMS_GRAPH_ALLREDUCE", "after"))
         gs.gout.copy_(gout)
         eager_step, step = step, gs.replay
 
@@ -505,6 +531,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                 kern[name]["valu_floor_us"] = vf
                 kern[name]["valu_frac"] = vf / (avg * 1e3)
         comm = {"backend": backend if distributed else None, "world_size": dist.get_world_size() if distributed else 1}
+        if distributed:
+            comm.update(ddp_buckets(model, bucket_mb) if not use_graph else
+                        {"gradient_exchange": f"one flat all-reduce per replay ({gs.allreduce} the graph), "
+                                              f"{sum(t.numel() * t.element_size() for t in gs.flat.values())} bytes"})
         if on_gpu:
             try:
                 comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
@@ -517,13 +547,13 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if autocast else "f32", "data": "synthetic",
-            "config": {"workload": f"{what}: fwd+bwd, autocast bf16, B={b} per GPU, L={l}, d_model={d_model}, "
+            "config": {"workload": f"{what}: fwd+bwd, autocast {'bf16' if autocast else 'off'}, B={b} per GPU, L={l}, d_model={d_model}, "
                                    f"expand={WORKLOADS[config][4]} (d_inner={d_inner}), d_state={D_STATE}, d_conv={D_CONV}",
                        "name": config,
                        "step": "fwd+bwd" + (" + DDP all-reduce" if distributed else ""),
                        "global_batch": world * b, "seq_len": l, "parallelism": f"dp{world}",
                        "input_grad": True, "clock_ramp_steps": ramp,
-                       "hip_graph": use_graph,   # --graph: the timed steps are replays of one captured graph (one GPU only)
+                       "hip_graph": use_graph,   # --graph: the timed steps are replays of one captured graph
                        "kernel_timing": (f"{dom_pre} inside the timed region (every launch of it), the other entry points in {kt_pre} of the "
                                          "untimed warm-up steps" if inline_timing else f"{kt_steps} extra steps after the timed region"),
                        "checkpoint_lvl": int(os.environ.get("VMS_CHECKPOINT_LVL", "0")),
@@ -555,7 +585,37 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     return res
 
 
-def main():
+def ensure_world(gpus, argv):
+    """--gpus N is a contract, not a comment: the job must BE N ranks.
+    * WORLD_SIZE set (launched by torch.distributed.run / torchrun): it must equal N, else SystemExit.
+    * WORLD_SIZE unset and N > 1 (`python bench.py --gpus 8`): re-launch this very command line under
+      `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` and
+      return its exit code (the ranks print the one JSON line); VMS_BENCH_NO_SELF_LAUNCH=1 fails loudly instead.
+    * N == 1 without WORLD_SIZE: run here.  -> None when the caller should go on in this process."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus} "
+                             f"(or pass --gpus {ws})")
+        return None
+    if gpus <= 1:
+        return None
+    if os.environ.get("VMS_BENCH_NO_SELF_LAUNCH") == "1":
+        raise SystemExit(f"bench.py: --gpus {gpus} needs one process per GPU: python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {gpus} ...")
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"bench.py: --gpus {gpus} without WORLD_SIZE: re-launching as {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -563,15 +623,26 @@ def main():
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-projections", action="store_true", help="skip the separate projection GEMM timing (profiling runs)")
-    ap.add_argument("--graph", action="store_true", help="one GPU only: replay the step as one HIP graph (launch-bound shapes)")
-    args = ap.parse_args()
-    res = run(args.config, args.steps, args.warmup, cpu_base=not args.no_cpu_baseline,
-              projections=not args.no_projections, graph=args.graph)
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (launch-bound shapes); under "
+                    "torch.distributed the gradients leave as one flat all-reduce per replay")
+    # tests only (tests/test_ddp_gloo.py): the same command line on CPU / gloo with tiny sizes
+    ap.add_argument("--device", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
+    ap.add_argument("--dims", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    rc = ensure_world(args.gpus, sys.argv if argv is None else [sys.argv[0]] + list(argv))
+    if rc is not None:
+        return rc
+    dims = tuple(int(v) for v in args.dims.split(",")) if args.dims else None
+    res = run(args.config, args.steps, args.warmup, device=args.device, backend=args.backend, dims=dims,
+              autocast=args.device is None, cpu_base=not args.no_cpu_baseline and args.device is None,
+              projections=not args.no_projections and args.device is None, graph=args.graph)
     if res is not None:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

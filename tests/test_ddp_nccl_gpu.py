@@ -1,0 +1,38 @@
+"""The data-parallel path on RCCL with the one GPU a test box has (no -m gpu test initialised nccl).
+Reference sites: action-recognition/run_class_finetuning.py:570-582 (DistributedDataParallel), temporal-action-localization/
+train_eval.py:76 (nn.DataParallel around the DBM model)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.mark.gpu
+def test_ddp_and_graphed_ddp_on_rccl_world1(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    out = str(tmp_path / "nccl.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(HERE, "ddp_nccl_worker.py"), out, port], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.load(open(out))
+    assert res["backend"] == "nccl" and res["world"] == 1
+    for name in ("vim", "dbm"):
+        # fp32 atomics make the small parameter gradients order-dependent in the last bits; bf16 activations
+        assert res[name + "_ddp_vs_bare"] < 2e-2, res
+        for mode in ("after", "captured"):
+            assert res[f"{name}_graph_{mode}_vs_ddp"] < 2e-2, res
+            assert res[f"{name}_graph_{mode}_views"] and res[f"{name}_graph_{mode}_rebinds"], res
+    assert res["vim_n_params"] == 16
+    c = res["bench_ddp"]["comm"]
+    assert c["backend"] == "nccl" and c["world_size"] == 1 and c["n_buckets"] >= 1 and c["rccl_version"]
+    assert res["bench_ddp"]["step"].endswith("DDP all-reduce") and not res["bench_ddp"]["hip_graph"]
+    c = res["bench_graph"]["comm"]
+    assert res["bench_graph"]["hip_graph"] and c["backend"] == "nccl" and "one flat all-reduce per replay" in c["gradient_exchange"]

@@ -1300,7 +1300,10 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     }
     // whole-vector rows run on the second generation (scan_bwd_pair4_kernel, W waves per workgroup)
     constexpr bool four = true;   // whole-vector rows: second generation, 8 waves (32 rows) per workgroup
-    constexpr int WK = 8;
+#ifndef VMS_BWD_WK
+#define VMS_BWD_WK 8
+#endif
+    constexpr int WK = VMS_BWD_WK;
     const size_t smem4 = B4<WK>::kSmem;
     if (four && smem4 > 64 * 1024) {   // 4-state slab groups: 88 KB
         static PerDeviceOnce attr4_once;
