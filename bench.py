@@ -75,9 +75,14 @@ def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, g
     bdl = batch * dim * seqlen
     bc = 2 * batch * groups * n * seqlen
     x = batch * dim * n_c * 2 * n * 4
+    bwd_small = bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4
     return {
         "vms_selective_scan_fwd": 5 * bdl * s + bc * s + x + (dim * n + 2 * dim) * 4,
-        "vms_selective_scan_bwd": (9 if bwd_out_z else 8) * bdl * s + bc * s + x + bc * 4 + (2 * dim * n + 4 * dim) * 4,
+        "vms_selective_scan_bwd": (9 if bwd_out_z else 8) * bdl * s + bwd_small,
+        # both directions of a bidirectional block in one call (vms_hip.h ABI v9): per direction u, delta, dout, z read and du,
+        # ddelta written (6 B D L s each), both pre-gate outputs read and dz written ONCE (3 B D L s) -- 15 where two single
+        # calls owe 16 (17 with the second call's read of the first's dz); SURVEY 8d's figure also rewrites out_z per direction
+        "vms_selective_scan_bwd_dual": (17 if bwd_out_z else 15) * bdl * s + 2 * bwd_small,
         "vms_causal_conv1d_fwd": 2 * bdl * s + dim * (w + 1) * 4,
         "vms_causal_conv1d_bwd": 3 * bdl * s + 2 * dim * (w + 1) * 4,
         # both directions' conv1d of a bidirectional block in one pass: x read once, two outputs written
@@ -94,7 +99,8 @@ def algorithmic_bytes(batch=B, dim=D_MODEL * EXPAND, seqlen=L, n=D_STATE, s=2, g
 #   forward : 1 exp + 5 lane-ops (delta*A, delta*u*B, local recurrence, seeded recurrence, y += C x)     = 18.3 cycles
 #   backward: 1.25 exp + 15 lane-ops (a, b, c, x re-scan + x chain, g chain, g*a*x, S1, S2, dA, dB, dC ..) = 40.4 cycles
 # on 1,024 SIMDs at the 2.4 GHz peak clock.  valu_frac = valu_floor_us / measured: the binding resource's own fraction.
-VALU_CYCLES_PER_64 = {"vms_selective_scan_fwd": 8.3 + 5 * 2.0, "vms_selective_scan_bwd": 1.25 * 8.3 + 15 * 2.0}
+VALU_CYCLES_PER_64 = {"vms_selective_scan_fwd": 8.3 + 5 * 2.0, "vms_selective_scan_bwd": 1.25 * 8.3 + 15 * 2.0,
+                      "vms_selective_scan_bwd_dual": 2 * (1.25 * 8.3 + 15 * 2.0)}   # two directions per call
 N_SIMD, PEAK_CLOCK_HZ = 1024, 2.4e9
 
 
@@ -573,8 +579,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
             if dom.startswith("vms_selective_scan") and res["config"]["x_layout"] == 3:
                 # the design's own extra traffic (8-element checkpoints, fp32): in `traffic`, not in `achieved`
-                res["roofline"]["checkpoint_bytes_per_launch"] = b * d_inner * (l // 8) * D_STATE * 4
-            if dom == "vms_selective_scan_bwd":   # SURVEY 8d also counts an out_z rewrite (9 B D L s) the blocks' nodes never ask for
+                res["roofline"]["checkpoint_bytes_per_launch"] = b * d_inner * (l // 8) * D_STATE * 4 * (2 if dom.endswith("_dual") else 1)
+            if dom.endswith("_dual"):
+                res["roofline"]["launch"] = "one call = the backward scans of BOTH directions of the block (vms_selective_scan_bwd_dual)"
+            if dom in ("vms_selective_scan_bwd", "vms_selective_scan_bwd_dual"):   # SURVEY 8d also counts an out_z rewrite (9 B D L s per direction) the blocks' nodes never ask for
                 ab8 = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l, bwd_out_z=True)[dom]
                 res["roofline"]["algorithmic_bytes_survey_8d"] = ab8
                 res["roofline"]["frac_survey_8d"] = ab8 / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 8
+#define VMS_ABI_VERSION 9
 
 typedef enum {
     VMS_OK = 0,
@@ -190,6 +190,19 @@ typedef struct {
 
 int vms_selective_scan_fwd(const vms_scan_fwd_params *p, void *stream);
 int vms_selective_scan_bwd(const vms_scan_bwd_params *p, void *stream);
+/* ABI v9 (an extension): the backward scans of BOTH directions of a bidirectional block (mamba_simple.py:234-258: two
+ * parameter sets over the same rows, the reference launches selective_scan_bwd twice, SSI:541-561) in one call.
+ * Result = vms_selective_scan_bwd(a) followed by vms_selective_scan_bwd(b) with b's dz ADDED to a's: every gradient of a and
+ * of b in its own tensors, the gradient z receives through both directions in a->dz (b->dz: NULL or the same tensor;
+ * a->dz_accumulate as usual).  When the pair qualifies -- a left-to-right, b right-to-left, the same z and dout, equal
+ * sizes / dtype / checkpoint layout, whole-vector rows, together at least one workgroup per CU, no forced split -- it is
+ * ONE grid: a's workgroups write dz = dout (out_a + out_b) dsilu(z) (linear in the pre-gate outputs; rounded once, where
+ * the two-call form rounds the first direction's part to `dtype` before adding the second's), b's none; otherwise the two calls run
+ * back to back.  A direction of the suite's most common shape, (8, 768, 3136), is 192 workgroups for 256 CUs; both
+ * directions as one grid of 4-wave workgroups take 489 us instead of 2 x 317.  vms_scan_bwd_dual_fused() != 0: the pair
+ * qualifies (then the workspaces of a and b are not used). */
+int vms_selective_scan_bwd_dual(const vms_scan_bwd_params *a, const vms_scan_bwd_params *b, void *stream);
+int vms_scan_bwd_dual_fused(const vms_scan_bwd_params *a, const vms_scan_bwd_params *b);
 /* scratch the fast kernels want for this problem (0: none / not eligible); only sizes, dtype and
  * flags of *p are read */
 int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params *p);

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(vms_hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert vms_hip.lib().vms_abi_version() == 8
+    assert vms_hip.lib().vms_abi_version() == 9
 
 
 def test_no_cpu_fallback():
@@ -348,3 +348,16 @@ def test_complex_A_inner_fn_host_logic(fake_extensions):
     assert (out - ref).abs().max().item() < 1e-3 * max(1.0, ref.abs().max().item())
     for a, r_ in zip(grads, grads_ref):
         assert (a - r_).abs().max().item() < 1e-3 * max(1.0, r_.abs().max().item())
+
+
+def test_compiled_binding_speaks_the_packages_abi():
+    """A stale _vms_torch.so (older ABI) used to be dropped silently: every call then ran on ctypes (round 4 found it so)."""
+    header = open(os.path.join(ROOT, "include", "vms_hip.h")).read()
+    assert int(re.search(r"#define VMS_ABI_VERSION (\d+)", header).group(1)) == vms_hip.ABI_VERSION
+    so = os.path.join(ROOT, "video-mamba-suite_amd", "_vms_torch.so")
+    if not os.path.exists(so) or os.environ.get("VMS_NO_TORCH_EXT") == "1" or "VMS_HIP_LIB" in os.environ:
+        pytest.skip("compiled binding not built / disabled")
+    ext = vms_hip.ext()
+    assert ext is not None and ext.abi_version() == vms_hip.ABI_VERSION
+    for fn in ("scan_fwd", "scan_bwd", "scan_bwd_dual", "inner_fwd", "inner_bwd", "inner_bwd_dual", "conv_fwd_dual"):
+        assert hasattr(ext, fn), fn

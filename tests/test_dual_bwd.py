@@ -1,0 +1,137 @@
+"""vms_selective_scan_bwd_dual (ABI v9): the backward scans of both directions of a bidirectional block in one call -- one
+grid when the pair qualifies (4-wave or 8-wave workgroups), two launches otherwise -- against the two single-direction calls
+it replaces (mamba/mamba_ssm/ops/selective_scan_interface.py:541-561: the reference runs selective_scan_cuda.bwd twice) and
+against the f64 oracle; then the same through the block's one-node form."""
+import numpy as np
+import pytest
+import torch
+
+from test_hip_parity import DEV, TOL, check, rel_err, tol_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _dir_inputs(b, d, L, itype, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)
+    u = r(b, d, L).to(itype).to(DEV)
+    delta = (0.5 * torch.rand(b, d, L, generator=g)).to(itype).to(DEV)
+    A = (-0.5 * torch.rand(d, 16, generator=g) - 0.05).to(DEV)
+    B = r(b, 1, 16, L).to(itype).to(DEV)
+    C = r(b, 1, 16, L).to(itype).to(DEV)
+    D = r(d).to(DEV)
+    bias = (0.5 * torch.rand(d, generator=g)).to(DEV)
+    return u, delta, A, B, C, D, bias
+
+
+def _run_pair(b, d, L, itype, layout1, monkeypatch, seed=0):
+    """-> (dual results, two-call results, kernel name, inputs) on identical inputs"""
+    import selective_scan_cuda as ssc
+    import vms_hip
+    if layout1:
+        monkeypatch.setenv("VMS_X_LAYOUT", "1")
+    a, bb = _dir_inputs(b, d, L, itype, seed), _dir_inputs(b, d, L, itype, seed + 1)
+    g = torch.Generator(device="cpu").manual_seed(seed + 2)
+    z = torch.randn(b, d, L, generator=g).to(itype).to(DEV)
+    dout = torch.randn(b, d, L, generator=g).to(itype).to(DEV)
+    fw = []
+    for i, (u, delta, A, B, C, D, bias) in enumerate((a, bb)):
+        out, x, _ = ssc.fwd(u, delta, A, B, C, D, z, bias, True, reverse=(i == 1))
+        fw.append((out, x))
+    # the two single-direction calls, the second adding its dz to the first's (what BiMambaInnerFnNoOutProj did before v9)
+    dz_ref = torch.empty_like(z)
+    ra = ssc.bwd(*a[:6], z, a[6], dout, fw[0][1], fw[0][0], dz_ref, True, False, reverse=False, keep_fp32=True)
+    rb = ssc.bwd(*bb[:6], z, bb[6], dout, fw[1][1], fw[1][0], dz_ref, True, False, reverse=True, keep_fp32=True, accumulate_dz=True)
+    single_kernel = vms_hip.lib().vms_last_kernel().decode()
+    dz = torch.full_like(z, float("nan"))
+    da, db = ssc.bwd_dual((*a[:6], a[6], fw[0][1], fw[0][0]), (*bb[:6], bb[6], fw[1][1], fw[1][0]), z, dout, dz, True, keep_fp32=True)
+    kernel = vms_hip.lib().vms_last_kernel().decode()
+    torch.cuda.synchronize()
+    return (da, db), (ra, rb), kernel, single_kernel, (a, bb, z, dout)
+
+
+NAMES = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"]
+
+
+@pytest.mark.parametrize("layout1", [False, True])
+@pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,want", [((5, 1024, 1040), "scan_bwd_pair4_dual_w4"),      # 320 8-wave workgroups: not whole rounds -> 4-wave
+                                        ((4, 1024, 528), "scan_bwd_pair4_dual_w8"),       # 256: whole rounds of 8-wave workgroups
+                                        ((8, 768, 400), "scan_bwd_pair4_dual_w4"),        # the suite's grid: 2 x 192
+                                        ((1, 64, 2048), None)])                             # too small to fill the chip: two launches
+def test_dual_equals_two_single_calls(monkeypatch, shape, want, itype, layout1):
+    (da, db), (ra, rb), kernel, single_kernel, _ = _run_pair(*shape, itype, layout1, monkeypatch)
+    if want is None:
+        assert "dual" not in kernel, kernel
+    else:
+        assert kernel == want, kernel
+    for got, ref, tag in ((da, ra, "a"), (db, rb, "b")):
+        for k, name in enumerate(NAMES):
+            # same kernel body, same order of operations within a row; the fp32 atomics (dB, dC over 32 / 16 rows, dA / dD /
+            # dbias over the batch) are order-dependent in the last bits and the dual grid sums 16-row partials
+            tol = 0.0 if name in ("du", "ddelta") else 2e-5
+            e = rel_err(got[k], ref[k])
+            assert e <= tol, f"{tag}.{name}: {e:.3e}"
+    # dz: one rounding of dout (out_a + out_b) dsilu(z) against the two-call form's two roundings: within an ulp of the dtype
+    check(da[7], ra[7], 2 * (2 ** -8 if itype == torch.bfloat16 else 2 ** -11), "dz dual vs accumulated")
+    assert len(db) == 7 and not torch.isnan(da[7].float()).any()
+
+
+@pytest.mark.parametrize("itype", [torch.bfloat16])
+def test_dual_vs_oracle(oracle, monkeypatch, itype):
+    b, d, L = 8, 768, 272     # the suite's grid (2 x 192 workgroups of 8 waves -> 768 of 4), short rows for the oracle
+    (da, db), _, kernel, _, (a, bb, z, dout) = _run_pair(b, d, L, itype, False, monkeypatch, seed=5)
+    assert kernel == "scan_bwd_pair4_dual_w4"
+    f = lambda t: t.detach().float().cpu().numpy()
+    dz_want = 0
+    for got, inp, rev in ((da, a, False), (db, bb, True)):
+        u, delta, A, B, C, D, bias = [f(t) for t in inp]
+        fl = (lambda t: np.ascontiguousarray(t[..., ::-1])) if rev else (lambda t: t)
+        o = oracle.scan_bwd(fl(u), fl(delta), A, fl(B), fl(C), D, fl(f(z)), bias, fl(f(dout)), True, prec="f64")
+        for k, name in enumerate(NAMES):
+            ref = o[name]
+            if rev and name in ("du", "ddelta", "dB", "dC"):
+                ref = ref[..., ::-1]
+            check(got[k], ref, tol_for(name, itype, "oracle"), f"{'b' if rev else 'a'}.{name} vs oracle")
+        dz_want = dz_want + (o["dz"][..., ::-1] if rev else o["dz"])
+    check(da[7], dz_want, tol_for("dz", itype, "oracle"), "dz (both directions) vs oracle")
+
+
+def test_dual_rejects_mismatched_dz():
+    import selective_scan_cuda as ssc
+    import vms_hip
+    if vms_hip.ext() is not None:
+        pytest.skip("argument check of the C entry point: reached through the ctypes binding (VMS_NO_TORCH_EXT=1)")
+    a, bb = _dir_inputs(1, 32, 64, torch.bfloat16, 0), _dir_inputs(1, 32, 64, torch.bfloat16, 1)
+    z = torch.randn(1, 32, 64, device=DEV, dtype=torch.bfloat16)
+    out, x, _ = ssc.fwd(*a[:6], z, a[6], True)
+    ka, _ = ssc._bwd_prepare(*a[:6], z, a[6], z, x, out, None, True, False, False, None, True, False, 0, 0)
+    kb, _ = ssc._bwd_prepare(*bb[:6], z, bb[6], z, x, out, None, True, False, True, None, True, False, 0, 0)   # b with its OWN dz
+    with pytest.raises(RuntimeError, match="delivered in a->dz"):
+        vms_hip.scan_bwd_dual(ka, kb)
+
+
+@pytest.mark.parametrize("shape", [(8, 400, 768), (2, 272, 256)])   # (B, L, d_model): the dual grid / the two-launch fallback
+def test_block_backward_dual_vs_two_launches(monkeypatch, shape):
+    """The ViM block's one-node backward with the two scans as one call == with one launch per direction."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    from mamba_ssm.ops import selective_scan_interface as ssi
+    b, L, dm = shape
+    torch.manual_seed(0)
+    block = Mamba(dm, d_state=16, expand=1, bimamba_type="v2").to(DEV)
+    x = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn(b, L, dm, device=DEV, dtype=torch.bfloat16)
+
+    def step():
+        block.zero_grad(set_to_none=True)
+        x.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = block(x)
+        y.backward(g)
+        return x.grad.clone(), {k: p.grad.clone() for k, p in block.named_parameters()}
+    dx1, g1 = step()
+    monkeypatch.setattr(ssi, "_DUAL_BWD", False)
+    dx0, g0 = step()
+    check(dx1, dx0, 2e-2, "block dx: dual vs two launches")
+    for k in g0:
+        check(g1[k], g0[k], 2e-2, f"block {k}: dual vs two launches")

@@ -42,6 +42,15 @@ def main():
         dxz = torch.empty_like(xz); dz = dxz[:, d:]
         t = timeit(lambda: selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, dz, True, False))
         print(f"scan_bwd  {t*1e3:9.1f} us  {ab['vms_selective_scan_bwd']/t/1e6:8.1f} GB/s  {ab['vms_selective_scan_bwd']/t/1e6/8000*100:5.1f}% of 8 TB/s")
+    if "dual" in which:   # both directions' backward scans as one call (vms_selective_scan_bwd_dual)
+        dout = torch.randn(b, d, L, device=dev, dtype=dt)
+        dxz = torch.empty_like(xz); dz = dxz[:, d:]
+        A2 = A * 1.1
+        out2, x2, _ = selective_scan_cuda.fwd(u, delta, A2, B, C, D, z, bias, True, reverse=True)
+        da, db_ = (u, delta, A, B, C, D, bias, x, out), (u, delta, A2, B, C, D, bias, x2, out2)
+        t = timeit(lambda: selective_scan_cuda.bwd_dual(da, db_, z, dout, dz, True, keep_fp32=True))
+        import vms_hip
+        print(f"scan_bwd_dual {t*1e3:9.1f} us  {ab['vms_selective_scan_bwd_dual']/t/1e6:8.1f} GB/s  {ab['vms_selective_scan_bwd_dual']/t/1e6/8000*100:5.1f}% of 8 TB/s  [{vms_hip.lib().vms_last_kernel().decode()}]")
     if "conv" in which:
         w = torch.randn(d, 4, device=dev); cb = torch.randn(d, device=dev)
         t = timeit(lambda: causal_conv1d_cuda.causal_conv1d_fwd(u, w, cb, True))
@@ -70,7 +79,7 @@ def norm_bench():
 
 if __name__ == "__main__":
     args = sys.argv[1:]
-    if not args or any(a in ("fwd", "bwd", "conv") for a in args):
+    if not args or any(a in ("fwd", "bwd", "conv", "dual") for a in args):
         main()
     if "norm" in args:
         norm_bench()

@@ -24,6 +24,8 @@ int validate_scan_common(const vms_scan_fwd_params& p);
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p);
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream);
+bool scan_bwd_pair_dual_fusable(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b);
+int launch_scan_bwd_pair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream);
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q);
 int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q);
 bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
@@ -416,4 +418,40 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
         case VMS_F16: return dispatch_bwd<f16_t, 16>(q, vec, s);
         default: return dispatch_bwd<bf16_t, 16>(q, vec, s);
     }
+}
+
+// Both directions of a bidirectional block (vms_hip.h): one grid when the pair qualifies, else the two single calls with the
+// second adding its dz to the first's.
+static bool scan_bwd_dual_checks_ok(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b) {
+    using namespace vms;
+    const vms_scan_fwd_params &pa = a.f, &pb = b.f;
+    if (pa.is_complex || pb.is_complex || validate_scan_common(pa) != VMS_OK || validate_scan_common(pb) != VMS_OK) return false;
+    if (!(a.dout && a.du && a.ddelta && a.dA && a.dB && a.dC && b.dout && b.du && b.ddelta && b.dA && b.dB && b.dC)) return false;
+    if ((pa.D == nullptr) != (a.dD == nullptr) || (pb.D == nullptr) != (b.dD == nullptr)) return false;
+    if ((pa.delta_bias == nullptr) != (a.ddelta_bias == nullptr) || (pb.delta_bias == nullptr) != (b.ddelta_bias == nullptr)) return false;
+    if (pa.impl < VMS_IMPL_AUTO || pa.impl > VMS_IMPL_ROWS || pb.impl != pa.impl || pa.segments < 0 || pb.segments < 0) return false;
+    return scan_impl_level(pa) >= VMS_IMPL_PAIR;
+}
+
+extern "C" int vms_scan_bwd_dual_fused(const vms_scan_bwd_params* a, const vms_scan_bwd_params* b) {
+    if (a == nullptr || b == nullptr) return 0;
+    return scan_bwd_dual_checks_ok(*a, *b) && vms::scan_bwd_pair_dual_fusable(*a, *b) ? 1 : 0;
+}
+
+extern "C" int vms_selective_scan_bwd_dual(const vms_scan_bwd_params* a, const vms_scan_bwd_params* b, void* stream) {
+    using namespace vms;
+    VMS_CHECK(a != nullptr && b != nullptr, "null params");
+    VMS_CHECK(b->dz == nullptr || b->dz == a->dz, "dual: the gradient of z is delivered in a->dz (b->dz must be NULL or the same tensor)");
+    VMS_CHECK(!b->dz_accumulate || b->dz != nullptr, "dual: b->dz_accumulate needs b->dz");
+    if (vms_scan_bwd_dual_fused(a, b)) return launch_scan_bwd_pair_dual(*a, *b, static_cast<hipStream_t>(stream));
+    if (int rc = vms_selective_scan_bwd(a, stream)) return rc;
+    vms_scan_bwd_params b2 = *b;
+    if (b2.f.z) {
+        VMS_CHECK(a->dz != nullptr && a->f.z != nullptr, "dual: a->dz is required when z is given");
+        b2.dz = a->dz;
+        b2.dz_batch_stride = a->dz_batch_stride;
+        b2.dz_d_stride = a->dz_d_stride;
+        b2.dz_accumulate = 1;
+    }
+    return vms_selective_scan_bwd(&b2, stream);
 }

@@ -596,8 +596,14 @@ template <int W> struct B4 {
     static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4);
 };
 
-template <typename T, bool HZ, bool REV, int W, bool XL>
-__device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry) {
+// DZM (two directions of a bidirectional block in one launch, vms_selective_scan_bwd_dual): 0 = dz from this launch's own
+// `out` (the single-direction call); 1 = dz = dout (out + out2) dsilu(z) -- the gradient z receives through BOTH directions,
+// which is linear in the pre-gate outputs (out2 = the other direction's, same physical positions); 2 = no dz (the other
+// direction's workgroups write it).  bid / nblk: this problem's workgroup index and count inside the launch.
+template <typename T, bool HZ, bool REV, int W, bool XL, int DZM = 0>
+__device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry,
+                                                    const int bid, const int nblk, const T* __restrict__ out2_b = nullptr,
+                                                    const int64_t out2_batch_stride = 0, const int64_t out2_d_stride = 0) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN, CH = kCH;
@@ -610,8 +616,8 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const int j = lane & 15, r = lane >> 4;
     lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * B4<W>::kRecPitch;
     __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
-    const int wg_per_seg = gridDim.x / n_seg;
-    const int seg = blockIdx.x / wg_per_seg, wg = blockIdx.x - seg * wg_per_seg;
+    const int wg_per_seg = nblk / n_seg;
+    const int seg = bid / wg_per_seg, wg = bid - seg * wg_per_seg;
     const int b = wg % p.batch;
     const int d0 = (wg / p.batch) * kRows4;
     const int d = d0 + quad * 4 + r;
@@ -692,6 +698,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     RawB<T, REV> pu, pdt, pdo, pz, pout;   // row data of the NEXT chunk: requested while the current one computes
     RawB<T, REV> pdzo;                     // dz_accumulate: what dz holds (round 3: requested with the row data instead of right
                                            // before its use, where every chunk waited for it: +36 -> +? us for the accumulating launch)
+    RawB<T, REV> pout2;                    // DZM == 1: the other direction's pre-gate output
     float hck_next = 0.f;
     // XL (x_has_sub == 3): the forward left the state after every 8 elements; a lane takes the one entering its elements
     // instead of rebuilding it (its own 8-step recurrence from zero + the row scan of the lane aggregates)
@@ -724,8 +731,9 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         pdo.load_stream(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl, v);
         if (HZ) {
             pz.load_stream(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
-            pout.load_stream(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
-            if (q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
+            if (DZM != 2 || out_z_b) pout.load_stream(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
+            if (DZM == 1) pout2.load_stream(out2_b, VMS_OFF(out2_batch_stride, out2_d_stride) + pl, v);
+            if (DZM != 2 && q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
         }
         if constexpr (!XL) {
             const int e128 = cc * (CH / 128) - 1;
@@ -796,17 +804,17 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                     const float zv = pz.at(i);
                     const float s = sigmoidf_(zv);
                     const float silu = zv * s;
-                    ov[i] = pout.at(i);
-                    dzv[i] = dy[i] * ov[i] * s * (1.f + zv * (1.f - s));
+                    if (DZM != 2 || out_z_b) ov[i] = pout.at(i);
+                    if (DZM != 2) dzv[i] = dy[i] * (DZM == 1 ? ov[i] + pout2.at(i) : ov[i]) * s * (1.f + zv * (1.f - s));
                     dy[i] *= silu;
-                    ov[i] *= silu;
+                    if (DZM != 2 || out_z_b) ov[i] *= silu;
                 }
-                if (q.dz_accumulate) {  // dz += (vms_hip.h)
+                if (DZM != 2 && q.dz_accumulate) {  // dz += (vms_hip.h)
 #pragma unroll
                     for (int i = 0; i < K; ++i) dzv[i] += pdzo.at(i);
                 }
                 if (ok) {
-                    store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
+                    if (DZM != 2) store_b<T, REV>(dz_b + (VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl0), dzv);
                     if (out_z_b) store_b<T, REV>(out_z_b + (VMS_OFF(p.out_z_batch_stride, p.out_z_d_stride) + pl0), ov);
                 }
             }
@@ -1036,10 +1044,28 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
-        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry);
-        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry);
+        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
+        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
     } else {
-        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry);
+        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
+    }
+}
+
+// Both directions of a bidirectional block (mamba_simple.py:234-258: two parameter sets over the same rows, the second scanned
+// right-to-left) in ONE grid: the first half of the workgroups runs qa left-to-right and writes the whole dz (DZM 1), the second
+// half runs qb right-to-left (DZM 2).  Why: a direction of the suite's most common shape, (8, 768, 3136), is 192 workgroups of
+// 8 waves for 256 CUs -- a quarter of the chip idles through both launches, and no split of ONE direction helps (the kernel
+// needs its 2 waves per SIMD, profiles/r03_bwd_segments.md).  Together, as 768 workgroups of W = 4 waves (one wave per SIMD
+// each, two resident per CU), the grid is 1.5 rounds whose last half-round runs one wave per SIMD at 0.7x the time:
+// 2 x 317 -> 489 us (profiles/r04_dual_bwd.md).
+template <typename T, int W, bool XL>
+__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_dual_kernel(const vms_scan_bwd_params qa, const vms_scan_bwd_params qb) {
+    const int half = gridDim.x >> 1;
+    if ((int)blockIdx.x < half) {
+        scan_bwd_pair4_body<T, true, false, W, XL, 1>(qa, 1, nullptr, blockIdx.x, half, static_cast<const T*>(qb.f.out),
+                                                       qb.f.out_batch_stride, qb.f.out_d_stride);
+    } else {
+        scan_bwd_pair4_body<T, true, true, W, XL, 2>(qb, 1, nullptr, blockIdx.x - half, half);
     }
 }
 
@@ -1350,6 +1376,63 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
                         : four ? (n_seg > 1 ? "scan_bwd_pair4+split" : "scan_bwd_pair4")
                                : (n_seg > 1 ? "scan_bwd_pair+split" : "scan_bwd_pair"));
     return VMS_OK;
+}
+
+// ---- both directions of a bidirectional block as one grid (vms_selective_scan_bwd_dual) ------------------------------------
+// Conditions: the two problems are the two directions of one block -- same sizes and dtype, a left-to-right, b right-to-left,
+// the SAME z and dout (then dz = dout (out_a + out_b) dsilu(z) is what z receives through both), whole-vector rows, the same
+// checkpoint layout -- and together they fill the chip (below that each direction is better off split into ranges of chunks on
+// its own, scan_bwd_pair_segments).
+bool scan_bwd_pair_dual_fusable(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b) {
+    const vms_scan_fwd_params &pa = a.f, &pb = b.f;
+    if (pa.batch != pb.batch || pa.dim != pb.dim || pa.seqlen != pb.seqlen || pa.dtype != pb.dtype || pa.n_groups != pb.n_groups ||
+        pa.dstate != pb.dstate)
+        return false;
+    if (pa.reverse != 0 || pb.reverse == 0 || pa.reverse_from != 0 || pb.reverse_from != 0) return false;
+    if (pa.dtype == VMS_F32) return false;   // 16-bit activations (what autocast runs); the fp32 body has no registers to spare
+    if (pa.seqlen % kBK != 0 || pa.segments > 1 || pb.segments > 1) return false;
+    if (!pa.z || pa.z != pb.z || pa.z_batch_stride != pb.z_batch_stride || pa.z_d_stride != pb.z_d_stride) return false;
+    if (a.dout != b.dout || a.dout_batch_stride != b.dout_batch_stride || a.dout_d_stride != b.dout_d_stride) return false;
+    if (!a.dz || !pa.out || !pb.out || pa.out == pb.out) return false;
+    if (!scan_bwd_pair_eligible(a, true) || !scan_bwd_pair_eligible(b, true)) return false;
+    auto xl = [](const vms_scan_fwd_params& p) {
+        return p.x_has_sub == 3 && (int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
+    };
+    if (xl(pa) != xl(pb)) return false;
+    const int n8 = pa.batch * ((pa.dim + kBRows - 1) / kBRows);
+    return 2 * n8 >= device_cu_count();
+}
+
+template <typename T>
+static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream) {
+    const vms_scan_fwd_params& p = a.f;
+    const int n8 = p.batch * ((p.dim + kBRows - 1) / kBRows), cus = device_cu_count();
+    // whole rounds of 8-wave workgroups at 2 waves per SIMD (the benchmark shape: 512 workgroups = 2 per CU) are the better
+    // kernel (793 vs 835 us per direction there); everything else runs 4-wave workgroups, whose partial last round has one
+    // wave per SIMD (profiles/r04_dual_bwd.md)
+    const bool w8 = (2 * n8) % cus == 0;
+    const bool xl = p.x_has_sub == 3;
+    if (w8) {
+        const dim3 grid(2 * n8), block(8 * kWave);
+        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 8, true>), grid, block, B4<8>::kSmem, stream, a, b);
+        else hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 8, false>), grid, block, B4<8>::kSmem, stream, a, b);
+    } else {
+        const dim3 grid(2 * p.batch * ((p.dim + 15) / 16)), block(4 * kWave);
+        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, true>), grid, block, B4<4>::kSmem, stream, a, b);
+        else hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, false>), grid, block, B4<4>::kSmem, stream, a, b);
+    }
+    VMS_LAUNCH_CHECK();
+    set_last_kernel(w8 ? "scan_bwd_pair4_dual_w8" : "scan_bwd_pair4_dual_w4");
+    return VMS_OK;
+}
+
+int launch_scan_bwd_pair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream) {
+    static_assert(B4<8>::kSmem <= 64 * 1024 && B4<4>::kSmem <= 64 * 1024, "the dual launch sets no LDS attribute");
+    switch (a.f.dtype) {
+        case VMS_BF16: return launch_bpair_dual<bf16_t>(a, b, stream);
+        case VMS_F16: return launch_bpair_dual<f16_t>(a, b, stream);
+        default: set_error("dual backward: 16-bit activations only"); return VMS_ERR_UNSUPPORTED;
+    }
 }
 
 int launch_scan_bwd_pair(const vms_scan_bwd_params& q, hipStream_t stream) {

@@ -214,21 +214,36 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
     return res;
 }
 
-// -> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492); B / C as for scan_fwd;
-// Bshape / Cshape: the caller's unpadded B / C, whose shapes and dtypes dB / dC take
-std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
-                           const OptT& z_, const OptT& delta_bias_, const Tensor& dout, const OptT& x_, const OptT& out_, const OptT& dz_,
-                           bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
-                           bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape,
-                           int64_t reverse_from = 0) {
+// everything selective_scan.cpp:338-492 does before its launch: checks, allocations, the parameter block
+struct ScanBwdJob {
+    vms_scan_bwd_params Q;
+    Tensor du, ddelta, dA, dB, dC, ws, Bshape, Cshape;
+    OptT dD, dbias, dz, out_z;
+    bool has_z = false, recompute_out_z = false, keep_fp32 = false;
+    std::vector<OptT> results() {
+        if (!keep_fp32) { dB = dB.to(Bshape.scalar_type()); dC = dC.to(Cshape.scalar_type()); }
+        std::vector<OptT> res{du, ddelta, dA, dB, dC, dD, dbias};
+        if (has_z) res.push_back(dz);
+        if (recompute_out_z) res.push_back(out_z);
+        return res;
+    }
+};
+
+// no_dz: z is given but this call does not produce dz (the second direction of vms_selective_scan_bwd_dual)
+ScanBwdJob scan_bwd_prep(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
+                         const OptT& z_, const OptT& delta_bias_, const Tensor& dout, const OptT& x_, const OptT& out_, const OptT& dz_,
+                         bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
+                         bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape,
+                         int64_t reverse_from, bool no_dz = false) {
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
-    c10::DeviceGuard guard(u.device());   // covers the workspace query (CU count of the tensors' device) and the allocations
+    ScanBwdJob J;
+    J.Bshape = Bshape; J.Cshape = Cshape; J.keep_fp32 = keep_fp32; J.has_z = z_.has_value(); J.recompute_out_z = recompute_out_z && z_.has_value();
     auto bdl = [&](const Tensor& t) { return t.dim() == 3 && t.size(0) == s.batch && t.size(1) == s.dim && t.size(2) == s.seqlen; };
     TORCH_CHECK(dout.scalar_type() == u.scalar_type(), "dout.scalar_type() == input_type");
     TORCH_CHECK(dout.is_cuda(), "dout.is_cuda()");
     TORCH_CHECK(dout.stride(-1) == 1, "dout.stride(-1) == 1");
     TORCH_CHECK(bdl(dout), "dout must have shape (batch, dim, seqlen)");
-    OptT out, dz, out_z;
+    OptT out;
     if (z_.has_value()) {
         TORCH_CHECK(out_.has_value(), "out_.has_value()");
         out = out_;
@@ -236,13 +251,13 @@ std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A
                     "out must be (batch, dim, seqlen), input dtype, unit last stride");
         TORCH_CHECK(!accumulate_dz || dz_.has_value(), "accumulate_dz needs the dz tensor to add to");
         if (dz_.has_value()) {
-            dz = dz_;
-            TORCH_CHECK(dz->scalar_type() == u.scalar_type() && dz->is_cuda() && dz->stride(-1) == 1 && bdl(*dz),
+            J.dz = dz_;
+            TORCH_CHECK(J.dz->scalar_type() == u.scalar_type() && J.dz->is_cuda() && J.dz->stride(-1) == 1 && bdl(*J.dz),
                         "dz must be (batch, dim, seqlen), input dtype, unit last stride");
-        } else {
-            dz = at::empty_like(*z_);
+        } else if (!no_dz) {
+            J.dz = at::empty_like(*z_);
         }
-        if (recompute_out_z) out_z = at::empty_like(*out);
+        if (recompute_out_z) J.out_z = at::empty_like(*out);
     }
     const int64_t n_chunks = (s.seqlen + 2047) / 2048;
     if (n_chunks > 1) TORCH_CHECK(x_.has_value(), "x_.has_value()");
@@ -254,9 +269,7 @@ std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A
     } else {
         TORCH_CHECK(s.seqlen <= 1024, "x (the forward's checkpoints) is required when seqlen > 1024");
     }
-    Tensor du = at::empty_like(u), ddelta = at::empty_like(delta);
-    Tensor dA, dB, dC;
-    OptT dD, dbias;
+    J.du = at::empty_like(u); J.ddelta = at::empty_like(delta);
     const auto f32 = u.options().dtype(at::kFloat);
     if (zeroed.has_value()) {
         int64_t need = A.numel() + Bshape.numel() + Cshape.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
@@ -264,44 +277,86 @@ std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A
                     "zeroed must be a flat float32 tensor of at least bwd_accumulator_elems() elements");
         int64_t o = 0;
         auto carve = [&](const Tensor& like) { Tensor t = zeroed->narrow(0, o, like.numel()).view(like.sizes()); o += like.numel(); return t; };
-        dA = carve(A); dB = carve(Bshape); dC = carve(Cshape);
-        if (D_.has_value()) dD = carve(*D_);
-        if (delta_bias_.has_value()) dbias = carve(*delta_bias_);
+        J.dA = carve(A); J.dB = carve(Bshape); J.dC = carve(Cshape);
+        if (D_.has_value()) J.dD = carve(*D_);
+        if (delta_bias_.has_value()) J.dbias = carve(*delta_bias_);
     } else {
-        dA = at::zeros_like(A);
-        dB = at::zeros(Bshape.sizes(), f32);
-        dC = at::zeros(Cshape.sizes(), f32);
-        if (D_.has_value()) dD = at::zeros_like(*D_);
-        if (delta_bias_.has_value()) dbias = at::zeros_like(*delta_bias_);
+        J.dA = at::zeros_like(A);
+        J.dB = at::zeros(Bshape.sizes(), f32);
+        J.dC = at::zeros(Cshape.sizes(), f32);
+        if (D_.has_value()) J.dD = at::zeros_like(*D_);
+        if (delta_bias_.has_value()) J.dbias = at::zeros_like(*delta_bias_);
     }
-    vms_scan_bwd_params Q{};
-    fill_scan(Q.f, s, u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x_, delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
-    Q.dout = dout.data_ptr(); Q.du = du.data_ptr(); Q.ddelta = ddelta.data_ptr(); Q.dz = mptr(dz);
-    Q.dA = dA.data_ptr<float>(); Q.dB = dB.data_ptr<float>(); Q.dC = dC.data_ptr<float>();
-    Q.dD = dD.has_value() ? dD->data_ptr<float>() : nullptr;
-    Q.ddelta_bias = dbias.has_value() ? dbias->data_ptr<float>() : nullptr;
+    vms_scan_bwd_params& Q = J.Q;
+    Q = vms_scan_bwd_params{};
+    fill_scan(Q.f, s, u, delta, A, B, C, D_, z_, delta_bias_, out, J.out_z, x_, delta_softplus, reverse, impl, segments, bc_pad, reverse_from);
+    Q.dout = dout.data_ptr(); Q.du = J.du.data_ptr(); Q.ddelta = J.ddelta.data_ptr(); Q.dz = mptr(J.dz);
+    Q.dA = J.dA.data_ptr<float>(); Q.dB = J.dB.data_ptr<float>(); Q.dC = J.dC.data_ptr<float>();
+    Q.dD = J.dD.has_value() ? J.dD->data_ptr<float>() : nullptr;
+    Q.ddelta_bias = J.dbias.has_value() ? J.dbias->data_ptr<float>() : nullptr;
     Q.dout_batch_stride = dout.stride(0); Q.dout_d_stride = dout.stride(1);
-    Q.du_batch_stride = du.stride(0); Q.du_d_stride = du.stride(1);
-    Q.ddelta_batch_stride = ddelta.stride(0); Q.ddelta_d_stride = ddelta.stride(1);
-    if (dz.has_value()) { Q.dz_batch_stride = dz->stride(0); Q.dz_d_stride = dz->stride(1); }
-    Q.dA_d_stride = dA.stride(0); Q.dA_dstate_stride = dA.stride(1);
-    if (s.var_B) { Q.dB_batch_stride = dB.stride(0); Q.dB_group_stride = dB.stride(1); Q.dB_dstate_stride = dB.stride(2); }
-    else { Q.dB_d_stride = dB.stride(0); Q.dB_dstate_stride = dB.stride(1); }
-    if (s.var_C) { Q.dC_batch_stride = dC.stride(0); Q.dC_group_stride = dC.stride(1); Q.dC_dstate_stride = dC.stride(2); }
-    else { Q.dC_d_stride = dC.stride(0); Q.dC_dstate_stride = dC.stride(1); }
+    Q.du_batch_stride = J.du.stride(0); Q.du_d_stride = J.du.stride(1);
+    Q.ddelta_batch_stride = J.ddelta.stride(0); Q.ddelta_d_stride = J.ddelta.stride(1);
+    if (J.dz.has_value()) { Q.dz_batch_stride = J.dz->stride(0); Q.dz_d_stride = J.dz->stride(1); }
+    Q.dA_d_stride = J.dA.stride(0); Q.dA_dstate_stride = J.dA.stride(1);
+    if (s.var_B) { Q.dB_batch_stride = J.dB.stride(0); Q.dB_group_stride = J.dB.stride(1); Q.dB_dstate_stride = J.dB.stride(2); }
+    else { Q.dB_d_stride = J.dB.stride(0); Q.dB_dstate_stride = J.dB.stride(1); }
+    if (s.var_C) { Q.dC_batch_stride = J.dC.stride(0); Q.dC_group_stride = J.dC.stride(1); Q.dC_dstate_stride = J.dC.stride(2); }
+    else { Q.dC_d_stride = J.dC.stride(0); Q.dC_dstate_stride = J.dC.stride(1); }
     Q.dz_accumulate = accumulate_dz;
-    Tensor ws;
-    const int64_t nws = vms_scan_bwd_workspace_bytes(&Q);   // adjoint carries of a sequence-split backward
+    return J;
+}
+
+void scan_bwd_workspace(ScanBwdJob& J, const Tensor& u) {   // adjoint carries of a sequence-split backward
+    const int64_t nws = vms_scan_bwd_workspace_bytes(&J.Q);
     if (nws > 0) {
-        ws = at::empty({nws}, u.options().dtype(at::kByte));
-        Q.f.workspace = ws.data_ptr(); Q.f.workspace_bytes = nws;
+        J.ws = at::empty({nws}, u.options().dtype(at::kByte));
+        J.Q.f.workspace = J.ws.data_ptr(); J.Q.f.workspace_bytes = nws;
     }
-    call("vms_selective_scan_bwd", vms_selective_scan_bwd, Q, u);
-    if (!keep_fp32) { dB = dB.to(Bshape.scalar_type()); dC = dC.to(Cshape.scalar_type()); }
-    std::vector<OptT> res{du, ddelta, dA, dB, dC, dD, dbias};
-    if (z_.has_value()) res.push_back(dz);
-    if (recompute_out_z) res.push_back(out_z);
-    return res;
+}
+
+// -> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492); B / C as for scan_fwd;
+// Bshape / Cshape: the caller's unpadded B / C, whose shapes and dtypes dB / dC take
+std::vector<OptT> scan_bwd(const Tensor& u, const Tensor& delta, const Tensor& A, const Tensor& B, const Tensor& C, const OptT& D_,
+                           const OptT& z_, const OptT& delta_bias_, const Tensor& dout, const OptT& x_, const OptT& out_, const OptT& dz_,
+                           bool delta_softplus, bool recompute_out_z, bool reverse, const OptT& zeroed, bool keep_fp32,
+                           bool accumulate_dz, int64_t bc_pad, int64_t impl, int64_t segments, const Tensor& Bshape, const Tensor& Cshape,
+                           int64_t reverse_from = 0) {
+    c10::DeviceGuard guard(u.device());   // covers the workspace query (CU count of the tensors' device) and the allocations
+    ScanBwdJob J = scan_bwd_prep(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse, zeroed,
+                                 keep_fp32, accumulate_dz, bc_pad, impl, segments, Bshape, Cshape, reverse_from);
+    scan_bwd_workspace(J, u);
+    call("vms_selective_scan_bwd", vms_selective_scan_bwd, J.Q, u);
+    return J.results();
+}
+
+// Two launches' worth of work behind one entry point (vms_selective_scan_bwd_dual); timed under the single call's name so that
+// per-kernel reports keep one row per entry point
+void call_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, const Tensor& ref) {
+    struct Pair { vms_scan_bwd_params a, b; } pr{a, b};
+    call<Pair>("vms_selective_scan_bwd_dual",
+               [](const Pair* q, void* s) { return vms_selective_scan_bwd_dual(&q->a, &q->b, s); }, pr, ref);
+}
+
+// Both directions of a bidirectional block: a (left-to-right) and b (right-to-left) share z, dout and dz.
+// -> [results of a (dz = the gradient of z through BOTH directions), results of b without dz]
+std::vector<std::vector<OptT>> scan_bwd_dual(
+    const Tensor& u_a, const Tensor& delta_a, const Tensor& A_a, const Tensor& B_a, const Tensor& C_a, const OptT& D_a, const OptT& bias_a,
+    const OptT& x_a, const Tensor& out_a, const OptT& zeroed_a, const Tensor& Bshape_a, const Tensor& Cshape_a,
+    const Tensor& u_b, const Tensor& delta_b, const Tensor& A_b, const Tensor& B_b, const Tensor& C_b, const OptT& D_b, const OptT& bias_b,
+    const OptT& x_b, const Tensor& out_b, const OptT& zeroed_b, const Tensor& Bshape_b, const Tensor& Cshape_b,
+    const Tensor& z, const Tensor& dout, const OptT& dz_, bool delta_softplus, bool keep_fp32, bool accumulate_dz,
+    int64_t bc_pad_a, int64_t bc_pad_b, int64_t impl, int64_t segments) {
+    c10::DeviceGuard guard(u_a.device());
+    ScanBwdJob Ja = scan_bwd_prep(u_a, delta_a, A_a, B_a, C_a, D_a, z, bias_a, dout, x_a, out_a, dz_, delta_softplus, false, /*reverse=*/false,
+                                  zeroed_a, keep_fp32, accumulate_dz, bc_pad_a, impl, segments, Bshape_a, Cshape_a, 0);
+    ScanBwdJob Jb = scan_bwd_prep(u_b, delta_b, A_b, B_b, C_b, D_b, z, bias_b, dout, x_b, out_b, OptT(), delta_softplus, false, /*reverse=*/true,
+                                  zeroed_b, keep_fp32, false, bc_pad_b, impl, segments, Bshape_b, Cshape_b, 0, /*no_dz=*/true);
+    if (!vms_scan_bwd_dual_fused(&Ja.Q, &Jb.Q)) { scan_bwd_workspace(Ja, u_a); scan_bwd_workspace(Jb, u_b); }
+    call_dual(Ja.Q, Jb.Q, u_a);
+    std::vector<OptT> rb = Jb.results();
+    rb.pop_back();   // b has no dz of its own
+    return {Ja.results(), rb};
 }
 
 // ---- causal conv1d ----------------------------------------------------------------------------------------------------
@@ -565,44 +620,59 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     return {r[2], conv_out, x_dbl, delta, r[1], r[0]};
 }
 
-// -> [dxz, dconv_w (d, w), dconv_b | undefined, dx_proj_w, ddt_proj_w, dA, dD | undefined, ddelta_bias | undefined]
-// dxz_into: a dxz that already holds what xz received through another node; this node's dx / dz are ADDED by the kernels.
-std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w,
-                            const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
-                            const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
-                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32,
-                            int64_t proj_flags) {
-    const bool use_mfma_proj = (proj_flags & 1) != 0;
-    c10::DeviceGuard guard(xz.device());
-    const auto wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
-    const int64_t b = xz.size(0), d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
-    const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
-    const Tensor x = xz.narrow(1, 0, d), z = xz.narrow(1, d, d);
-    const bool acc = dxz_into.has_value();
-    Tensor dxz = acc ? *dxz_into : at::empty_like(xz);
-    Tensor dx = dxz.narrow(1, 0, d), dz = dxz.narrow(1, d, d);
-    const Tensor Bv = x_dbl.narrow(1, R, N).unsqueeze(1), Cv = x_dbl.narrow(1, R + N, N).unsqueeze(1);
+// The node's backward around its scan: what is decided and allocated before the scan (begin) and everything after it (finish).
+struct InnerBwd {
+    Tensor xz, x, z, dxz, dx, dz, Bv, Cv, dt_in, zeros, conv_w, x_proj_w, dt_proj_w, conv_out, x_dbl, A;
+    OptT conv_b, D_, delta_bias_;
+    PaddedBC bc;
+    int64_t b, d, R, N, K2, n_scan, n_conv, n_proj;
+    bool acc, use_mfma_proj, mfma_wg, fused_tail, reverse;
+    int64_t reverse_from;
+    at::ScalarType wdt;
+};
+
+InnerBwd inner_bwd_begin(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
+                         const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out, const Tensor& x_dbl,
+                         const Tensor& delta, bool reverse, const OptT& dxz_into, int64_t reverse_from, bool wgrad_fp32, int64_t proj_flags) {
+    InnerBwd I;
+    I.use_mfma_proj = (proj_flags & 1) != 0;
+    I.wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
+    I.b = xz.size(0); I.d = conv_w.size(0); I.R = dt_proj_w.size(1); I.N = A.size(1);
+    I.xz = xz; I.conv_w = conv_w; I.conv_b = conv_b; I.x_proj_w = x_proj_w; I.dt_proj_w = dt_proj_w; I.conv_out = conv_out; I.x_dbl = x_dbl;
+    I.A = A; I.D_ = D_; I.delta_bias_ = delta_bias_; I.reverse = reverse; I.reverse_from = reverse_from;
+    I.x = xz.narrow(1, 0, I.d); I.z = xz.narrow(1, I.d, I.d);
+    I.acc = dxz_into.has_value();
+    I.dxz = I.acc ? *dxz_into : at::empty_like(xz);
+    I.dx = I.dxz.narrow(1, 0, I.d); I.dz = I.dxz.narrow(1, I.d, I.d);
+    I.Bv = x_dbl.narrow(1, I.R, I.N).unsqueeze(1); I.Cv = x_dbl.narrow(1, I.R + I.N, I.N).unsqueeze(1);
     // one zero fill for every fp32 atomics target of the node (scan: dA, dB, dC, dD, ddelta_bias; conv: dweight, dbias)
-    const int64_t n_scan = A.numel() + 2 * Bv.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
-    const int64_t n_conv = conv_w.numel() + (conv_b.has_value() ? conv_b->numel() : 0);
+    I.n_scan = A.numel() + 2 * I.Bv.numel() + (D_.has_value() ? D_->numel() : 0) + (delta_bias_.has_value() ? delta_bias_->numel() : 0);
+    I.n_conv = conv_w.numel() + (conv_b.has_value() ? conv_b->numel() : 0);
     // the two small weight gradients on the matrix cores accumulate in fp32 into the same zero-filled buffer
-    const Tensor dt_in = x_dbl.narrow(1, 0, R);
-    const bool mfma_wg = use_mfma_proj && proj_wgrad_eligible(x_dbl, conv_out) && proj_wgrad_eligible(dt_in, delta);
-    const int64_t n_proj = mfma_wg ? (R + (R + 2 * N)) * d : 0;
-    const int64_t K2 = R + 2 * N;
-    const bool fused_tail = (proj_flags & 2) && proj_conv_bwd_eligible(x, conv_out, x_dbl, x_proj_w, conv_w, conv_b, dx);
-    Tensor zeros = at::zeros({n_scan + n_conv + n_proj + (fused_tail ? K2 * d : 0)}, xz.options().dtype(at::kFloat));
-    const PaddedBC bc = pad_bc(Bv, Cv, reverse, reverse_from > 0);
-    std::vector<OptT> g = scan_bwd(conv_out, delta, A, bc.B, bc.C, D_, z, delta_bias_, dout, ckpt, out, dz, delta_softplus,
-                                   /*recompute_out_z=*/false, reverse, zeros.narrow(0, 0, n_scan), /*keep_fp32=*/true, acc, bc.pad, impl,
-                                   segments, Bv, Cv, reverse_from);
+    I.dt_in = x_dbl.narrow(1, 0, I.R);
+    I.mfma_wg = I.use_mfma_proj && proj_wgrad_eligible(x_dbl, conv_out) && proj_wgrad_eligible(I.dt_in, delta);
+    I.n_proj = I.mfma_wg ? (I.R + (I.R + 2 * I.N)) * I.d : 0;
+    I.K2 = I.R + 2 * I.N;
+    I.fused_tail = (proj_flags & 2) && proj_conv_bwd_eligible(I.x, conv_out, x_dbl, x_proj_w, conv_w, conv_b, I.dx);
+    I.zeros = at::zeros({I.n_scan + I.n_conv + I.n_proj + (I.fused_tail ? I.K2 * I.d : 0)}, xz.options().dtype(at::kFloat));
+    I.bc = pad_bc(I.Bv, I.Cv, reverse, reverse_from > 0);
+    return I;
+}
+
+// g = the scan's [du, ddelta, dA, dB, dC, dD, ddelta_bias, ...]; dB / dC were accumulated in I.zeros
+std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
+    const int64_t b = I.b, d = I.d, R = I.R, N = I.N, K2 = I.K2, n_scan = I.n_scan, n_conv = I.n_conv, n_proj = I.n_proj;
+    const Tensor &x_dbl = I.x_dbl, &conv_out = I.conv_out, &x_proj_w = I.x_proj_w, &dt_proj_w = I.dt_proj_w, &conv_w = I.conv_w, &dt_in = I.dt_in;
+    const OptT& conv_b = I.conv_b;
+    Tensor& zeros = I.zeros;
+    const auto wdt = I.wdt;
     Tensor dconv_out = *g[0], ddelta = *g[1];
     Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
     // dB and dC sit back to back in the zero-filled buffer (scan_bwd carves dA, dB, dC, ...): one cast kernel for both
     dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)})
-        .copy_(zeros.narrow(0, A.numel(), 2 * Bv.numel()).view({2, b, N, dx_dbl.size(2)}).permute({1, 0, 2, 3}));
+        .copy_(zeros.narrow(0, I.A.numel(), 2 * I.Bv.numel()).view({2, b, N, dx_dbl.size(2)}).permute({1, 0, 2, 3}));
     Tensor ddt_proj_w, dx_proj_w;
-    if (mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
+    if (I.mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
         Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({R, d});                  // (R, d) = ddt_proj_w^T
         proj_wgrad(dt_in, ddelta, dw1);
         ddt_proj_w = dw1.t().to(wdt);                                                       // (d, R)
@@ -613,28 +683,72 @@ std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor&
         Tensor d_dt = dx_dbl.narrow(1, 0, R);
         at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
     }
-    if (fused_tail) {
+    if (I.fused_tail) {
         // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
         Tensor dwx = zeros.narrow(0, n_scan + n_conv + n_proj, K2 * d).view({K2, d});
         Tensor dcw = zeros.narrow(0, n_scan, conv_w.numel()).view(conv_w.sizes());
         OptT dcb;
         if (conv_b.has_value()) dcb = zeros.narrow(0, n_scan + conv_w.numel(), conv_b->numel());
-        proj_conv_bwd(x, dconv_out, dx_dbl, x_proj_w, conv_w, conv_b, dx, dcw, dcb, dwx, reverse, reverse_from, acc);
+        proj_conv_bwd(I.x, dconv_out, dx_dbl, x_proj_w, conv_w, conv_b, I.dx, dcw, dcb, dwx, I.reverse, I.reverse_from, I.acc);
         OptT db;
         if (conv_b.has_value()) db = dcb->to(conv_b->scalar_type());
-        return {dxz, dcw.to(conv_w.scalar_type()), db, dwx.to(wdt), ddt_proj_w, g[2], g[5], g[6]};
+        return {I.dxz, dcw.to(conv_w.scalar_type()), db, dwx.to(wdt), ddt_proj_w, g[2], g[5], g[6]};
     }
-    if (mfma_wg && proj_wgrad_eligible(dx_dbl, conv_out)) {
+    if (I.mfma_wg && proj_wgrad_eligible(dx_dbl, conv_out)) {
         Tensor dw2 = zeros.narrow(0, n_scan + n_conv + R * d, (R + 2 * N) * d).view({R + 2 * N, d});
         proj_wgrad(dx_dbl, conv_out, dw2);
         dx_proj_w = dw2.to(wdt);                                                            // (R + 2N, d)
     } else {
         dx_proj_w = at::sum(at::matmul(dx_dbl, conv_out.transpose(1, 2)), {0}, false, wdt);
     }
-    if (use_mfma_proj && proj_apply_eligible(x_proj_w.t(), dx_dbl, dconv_out)) proj_apply(x_proj_w.t(), dx_dbl, dconv_out, true);
+    if (I.use_mfma_proj && proj_apply_eligible(x_proj_w.t(), dx_dbl, dconv_out)) proj_apply(x_proj_w.t(), dx_dbl, dconv_out, true);
     else dconv_out.baddbmm_(x_proj_w.t().expand({b, -1, -1}), dx_dbl);                      // + W_x^T dx_dbl, in place
-    std::vector<OptT> c = conv_bwd(x, conv_w, conv_b, dconv_out, dx, true, reverse, zeros.narrow(0, n_scan, n_conv), acc, reverse_from);
-    return {dxz, c[1], c[2], dx_proj_w, ddt_proj_w, g[2], g[5], g[6]};
+    std::vector<OptT> c = conv_bwd(I.x, conv_w, conv_b, dconv_out, I.dx, true, I.reverse, zeros.narrow(0, n_scan, n_conv), I.acc, I.reverse_from);
+    return {I.dxz, c[1], c[2], dx_proj_w, ddt_proj_w, g[2], g[5], g[6]};
+}
+
+// -> [dxz, dconv_w (d, w), dconv_b | undefined, dx_proj_w, ddt_proj_w, dA, dD | undefined, ddelta_bias | undefined]
+// dxz_into: a dxz that already holds what xz received through another node; this node's dx / dz are ADDED by the kernels.
+std::vector<OptT> inner_bwd(const Tensor& dout_, const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w,
+                            const Tensor& dt_proj_w, const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out,
+                            const Tensor& x_dbl, const Tensor& delta, const Tensor& ckpt, const Tensor& out, bool delta_softplus,
+                            bool reverse, const OptT& dxz_into, int64_t impl, int64_t segments, int64_t reverse_from, bool wgrad_fp32,
+                            int64_t proj_flags) {
+    c10::DeviceGuard guard(xz.device());
+    const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
+    InnerBwd I = inner_bwd_begin(xz, conv_w, conv_b, x_proj_w, dt_proj_w, A, D_, delta_bias_, conv_out, x_dbl, delta, reverse, dxz_into,
+                                 reverse_from, wgrad_fp32, proj_flags);
+    std::vector<OptT> g = scan_bwd(conv_out, delta, A, I.bc.B, I.bc.C, D_, I.z, delta_bias_, dout, ckpt, out, I.dz, delta_softplus,
+                                   /*recompute_out_z=*/false, reverse, I.zeros.narrow(0, 0, I.n_scan), /*keep_fp32=*/true, I.acc, I.bc.pad, impl,
+                                   segments, I.Bv, I.Cv, reverse_from);
+    return inner_bwd_finish(I, g);
+}
+
+// Both directions of a bidirectional block (BiMambaInnerFnNoOutProj): `a` = the left-to-right parameter set, `b` = the
+// right-to-left one, each given as [conv_w, conv_b, x_proj_w, dt_proj_w, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out]
+// (conv_b / D / delta_bias may be None).  The two backward scans go out as ONE call (vms_selective_scan_bwd_dual: one grid when
+// the pair qualifies); everything after the scans runs per direction as in inner_bwd, b's dx added to a's by its kernels.
+// -> [dxz, then the 7 parameter gradients of a, then those of b]
+std::vector<OptT> inner_bwd_dual(const Tensor& dout_, const Tensor& xz, const std::vector<OptT>& a, const std::vector<OptT>& b,
+                                 bool delta_softplus, int64_t impl, int64_t segments, bool wgrad_fp32, int64_t proj_flags) {
+    TORCH_CHECK(a.size() == 12 && b.size() == 12, "inner_bwd_dual: 12 tensors per direction expected");
+    c10::DeviceGuard guard(xz.device());
+    const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
+    auto T = [](const OptT& t) -> const Tensor& { TORCH_CHECK(t.has_value(), "inner_bwd_dual: missing tensor"); return *t; };
+    InnerBwd Ia = inner_bwd_begin(xz, T(a[0]), a[1], T(a[2]), T(a[3]), T(a[4]), a[5], a[6], T(a[7]), T(a[8]), T(a[9]), /*reverse=*/false,
+                                  OptT(), 0, wgrad_fp32, proj_flags);
+    InnerBwd Ib = inner_bwd_begin(xz, T(b[0]), b[1], T(b[2]), T(b[3]), T(b[4]), b[5], b[6], T(b[7]), T(b[8]), T(b[9]), /*reverse=*/true,
+                                  Ia.dxz, 0, wgrad_fp32, proj_flags);
+    std::vector<std::vector<OptT>> g = scan_bwd_dual(
+        Ia.conv_out, T(a[9]), Ia.A, Ia.bc.B, Ia.bc.C, Ia.D_, Ia.delta_bias_, a[10], T(a[11]), Ia.zeros.narrow(0, 0, Ia.n_scan), Ia.Bv, Ia.Cv,
+        Ib.conv_out, T(b[9]), Ib.A, Ib.bc.B, Ib.bc.C, Ib.D_, Ib.delta_bias_, b[10], T(b[11]), Ib.zeros.narrow(0, 0, Ib.n_scan), Ib.Bv, Ib.Cv,
+        Ia.z, dout, Ia.dz, delta_softplus, /*keep_fp32=*/true, /*accumulate_dz=*/false, Ia.bc.pad, Ib.bc.pad, impl, segments);
+    std::vector<OptT> ra = inner_bwd_finish(Ia, g[0]);
+    std::vector<OptT> rb = inner_bwd_finish(Ib, g[1]);
+    std::vector<OptT> res{ra[0]};
+    res.insert(res.end(), ra.begin() + 1, ra.end());
+    res.insert(res.end(), rb.begin() + 1, rb.end());
+    return res;
 }
 
 // reserve: event pairs created now, outside the timed region (the pool grows on demand if a run needs more)
@@ -691,6 +805,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
           py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());
     m.def("inner_bwd", &inner_bwd);
+    m.def("inner_bwd_dual", &inner_bwd_dual);
+    m.def("scan_bwd_dual", &scan_bwd_dual);
     m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0, pybind11::arg("only") = "");
     m.def("timing_stop", &timing_stop);
     m.def("abi_version", []() { return vms_abi_version(); });

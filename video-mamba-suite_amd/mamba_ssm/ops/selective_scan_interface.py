@@ -457,6 +457,39 @@ def _inner_backward(ctx, dout, dxz_into=None):
                 dB_proj_bias=dB_proj_bias, dC_proj_bias=dC_proj_bias)
 
 
+_DUAL_BWD = os.environ.get("VMS_NO_DUAL_BWD", "0") != "1"   # =1: one backward-scan launch per direction (A/B, tests)
+
+
+def _inner_backward_dual(first, second, dout):
+    """Both directions' backward with their two scans as ONE call (vms_torch.cpp inner_bwd_dual -> vms_selective_scan_bwd_dual:
+    one grid when the pair qualifies -- the suite's (8, 768, 3136) direction is 192 workgroups for 256 CUs).
+    -> (g1, g2) as _inner_backward returns them, or (None, None) when the compiled one-call nodes are not in use."""
+    if not (_DUAL_BWD and getattr(first, "fast", False) and getattr(second, "fast", False)):
+        return None, None
+    ext = _inner_ext_module()
+    if ext is None or not hasattr(ext, "inner_bwd_dual") or first.reverse or not second.reverse:
+        return None, None
+    packs = []
+    for sub in (first, second):
+        (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, _, conv_out, delta, A, _, _, D, delta_bias, ckpt, out,
+         _, _, _) = sub.saved_tensors
+        if sub.checkpoint_lvl == 1:
+            R = delta_proj_weight.shape[1]
+            conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :conv_w.shape[0]], conv_w, conv_b, True, sub.reverse)
+            delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
+        packs.append([conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out])
+    r = ext.inner_bwd_dual(dout, xz, packs[0], packs[1], bool(first.delta_softplus), _vms.scan_impl_from_env(),
+                           _vms.segments_from_env("VMS_BWD_SEGMENTS"), first.w_dtype == torch.float32, _mfma_proj())
+    dxz = r[0]
+
+    def as_dict(v):
+        dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = v
+        return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b, dx_proj_weight=dx_proj_weight,
+                    ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=None, dout_proj_bias=None, dA=dA, dA_b=None,
+                    dB=None, dC=None, dD=dD, ddelta_bias=ddelta_bias, dB_proj_bias=None, dC_proj_bias=None)
+    return as_dict(r[1:8]), as_dict(r[8:15])
+
+
 class MambaInnerFnNoOutProj(torch.autograd.Function):
 
     @staticmethod
@@ -594,8 +627,10 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         saved = ctx.saved_tensors
         first, second = ctx.subs
         first.saved_tensors, second.saved_tensors = saved[:ctx.counts[0]], saved[ctx.counts[0]:]
-        g2 = _inner_backward(second, dout)
-        g1 = _inner_backward(first, dout, dxz_into=g2["dxz"])
+        g1, g2 = _inner_backward_dual(first, second, dout)
+        if g1 is None:
+            g2 = _inner_backward(second, dout)
+            g1 = _inner_backward(first, dout, dxz_into=g2["dxz"])
         first.saved_tensors = second.saved_tensors = None
         per_dir = lambda g: (g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"], g["dA"], g["dD"],
                              g["ddelta_bias"])

@@ -158,25 +158,10 @@ def _carve(flat, offset, like):
     return flat[offset:offset + n].view(like.shape), offset + n
 
 
-def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False,
-        zeroed=None, keep_fp32=False, accumulate_dz=False, bc_pad=None, reverse_from=0):
-    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)
-    zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
-    ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
-    accumulate_dz: dz_ += instead of dz_ = (dz_ must be given)."""
-    ext = _k.ext() if not A.is_complex() else None   # complex A: the checks / allocations below, launch through ctypes
-    impl = _k.scan_impl_from_env()
-    if A.is_complex():
-        _check(reverse_from == 0, "reverse_from is not available with a complex A")
-        bc_pad = 0
-    if ext is not None and impl < _k.IMPL_ROWS:
-        if bc_pad is None:
-            Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
-        else:
-            Bk, Ck = B, C
-        return ext.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out_, dz_, bool(delta_softplus),
-                            bool(recompute_out_z), bool(reverse), zeroed, bool(keep_fp32), bool(accumulate_dz), bc_pad, impl,
-                            _k.segments_from_env("VMS_BWD_SEGMENTS"), B, C, int(reverse_from))
+def _bwd_prepare(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse,
+                 zeroed, keep_fp32, accumulate_dz, bc_pad, reverse_from, no_dz=False):
+    """The checks and allocations of selective_scan.cpp:338-492 -> (arguments of vms_hip.scan_bwd, results()).
+    no_dz: z is given but this launch produces no dz (the second direction of bwd_dual)."""
     batch, dim, seqlen, dstate, var_B, var_C = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     _check(dout.dtype == u.dtype, "dout.scalar_type() == input_type")
     _check(dout.is_cuda, "dout.is_cuda()")
@@ -193,7 +178,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
             dz = dz_
             _check(dz.dtype == u.dtype and dz.is_cuda and dz.stride(-1) == 1 and
                    tuple(dz.shape) == (batch, dim, seqlen), "dz must be (batch, dim, seqlen), input dtype, unit last stride")
-        else:
+        elif not no_dz:
             dz = torch.empty_like(z_)
         if recompute_out_z:
             out_z = torch.empty_like(out)
@@ -232,13 +217,70 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
         dC = torch.zeros_like(C, dtype=torch.float32 if C.dim() >= 3 else A.dtype)
         dD = torch.zeros_like(D_) if D_ is not None else None
         ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
-    _k.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
-                ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz), bc_pad, reverse_from)
-    if not keep_fp32:
-        dB, dC = dB.to(B.dtype), dC.to(C.dtype)
-    result = [du, ddelta, dA, dB, dC, dD, ddelta_bias]
-    if z_ is not None:
-        result.append(dz)
-    if recompute_out_z:
-        result.append(out_z)
-    return result
+    kargs = (u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out, out_z, du, ddelta, dA, dB, dC, dD,
+             ddelta_bias, dz, delta_softplus, reverse, bool(accumulate_dz), bc_pad, reverse_from)
+
+    def results():
+        rB, rC = (dB, dC) if keep_fp32 else (dB.to(B.dtype), dC.to(C.dtype))
+        result = [du, ddelta, dA, rB, rC, dD, ddelta_bias]
+        if z_ is not None and not no_dz:
+            result.append(dz)
+        if recompute_out_z:
+            result.append(out_z)
+        return result
+    return kargs, results
+
+
+def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z, reverse=False,
+        zeroed=None, keep_fp32=False, accumulate_dz=False, bc_pad=None, reverse_from=0):
+    """-> [du, ddelta, dA, dB, dC, dD, ddelta_bias, (dz), (out_z)]   (selective_scan.cpp:338-492)
+    zeroed (extension): a flat, ZERO fp32 tensor of >= bwd_accumulator_elems(..) elements to hold dA, dB, dC, dD and
+    ddelta_bias (one fill by the caller instead of five here); keep_fp32: return dB / dC as accumulated (fp32);
+    accumulate_dz: dz_ += instead of dz_ = (dz_ must be given)."""
+    ext = _k.ext() if not A.is_complex() else None   # complex A: the checks / allocations below, launch through ctypes
+    impl = _k.scan_impl_from_env()
+    if A.is_complex():
+        _check(reverse_from == 0, "reverse_from is not available with a complex A")
+        bc_pad = 0
+    if ext is not None and impl < _k.IMPL_ROWS:
+        if bc_pad is None:
+            Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
+        else:
+            Bk, Ck = B, C
+        return ext.scan_bwd(u, delta, A, Bk, Ck, D_, z_, delta_bias_, dout, x_, out_, dz_, bool(delta_softplus),
+                            bool(recompute_out_z), bool(reverse), zeroed, bool(keep_fp32), bool(accumulate_dz), bc_pad, impl,
+                            _k.segments_from_env("VMS_BWD_SEGMENTS"), B, C, int(reverse_from))
+    kargs, results = _bwd_prepare(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softplus, recompute_out_z,
+                                  reverse, zeroed, keep_fp32, accumulate_dz, bc_pad, reverse_from)
+    _k.scan_bwd(*kargs)
+    return results()
+
+
+def bwd_dual(dir_a, dir_b, z, dout, dz_, delta_softplus, zeroed_a=None, zeroed_b=None, keep_fp32=False, accumulate_dz=False):
+    """The backward scans of BOTH directions of a bidirectional block in one call (vms_hip.h vms_selective_scan_bwd_dual; the
+    reference launches selective_scan_cuda.bwd twice, SSI:541-561).  dir_a / dir_b = (u, delta, A, B, C, D_, delta_bias_, x_,
+    out_) of the left-to-right / right-to-left direction; z, dout (and dz_) are shared.
+    -> ([du, ddelta, dA, dB, dC, dD, ddelta_bias, dz], [du, ddelta, dA, dB, dC, dD, ddelta_bias]): a's list carries the gradient
+    z receives through both directions.  One grid when the pair qualifies (vms_scan_bwd_dual_fused), else two launches."""
+    ua, da, Aa, Ba, Ca, Da, ba, xa, oa = dir_a
+    ub, db, Ab, Bb, Cb, Db, bb, xb, ob = dir_b
+    _check(z is not None, "bwd_dual: z is required (without a gate the two directions share nothing: call bwd twice)")
+    ext = _k.ext()
+    impl = _k.scan_impl_from_env()
+    Bka, Cka, pad_a = pad_bc(Ba, Ca, False)
+    Bkb, Ckb, pad_b = pad_bc(Bb, Cb, True)
+    if ext is not None and impl < _k.IMPL_ROWS and hasattr(ext, "scan_bwd_dual"):
+        ra, rb = ext.scan_bwd_dual(ua, da, Aa, Bka, Cka, Da, ba, xa, oa, zeroed_a, Ba, Ca,
+                                   ub, db, Ab, Bkb, Ckb, Db, bb, xb, ob, zeroed_b, Bb, Cb,
+                                   z, dout, dz_, bool(delta_softplus), bool(keep_fp32), bool(accumulate_dz), pad_a, pad_b, impl,
+                                   _k.segments_from_env("VMS_BWD_SEGMENTS"))
+        return ra, rb
+    ka, res_a = _bwd_prepare(ua, da, Aa, Bka, Cka, Da, z, ba, dout, xa, oa, dz_, delta_softplus, False, False, zeroed_a,
+                             keep_fp32, accumulate_dz, pad_a, 0)
+    kb, res_b = _bwd_prepare(ub, db, Ab, Bkb, Ckb, Db, z, bb, dout, xb, ob, None, delta_softplus, False, True, zeroed_b,
+                             keep_fp32, False, pad_b, 0, no_dz=True)
+    _k.scan_bwd_dual(ka, kb)
+    ra, rb = res_a(), res_b()
+    if not keep_fp32:   # _bwd_prepare saw the padded B / C: the gradients take the callers' dtypes (already their shapes)
+        ra[3], ra[4], rb[3], rb[4] = ra[3].to(Ba.dtype), ra[4].to(Ca.dtype), rb[3].to(Bb.dtype), rb[4].to(Cb.dtype)
+    return ra, rb

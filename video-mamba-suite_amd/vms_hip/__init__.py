@@ -161,11 +161,13 @@ EXPORTS = (
     "vms_proj_conv_bwd", "vms_sizeof_proj_conv_bwd_params",
     "vms_param_prep", "vms_sizeof_prep_params",
     "vms_causal_conv1d_fwd_dual", "vms_sizeof_conv_fwd_dual_params",
+    "vms_selective_scan_bwd_dual", "vms_scan_bwd_dual_fused",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
 # VMS_SCAN_IMPL = generic | fast | pair | rows, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
 # per call, and travel in the parameter block.
+ABI_VERSION = 9   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
 IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS = 0, 1, 2, 3, 4
 BUILD_EXPERIMENTAL = 1
 _IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS}
@@ -210,8 +212,12 @@ def ext():
             lib()
             try:
                 import _vms_torch
-                if _vms_torch.abi_version() == 8:
+                if _vms_torch.abi_version() == ABI_VERSION:
                     _ext = _vms_torch
+                else:   # a stale build must not go unnoticed either
+                    import warnings
+                    warnings.warn(f"_vms_torch.so speaks ABI {_vms_torch.abi_version()}, this package {ABI_VERSION}: rebuild it "
+                                  "with csrc/torch_binding/build.py --force.  Falling back to the ctypes binding.")
             except ImportError as e:
                 # absent: fine (ctypes serves the calls).  Present but unloadable -- built against another torch / Python,
                 # see csrc/torch_binding/build.py's stamp -- must not go unnoticed: every launch pays ~40 us more.
@@ -264,8 +270,8 @@ def lib():
         L = ctypes.CDLL(LIB_PATH)
         L.vms_last_error.restype = ctypes.c_char_p
         L.vms_last_kernel.restype = ctypes.c_char_p
-        if L.vms_abi_version() != 8:
-            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks 8: rebuild it")
+        if L.vms_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH} has ABI version {L.vms_abi_version()}, this binding speaks {ABI_VERSION}: rebuild it")
         for name, st in (("scan_fwd", ScanFwdParams), ("scan_bwd", ScanBwdParams),
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
@@ -285,7 +291,10 @@ def lib():
     return _lib
 
 
-def _call(fn_name, params, ref_tensor):
+def _call(fn_name, params, ref_tensor, params2=None):
+    """params2: the second parameter block of the two-block entry points (vms_selective_scan_bwd_dual)"""
+    if params2 is not None:
+        return _call2(fn_name, params, params2, ref_tensor)
     L = lib()
     if not ref_tensor.is_cuda:
         raise RuntimeError(f"{fn_name}: tensors must be on a GPU (no CPU path in this library)")
@@ -312,6 +321,24 @@ def _call(fn_name, params, ref_tensor):
             if timed:
                 e1.record(cur)
                 _timing.append((fn_name, e0, e1))
+    if rc != 0:
+        raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
+
+
+def _call2(fn_name, pa, pb, ref_tensor):
+    L = lib()
+    if not ref_tensor.is_cuda:
+        raise RuntimeError(f"{fn_name}: tensors must be on a GPU (no CPU path in this library)")
+    with torch.cuda.device(ref_tensor.device):
+        cur = torch.cuda.current_stream()
+        timed = _timing is not None and not (_timing_only and _timing_only != fn_name)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        rc = getattr(L, fn_name)(ctypes.byref(pa), ctypes.byref(pb), ctypes.c_void_p(cur.cuda_stream))
+        if timed:
+            e1.record(cur)
+            _timing.append((fn_name, e0, e1))
     if rc != 0:
         raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
 
@@ -445,8 +472,8 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
     return x
 
 
-def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
-             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
+def _fill_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
+                   ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
     if Q.f.impl >= IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
@@ -470,11 +497,36 @@ def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelt
     Q.dz_accumulate = int(bool(dz_accumulate))
     Q.f.bc_pad = int(bc_pad)
     Q.f.segments = _segments_from_env("VMS_BWD_SEGMENTS")
+    return Q
+
+
+def _scan_bwd_workspace(Q, u):
     nws = _ws_bytes("vms_scan_bwd_workspace_bytes", Q, u)   # adjoint carries of a sequence-split backward
+    ws = None
     if nws > 0:
         ws = torch.empty(nws, device=u.device, dtype=torch.uint8)
         Q.f.workspace, Q.f.workspace_bytes = _ptr(ws), nws
+    return ws
+
+
+def scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
+             ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
+    Q = _fill_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du, ddelta, dA, dB, dC, dD,
+                       ddelta_bias, dz, delta_softplus, reverse, dz_accumulate, bc_pad, reverse_from)
+    ws = _scan_bwd_workspace(Q, u)   # noqa: F841 -- alive until the launch is enqueued
     _call("vms_selective_scan_bwd", Q, u)
+
+
+def scan_bwd_dual(args_a, args_b):
+    """vms_selective_scan_bwd_dual: args_a / args_b = the positional arguments of scan_bwd for the left-to-right and the
+    right-to-left direction of one bidirectional block (b's dz: None).  -> True when the pair ran as ONE grid."""
+    Qa, Qb = _fill_scan_bwd(*args_a), _fill_scan_bwd(*args_b)
+    u = args_a[0]
+    with torch.cuda.device(u.device):
+        fused = bool(lib().vms_scan_bwd_dual_fused(ctypes.byref(Qa), ctypes.byref(Qb)))
+    ws = None if fused else (_scan_bwd_workspace(Qa, u), _scan_bwd_workspace(Qb, u))   # noqa: F841
+    _call("vms_selective_scan_bwd_dual", Qa, u, Qb)
+    return fused
 
 
 def fill_conv_fwd(P, x, weight, bias, out, silu, reverse=False, reverse_from=0):
