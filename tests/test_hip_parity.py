@@ -2051,14 +2051,9 @@ def test_conv_fwd_dual_equals_two_calls(shape, width, itype, bias, silu):
     d2 = d2full[:, :d]
     vms_hip.conv_fwd_dual(x, w, cb, d1, wb, cbb, d2, silu)
     assert vms_hip.last_kernel().startswith("conv_fwd_dual")
-    if itype == torch.float16 and not silu:
-        # hipcc may fold the last fma's rounding into the fp16 conversion (v_fma_mixlo_f16) in one kernel and not in the other:
-        # a handful of last-bit differences per 100 K elements
-        assert (d1.float() - o1.float()).abs().max() <= 2e-3 * o1.float().abs().max()
-        assert (d2.float() - o2.float()).abs().max() <= 2e-3 * o2.float().abs().max()
-        assert ((d1 != o1).sum() + (d2 != o2).sum()).item() <= 1e-3 * o1.numel()
-    else:
-        assert torch.equal(d1, o1) and torch.equal(d2, o2)
+    # every dtype, with and without SiLU: both kernels narrow the ROUNDED fp32 result (round 3's fp16 exception -- hipcc folding
+    # the last fma into the fp16 conversion in one kernel only -- is closed by pinning the fp32 value in both)
+    assert torch.equal(d1, o1) and torch.equal(d2, o2)
     assert torch.isnan(d2full[:, d]).all()
 
 

@@ -1,0 +1,198 @@
+"""Parity hardening (VERDICT r3 "weak" #1): the same kernels under the REFERENCE'S OWN metric, and the checks that only the
+benchmark's size exercises.
+
+1. Element-wise rtol / atol with the reference's table (mamba/tests/ops/test_selective_scan.py:45-51, 137-149) next to this
+   repo's scale-relative metric (tests/test_hip_parity.py: max |a - ref| / max |ref|, under which a wrong small element can
+   hide behind the tensor's largest entry): golden fixtures and random shapes.
+2. At (8, 8192, 1024) bf16, the forward with 8-element checkpoints (vms_hip.h x_has_sub == 3) against the forward with
+   128-element ones: every 16th lane checkpoint IS the 128-element checkpoint (to a few fp32 ulp: two routes to the same
+   state), outputs identical, and the nine
+   backward results of the two layouts agree element by element -- the tripwire for the 16-byte-store write-data hazard the
+   checkpoint stores work around by hand: a toolchain bump that undoes the fix shows up here.
+3. dA, dB, dC, dD, ddelta_bias at full size: a whole batch entry (all 1024 rows) through the f64 oracle, and the full launch's
+   batch sums against the sum of per-entry launches."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from test_hip_parity import DEV, G, check, itype_of, rel_err, run_scan
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- 1. the reference's metric -------------------------------------------------------------------------------------
+def ref_tolerances(itype, has_z, var_B=True, var_C=True):
+    """test_selective_scan.py:45-51 (table) and :137-149 (which multiple each tensor gets) -> {name: (rtol, atol)}"""
+    rtol, atol = (6e-4, 2e-3) if itype == torch.float32 else (3e-3, 5e-3)
+    if itype == torch.bfloat16:
+        rtol, atol = 3e-2, 5e-2
+    rtolw, atolw = 1e-3, 1e-3
+    if has_z:
+        rtolw, atolw = max(rtolw, rtol), max(atolw, atol)
+    return {"out": (rtol, atol), "du": (rtol * 2, atol * 2), "ddelta": (rtol * 5, atol * 10), "dA": (rtolw, atolw * 5),
+            "dB": (rtol, atol) if var_B else (rtolw, atolw), "dC": (rtol, atol) if var_C else (rtolw, atolw),
+            "dD": (rtolw, atolw), "dz": (rtolw, atolw), "ddelta_bias": (rtolw, atolw)}
+
+
+def allclose_ref(a, ref, rtol, atol, what):
+    """torch.allclose's rule, |a - ref| <= atol + rtol |ref| for EVERY element; reports the worst one"""
+    a = a.detach().float().cpu().numpy().astype(np.float64)
+    ref = (ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)).astype(np.float64)
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    excess = np.abs(a - ref) - (atol + rtol * np.abs(ref))
+    i = np.unravel_index(np.argmax(excess), excess.shape)
+    assert excess[i] <= 0, f"{what}: element {i}: got {a[i]:.6g}, want {ref[i]:.6g} (rtol {rtol:g}, atol {atol:g})"
+
+
+@pytest.mark.parametrize("name", golden_names("scan_"))
+def test_scan_golden_under_the_references_metric(oracle, name):
+    """every golden scan fixture: HIP vs the reference's PyTorch path (the fixture) and vs the f64 oracle, element-wise"""
+    g = load_golden(name)
+    itype = itype_of(g)
+    got, want = run_scan(g, itype, oracle)
+    tols = ref_tolerances(itype, "z" in g, g["B"].ndim >= 3, g["C"].ndim >= 3)
+    for k, (rtol, atol) in tols.items():
+        if want.get(k) is None:
+            continue
+        allclose_ref(got[k], g[k], rtol, atol, f"{name}:{k} vs golden")
+        allclose_ref(got[k], want[k], rtol, atol, f"{name}:{k} vs oracle")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 32, 16, 1040), (1, 64, 16, 2304), (2, 8, 16, 1569), (1, 6, 8, 3000), (2, 32, 16, 4096)])
+def test_scan_random_under_the_references_metric(oracle, shape, itype):
+    """random shapes over every kernel family (LDS forward + lane checkpoints, ragged, generic dstate 8, multi-chunk), inputs
+    drawn as the reference's test draws them (:53-88)"""
+    b, d, N, L = shape
+    rng = np.random.default_rng(b * 1000 + L)
+    g = dict(u=rng.standard_normal((b, d, L), dtype=np.float32), delta=0.5 * rng.random((b, d, L), dtype=np.float32),
+             A=-0.5 * rng.random((d, N), dtype=np.float32), B=rng.standard_normal((b, 1, N, L), dtype=np.float32),
+             C=rng.standard_normal((b, 1, N, L), dtype=np.float32), D=rng.standard_normal(d, dtype=np.float32),
+             z=rng.standard_normal((b, d, L), dtype=np.float32), delta_bias=0.5 * rng.random(d, dtype=np.float32),
+             g=rng.standard_normal((b, d, L), dtype=np.float32), softplus=True)
+    if itype != torch.float32:   # the upstream gradient as the kernel sees it
+        g["g"] = torch.tensor(g["g"]).to(itype).float().numpy()
+    got, want = run_scan(g, itype, oracle)
+    for k, (rtol, atol) in ref_tolerances(itype, True).items():
+        allclose_ref(got[k], want[k], rtol, atol, f"{shape} {itype}: {k} vs oracle")
+
+
+# ---- 2. the two checkpoint layouts at the benchmark's size ------------------------------------------------------------
+def _headline_inputs(b=8, d=1024, L=8192, N=16, itype=torch.bfloat16, seed=0):
+    torch.manual_seed(seed)
+    xz = torch.randn(b, 2 * d, L, device=DEV).to(itype)
+    u, z = xz[:, :d], xz[:, d:]
+    delta = (0.5 * torch.rand(d, b, L, device=DEV)).to(itype).permute(1, 0, 2)     # d-slowest, as the block produces it
+    A = -0.5 * torch.rand(d, N, device=DEV) - 0.02
+    B = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    C = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    dout = torch.randn(d, b, L, device=DEV).to(itype).permute(1, 0, 2)
+    return u, delta, A, B, C, D, z, bias, dout
+
+
+def _x_full(x):
+    """the whole checkpoint allocation behind the reference-shaped (b, d, n_chunks, 2N) view"""
+    b, d, nc, _ = x.shape
+    return x.as_strided((b, d, nc, x.stride(2)), x.stride())
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_lane_checkpoints_full_size_tripwire(monkeypatch, reverse):
+    import selective_scan_cuda as ssc
+    import vms_hip
+    u, delta, A, B, C, D, z, bias, dout = _headline_inputs()
+    b, d, L = u.shape
+    N = 16
+    res = {}
+    for layout in (3, 1):
+        if layout == 1:
+            monkeypatch.setenv("VMS_X_LAYOUT", "1")
+        out, x, out_z = ssc.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
+        assert vms_hip.x_layout_of(x, N) == layout
+        dz = torch.empty_like(z)
+        g = ssc.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, dz, True, False, reverse=reverse, keep_fp32=True)
+        assert vms_hip.last_kernel() == "scan_bwd_pair4"
+        torch.cuda.synchronize()
+        res[layout] = (out, out_z, x, g)
+    (out3, oz3, x3, g3), (out1, oz1, x1, g1) = res[3], res[1]
+    # the forward's outputs do not depend on what it leaves for the backward
+    assert torch.equal(out3, out1) and torch.equal(oz3, oz1)
+    assert torch.equal(x3, x1)                                  # the reference-shaped slots (last_state, 1024-element states)
+    # every 16th 8-element checkpoint == the 128-element checkpoint, for ALL (batch, row, chunk, state): bit for bit
+    f3, f1 = _x_full(x3), _x_full(x1)
+    nc = x3.shape[2]
+    lane = f3[..., 2 * N:2 * N + 4 * 256 * 4].reshape(b, d, nc, 4, 256, 4)          # [n / 4][i][n % 4], i = 8-element index
+    sub = f1[..., 2 * N:2 * N + 16 * N].reshape(b, d, nc, 16, N)                     # [s][n], s = 128-element index
+    lane16 = lane[:, :, :, :, 15::16, :].permute(0, 1, 2, 4, 3, 5).reshape(b, d, nc, 16, N)
+    valid = torch.ones(nc, 16, dtype=torch.bool, device=DEV)
+    for c in range(nc):
+        for s in range(16):
+            valid[c, s] = c * 2048 + 128 * (s + 1) <= L
+    a, r = lane16[:, :, valid], sub[:, :, valid]
+    # The two are the same state reached by two fp32 routes -- the lane's running recurrence (8-element checkpoints) and the
+    # lane aggregate applied to the state entering the lane (128-element ones): equal to a few ulp, never bit for bit.  The
+    # hazard this guards against replaces values (3-8 per 65 K before the fix): 2e-5 of the element (or of 1e-2 of the states'
+    # scale for small ones, where the two routes' terms cancel) over ALL 8.4 M values separates the two cleanly.
+    scale = r.abs().max()
+    bad = (a - r).abs() > 2e-5 * torch.maximum(r.abs(), 1e-2 * scale)
+    assert not bad.any(), f"{int(bad.sum())} of {a.numel()} lane checkpoints differ from the 128-element ones; first: " \
+                          f"{a[bad][:4].tolist()} vs {r[bad][:4].tolist()}"
+    assert (a == r).float().mean().item() > 0.2    # and a good part of them IS identical
+    # and nothing the checkpoints hold is garbage: finite, bounded by the states' scale
+    assert torch.isfinite(lane).all()
+    # the nine backward results of the two layouts, element by element: the seeds differ in how they were accumulated (stored
+    # 8-element states vs states rebuilt from the 128-element ones), which moves a bf16 result by an ulp at most now and then
+    names = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz"]
+    for k, name in enumerate(names):
+        a, r = g3[k].float(), g1[k].float()
+        scale = r.abs().max().item()
+        if name in ("du", "ddelta", "dz"):      # bf16: within 2 ulp of the element, or 1e-4 of the tensor's scale for tiny ones
+            excess = (a - r).abs() - (2.0 ** -7 * r.abs() + 1e-4 * scale)
+            assert excess.max().item() <= 0, f"{name}: {int((excess > 0).sum())} elements apart (worst {excess.max().item():.3e})"
+            assert ((a != r).float().mean().item()) < 2e-2, f"{name}: too many elements differ at all"
+        else:                                   # fp32 sums: 1e-4 of the tensor's scale over the whole tensor
+            assert (a - r).abs().max().item() <= 1e-4 * scale, f"{name}: {(a - r).abs().max().item() / scale:.3e}"
+
+
+# ---- 3. parameter gradients at the benchmark's size ---------------------------------------------------------------------
+def test_parameter_gradients_full_size(oracle):
+    """dB, dC of one whole batch entry (sums over all 1024 rows) and that entry's dA / dD / ddelta_bias against the f64 oracle;
+    the full launch's batch sums against the per-entry launches (the benchmark's kernel: scan_bwd_pair4 with lane checkpoints)"""
+    import selective_scan_cuda as ssc
+    import vms_hip
+    u, delta, A, B, C, D, z, bias, dout = _headline_inputs(seed=1)
+    b, d, L = u.shape
+
+    def run(sl):
+        args = (u[sl], delta[sl], A, B[sl], C[sl], D, z[sl], bias)
+        out, x, _ = ssc.fwd(*args, True)
+        g = ssc.bwd(*args, dout[sl], x, out, torch.empty_like(z[sl]), True, False, keep_fp32=True)
+        assert vms_hip.last_kernel().startswith("scan_bwd_pair4") and vms_hip.x_layout_of(x, 16) == 3
+        return g
+    full = run(slice(0, b))
+    per = [run(slice(i, i + 1)) for i in range(b)]
+    # batch sums == sum of the entries' (same kernel, one entry per launch): fp32 atomics in another order
+    for k, name in ((2, "dA"), (5, "dD"), (6, "ddelta_bias")):
+        want = sum(p[k].double() for p in per)
+        assert (full[k].double() - want).abs().max().item() <= 1e-4 * want.abs().max().item(), name
+    for k, name in ((3, "dB"), (4, "dC")):
+        want = torch.cat([p[k] for p in per])
+        assert (full[k] - want).abs().max().item() <= 1e-4 * want.abs().max().item(), name
+    # one whole entry through the oracle (1024 rows x 8192 positions x 16 states, f64)
+    e = b - 1
+    f = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())
+    sl = slice(e, e + 1)
+    ob = oracle.scan_bwd(f(u[sl]), f(delta[sl]), f(A), f(B[sl]), f(C[sl]), f(D), f(z[sl]), f(bias), f(dout[sl]), True, prec="f64")
+    bf = 1e-2
+    check(per[e][3], ob["dB"], 2 * bf, "dB of a whole entry vs oracle")
+    check(per[e][4], ob["dC"], 2 * bf, "dC of a whole entry vs oracle")
+    check(per[e][2], ob["dA"], 5 * bf, "dA of one entry vs oracle")
+    check(per[e][5], ob["dD"], 5 * bf, "dD of one entry vs oracle")
+    check(per[e][6], ob["ddelta_bias"], 5 * bf, "ddelta_bias of one entry vs oracle")
+    # per ROW and per state, not only relative to the tensor's largest entry: dA rows against their own scale
+    dA, want = per[e][2].double().cpu().numpy(), ob["dA"]
+    row_scale = np.abs(want).max(axis=1, keepdims=True)
+    assert (np.abs(dA - want) / np.maximum(row_scale, 1e-3 * np.abs(want).max())).max() <= 5 * bf

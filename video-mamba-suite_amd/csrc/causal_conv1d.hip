@@ -183,7 +183,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const vms_conv_f
             float acc = bias;
 #pragma unroll
             for (int k = 0; k < kTaps; ++k) acc = fmaf(taps[k], xv[s][i + k], acc);
-            o[i] = SILU ? acc * sigmoidf_(acc) : acc;
+            // the fp32 result is final BEFORE it is narrowed: left to itself hipcc folds the last fma into an fp16 conversion
+            // (v_fma_mixlo_f16: one rounding instead of two) in one kernel and not in another -- conv_fwd_dual_kernel must give
+            // this kernel's bits for every dtype (vms_hip.h)
+            float r = SILU ? acc * sigmoidf_(acc) : acc;
+            asm volatile("" : "+v"(r));
+            o[i] = r;
         }
         out.store(base + s * 64 * E, o);
     }
@@ -255,8 +260,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_dual_kernel(const vms_c
                 acc = fmaf(taps[k], xv[s][i + k], acc);
                 acc_b = fmaf(taps_b[k], xv[s][i + 6 - k], acc_b);
             }
-            o[i] = SILU ? acc * sigmoidf_(acc) : acc;
-            ob[i] = SILU ? acc_b * sigmoidf_(acc_b) : acc_b;
+            float r = SILU ? acc * sigmoidf_(acc) : acc, rb = SILU ? acc_b * sigmoidf_(acc_b) : acc_b;
+            asm volatile("" : "+v"(r), "+v"(rb));   // as conv_fwd_kernel: narrowed from the rounded fp32 value
+            o[i] = r;
+            ob[i] = rb;
         }
         out.store(base + s * 64 * E, o);
         out_b.store(base + s * 64 * E, ob);

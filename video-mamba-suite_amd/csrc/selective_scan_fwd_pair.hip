@@ -689,7 +689,10 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_car
 }
 
 // ranges a forward is split into (1 = not split): only when the rows do not give every SIMD a wave (4 SIMDs per CU);
-// aims at ~2.5 waves per SIMD, at least 4 chunks (4096 elements) per range; p.segments >= 1 forces a count (vms_hip.h)
+// aims at ~12 waves per SIMD = three rounds of the 4 resident ones (round 4, profiles/r04_seg_sweep.txt: (1, 768, 65536) 535 us
+// with the 4 ranges the earlier 2.5-waves rule gave, 492 / 453 / 464 / 446 us with 6 / 8 / 12 / 16: the carry pass costs the
+// same whatever the count, the main pass needs the occupancy the kernel was built for), at least 4 chunks (4096 elements)
+// per range; p.segments >= 1 forces a count (vms_hip.h)
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
     if (p.seqlen % kPK != 0) return 1;
     const int n_k = (p.seqlen + kWave * kPK - 1) / (kWave * kPK);
@@ -699,7 +702,7 @@ int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
     if (p.segments >= 1) {
         want = p.segments;
     } else if (waves <= simds) {
-        want = (int)((simds * 5 / 2 + waves - 1) / waves);
+        want = (int)((simds * 12 + waves - 1) / waves);
         if (want > n_k / 4) want = n_k / 4;
     }
     if (want > 16) want = 16;
