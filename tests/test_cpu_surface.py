@@ -361,3 +361,35 @@ def test_compiled_binding_speaks_the_packages_abi():
     assert ext is not None and ext.abi_version() == vms_hip.ABI_VERSION
     for fn in ("scan_fwd", "scan_bwd", "scan_bwd_dual", "inner_fwd", "inner_bwd", "inner_bwd_dual", "conv_fwd_dual"):
         assert hasattr(ext, fn), fn
+
+
+def test_checkpoint_layout_policy(monkeypatch):
+    """vms_hip.x_mode_for_shape: which checkpoints a forward leaves (the 8-element layout -- 8 B D L bytes per scan --
+    must not be unconditional).  Environment > per-thread context (the modules' scan_checkpoints=) > process default; "auto" on a
+    CPU tensor cannot look at device memory and lets the library choose."""
+    monkeypatch.delenv("VMS_X_LAYOUT", raising=False)
+    shp = (8, 1024, 8192, 16, "cpu")
+    assert vms_hip.current_x_layout_policy() == "auto"
+    assert vms_hip.x_mode_for_shape(*shp, for_backward=False) == 1          # inference: the small layout, whatever the policy
+    assert vms_hip.x_mode_for_shape(*shp) == -1
+    with vms_hip.x_layout_policy("coarse"):
+        assert vms_hip.x_mode_for_shape(*shp) == 1
+        with vms_hip.x_layout_policy(None):                                  # None = no opinion: the enclosing one stays
+            assert vms_hip.x_mode_for_shape(*shp) == 1
+        monkeypatch.setenv("VMS_X_LAYOUT", "3")
+        assert vms_hip.x_mode_for_shape(*shp) == -1                          # the environment wins
+        monkeypatch.delenv("VMS_X_LAYOUT")
+    assert vms_hip.current_x_layout_policy() == "auto"
+    vms_hip.set_x_layout_policy("coarse")
+    try:
+        assert vms_hip.x_mode_for_shape(*shp) == 1
+        with vms_hip.x_layout_policy("fine"):
+            assert vms_hip.x_mode_for_shape(*shp) == -1
+    finally:
+        vms_hip.set_x_layout_policy("auto")
+    monkeypatch.setenv("VMS_X_LAYOUT", "1")
+    assert vms_hip.x_mode_for_shape(*shp) == 1
+    from mamba_ssm.modules.mamba_simple import Mamba
+    from mamba_ssm.modules.mamba_new import Mamba as DBM
+    assert Mamba(32, expand=1, bimamba_type="v2", scan_checkpoints="coarse").scan_checkpoints == "coarse"
+    assert DBM(32, expand=1).scan_checkpoints is None

@@ -196,3 +196,53 @@ def test_parameter_gradients_full_size(oracle):
     dA, want = per[e][2].double().cpu().numpy(), ob["dA"]
     row_scale = np.abs(want).max(axis=1, keepdims=True)
     assert (np.abs(dA - want) / np.maximum(row_scale, 1e-3 * np.abs(want).max())).max() <= 5 * bf
+
+
+# ---- 4. complex A at a block-sized shape (parity existed at small shapes only) ------------------------------------
+@pytest.mark.parametrize("groups", [1, 2])
+def test_complex_scan_large_shape(oracle, groups):
+    """(2, 256, 8 complex states, 4096): 64 KB dB / dC slab, 8-wave barriers, the 512-element checkpoints across two 2048-element
+    chunks; groups = 2 makes half of the 8-row workgroups straddle nothing and keeps both group branches in play (256 / 2 = 128
+    rows per group: whole workgroups) -- against the f64 oracle."""
+    from test_hip_parity import ccheck, run_cscan
+    b, d, N, L = 2, 256, 8, 4096
+    rng = np.random.default_rng(7)
+    f = lambda *s: rng.standard_normal(s, dtype=np.float32)
+    g = dict(u=f(b, d, L), delta=0.5 * rng.random((b, d, L), dtype=np.float32),
+             A=(-0.5 * rng.random((d, N), dtype=np.float32) + 1j * (0.5 * rng.random((d, N), dtype=np.float32))).astype(np.complex64),
+             B=f(b, groups, N, 2 * L), C=f(b, groups, N, 2 * L), D=f(d), z=f(b, d, L), delta_bias=0.5 * rng.random(d, dtype=np.float32),
+             g=f(b, d, L), softplus=True)
+    itype = torch.bfloat16
+    g["g"] = torch.tensor(g["g"]).to(itype).float().numpy()
+    got, want = run_cscan(g, itype, oracle)
+    ccheck(got, want, itype, "oracle", f"complex (2, 256, 8, 4096) groups {groups}")
+
+
+# ---- 5. the checkpoint policy through the module surface ----------------------------------------------------------------------
+def test_module_scan_checkpoints_argument(monkeypatch):
+    """Mamba(..., scan_checkpoints="coarse" | "fine"): the 128-element / 8-element checkpoint layouts give the same gradients; the
+    saved checkpoint tensors differ 16-fold in size (what the argument is for)."""
+    import vms_hip
+    from mamba_ssm.modules.mamba_simple import Mamba
+    monkeypatch.delenv("VMS_X_LAYOUT", raising=False)
+    torch.manual_seed(0)
+    x = torch.randn(2, 1040, 256, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    g = torch.randn_like(x)
+    grads, sizes = {}, {}
+    for pol in ("coarse", "fine", None):
+        torch.manual_seed(1)
+        m = Mamba(256, expand=1, bimamba_type="v2", scan_checkpoints=pol).to(DEV)
+        x.grad = None
+        saved = []
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t.numel() * t.element_size()) or t), lambda t: t):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m(x)
+        y.backward(g)
+        grads[pol] = [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
+        sizes[pol] = sum(saved)
+    for a, r in zip(grads["coarse"], grads["fine"]):
+        check(a, r, 2e-2, "coarse vs fine checkpoints")
+    ck = 2 * 2 * 256 * 1040 * 8                       # two directions x (8 B D L bytes of 8-element checkpoints)
+    assert sizes["fine"] - sizes["coarse"] > 0.8 * ck, sizes
+    assert sizes[None] == sizes["fine"]               # "auto" on an almost empty device: the fast layout
+    assert vms_hip.current_x_layout_policy() == "auto"

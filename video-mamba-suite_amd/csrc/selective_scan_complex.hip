@@ -523,11 +523,20 @@ int launch_cbwd(const vms_scan_bwd_params& q, bool vec, hipStream_t stream) {
     dim3 grid(p.batch * tiles), block(kCBRows * kWave);
     static_assert(kCBRows * kWave == kCCS, "the slab flush maps one thread to one position of a chunk");
     const size_t smem = sizeof(float) * (2 * kCBRows * kCK * kWave * 2 + kCBRows * 10 * p.dstate);   // 64 KB slab + per-wave state arrays
-    // more than 64 KB of dynamic LDS needs the attribute on each device the kernel runs on (cheap; this is not a hot path)
-    const void* fn = vec ? reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, true>)
-                         : reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    // more than 64 KB of dynamic LDS needs the attribute on each device the kernel runs on: set once per (instantiation, device)
+    // to what the largest dstate (256, validate_scan_common) can ask for, like the real-A kernels (vms_hip.h "Conventions")
+    static PerDeviceOnce attr_once;
+    const hipError_t arc = attr_once.run([&]() -> hipError_t {
+        const int smem_max = (int)(sizeof(float) * (2 * kCBRows * kCK * kWave * 2 + kCBRows * 10 * 256));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cscan_bwd_kernel<T, VB, VC, HZ, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
+        return e;
+    });
+    if (arc != hipSuccess) {
+        set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(arc));
         return VMS_ERR_LAUNCH;
     }
     if (vec)

@@ -63,8 +63,12 @@ class InProjFn(torch.autograd.Function):
         x2 = hidden.reshape(batch * seqlen, d_model)
         if stack_halves:
             assert channels % 2 == 0
-        if hidden.is_cuda:
-            dt = _autocast_dtype() or weight.dtype
+        dt = (_autocast_dtype() or weight.dtype) if hidden.is_cuda else weight.dtype
+        # the K-contiguous copy of the weight pays when a copy is made anyway -- autocast's cast, or the block's prepared one;
+        # an fp32 (or already low-precision) weight outside autocast keeps the parameter itself: no copy kernel, no weight-sized
+        # saved tensor, autograd's version check on the parameter intact
+        transposed = hidden.is_cuda and (wt_prepared is not None or dt != weight.dtype)
+        if transposed:
             if wt_prepared is not None:
                 assert not stack_halves and wt_prepared.dtype == dt and tuple(wt_prepared.shape) == (d_model, channels)
                 wt = wt_prepared
@@ -80,9 +84,11 @@ class InProjFn(torch.autograd.Function):
             if x2.dtype != dt:
                 x2 = x2.to(dt)
             prod = wt.t() @ x2.t()                               # (channels, B L)
-        else:  # CPU (tests with checker-backed extensions): the plain formulation
+        else:  # the plain formulation (also the CPU one, for the tests with checker-backed extensions)
             wt = weight
             w = _interleave_halves(weight, 0).reshape(channels, d_model) if stack_halves else weight
+            if x2.dtype != w.dtype:
+                x2 = x2.to(w.dtype)
             prod = w @ x2.t()
         if bias is not None:
             b = _interleave_halves(bias, 0).reshape(channels) if stack_halves else bias
@@ -92,7 +98,7 @@ class InProjFn(torch.autograd.Function):
         else:
             xz = prod.view(channels, batch, seqlen).permute(1, 0, 2)
         ctx.save_for_backward(hidden, wt)
-        ctx.transposed = hidden.is_cuda
+        ctx.transposed = transposed
         ctx.w_dtype = weight.dtype   # the K-split partial sums are added in the PARAMETER's dtype: no cast kernel in autograd
         ctx.stack_halves = stack_halves
         ctx.has_bias = bias is not None
@@ -116,9 +122,11 @@ class InProjFn(torch.autograd.Function):
                 dhidden = (g2.to(wt.dtype).t() @ wt.t()).view(batch, seqlen, d_model).to(hidden.dtype)
             else:
                 w = _interleave_halves(wt, 0).reshape(channels, d_model) if ctx.stack_halves else wt
-                dhidden = (g2.t() @ w).view(batch, seqlen, d_model)
+                dhidden = (g2.to(w.dtype).t() @ w).view(batch, seqlen, d_model).to(hidden.dtype)
         if ctx.needs_input_grad[1]:
             s = _k_splits(rows)
+            if x2.dtype != g2.dtype:
+                x2 = x2.to(g2.dtype)
             dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model))
                               .sum(0, dtype=ctx.w_dtype))
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -184,9 +184,12 @@ def _for_backward(ctx):
     return getattr(ctx, "for_backward", True) if nig is None else any(nig)
 
 
-def _x_flags(ctx):
-    """inner_fwd proj_flags bits 4 / 8: no backward / VMS_X_LAYOUT=1 (keep the 128-element checkpoints)."""
-    return (0 if _for_backward(ctx) else 4) | (8 if os.environ.get("VMS_X_LAYOUT") == "1" else 0)
+def _x_flags(ctx, xz, d_state):
+    """inner_fwd proj_flags bits 4 / 8: no backward / keep the 128-element checkpoints (the checkpoint policy of
+    vms_hip.x_mode_for_shape: VMS_X_LAYOUT, set_x_layout_policy, the modules' scan_checkpoints=, or memory-aware "auto")."""
+    fb = _for_backward(ctx)
+    coarse = fb and _vms.x_mode_for_shape(xz.shape[0], xz.shape[1] // 2, xz.shape[2], d_state, xz.device) == 1
+    return (0 if fb else 4) | (8 if coarse else 0)
 
 
 def _autocast_weights(*ws):
@@ -297,7 +300,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous() if D is not None else None
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
-            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx),
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx, xz, d_state),
             conv_out, x_dbl)
         ctx.reverse_from = int(reverse_from)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
@@ -700,8 +703,11 @@ def mamba_inner_fn(
         # complex A (tested by the reference, tests/ops/test_selective_scan.py:152-250; no suite model has one): the node as
         # the composition of the differentiable HIP ops -- conv1d, the projections, the complex scan -- instead of the
         # one-call node built for the real case
-        return mamba_inner_ref(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
-                               out_proj_bias, A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)
+        # (not mamba_inner_ref: like the reference's, it hard-wires delta_softplus=True, SSI:669 -- MambaInnerFn honours the flag)
+        x, z, delta, B, C = _inner_ref_scan_inputs(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, B, C,
+                                                   B_proj_bias, C_proj_bias)
+        y = selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
+        return F.linear(y.transpose(1, 2), out_proj_weight, out_proj_bias)
     return MambaInnerFn.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               out_proj_weight, out_proj_bias,
                               A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus)

@@ -108,7 +108,7 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
             B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         return ext.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, bool(delta_softplus), bool(reverse), out_z_into,
                             bc_pad, impl, _k.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from),
-                            _k.x_mode_from_env() if for_backward else 1)
+                            _k.x_mode_for(u, A.shape[1], for_backward))
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)  # inherits delta's (d-slowest) layout, selective_scan.cpp:310-311

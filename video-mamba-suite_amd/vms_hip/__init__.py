@@ -354,11 +354,77 @@ def dtype_code(t):
         raise RuntimeError(f"unsupported dtype {t.dtype}: expected float32, float16 or bfloat16") from None
 
 
+# ---- which checkpoints a forward leaves for its backward (vms_hip.h x_has_sub) ----------------------------------------------
+# "fine"   = the state after every 8 elements (x_has_sub == 3): 8 * batch * dim * seqlen BYTES per scan at d_state 16 -- as much
+#            again as the scan's own saved activations (537 MB per direction at (8, 1024, 8192), the reference's x is 4 MB) --
+#            for a backward scan ~10 % faster;
+# "coarse" = the state after every 128 elements (x_has_sub == 1, 1/16 of that);
+# "auto"   (default) = fine while the device has room to spare, coarse otherwise: fine only if, on the tensors' device, no more
+#            than a quarter of the memory is allocated and this scan's fine checkpoints take under 1/8 of what is unallocated.
+#            A stack that fits with the coarse layout in under ~7/8 of the device's memory therefore still fits; training runs
+#            sized closer to the limit than that should pin "coarse".
+# VMS_X_LAYOUT = 1 | 3 (environment) overrides everything; set_x_layout_policy() sets the process default; the
+# x_layout_policy(...) context (what the Mamba modules' `scan_checkpoints=` argument uses) overrides it per thread.
+import threading
+
+_x_policy = "auto"
+_x_tls = threading.local()
+_total_mem = {}
+_POLICIES = {"auto": "auto", "fine": "fine", "3": "fine", "coarse": "coarse", "1": "coarse"}
+
+
+def set_x_layout_policy(policy):
+    global _x_policy
+    _x_policy = _POLICIES[str(policy)]
+
+
+class x_layout_policy:
+    def __init__(self, policy):
+        self.policy = None if policy is None else _POLICIES[str(policy)]
+
+    def __enter__(self):
+        self.prev = getattr(_x_tls, "policy", None)
+        if self.policy is not None:
+            _x_tls.policy = self.policy
+
+    def __exit__(self, *exc):
+        _x_tls.policy = self.prev
+
+
+def current_x_layout_policy():
+    env = os.environ.get("VMS_X_LAYOUT")
+    if env in _POLICIES:
+        return _POLICIES[env]
+    return getattr(_x_tls, "policy", None) or _x_policy
+
+
+def x_mode_for_shape(batch, dim, seqlen, dstate, device, for_backward=True):
+    """-> the `mode` argument of vms_scan_x_pitch: 1 = the 128-element checkpoints, -1 = the 8-element ones where the backward
+    kernel that reads them takes the problem (the library decides that part)."""
+    if not for_backward:
+        return 1
+    pol = current_x_layout_policy()
+    if pol != "auto":
+        return 1 if pol == "coarse" else -1
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        return -1
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    total = _total_mem.get(idx)
+    if total is None:
+        total = _total_mem[idx] = torch.cuda.get_device_properties(idx).total_memory
+    need = batch * dim * (seqlen // 8) * dstate * 4
+    used = torch.cuda.memory_allocated(idx)
+    return -1 if (4 * used <= total and 8 * need <= total - used) else 1
+
+
+def x_mode_for(u, dstate, for_backward=True):
+    return x_mode_for_shape(u.shape[0], u.shape[1], u.shape[2], dstate, u.device, for_backward)
+
+
 def x_mode_from_env():
-    """vms_scan_x_pitch mode of a forward whose backward will run: VMS_X_LAYOUT=1 keeps the 128-element sub-checkpoints
-    (16x less checkpoint memory, backward scan ~10 % slower); default: the library's choice (8-element checkpoints when
-    the backward kernel that uses them takes the problem)."""
-    return 1 if os.environ.get("VMS_X_LAYOUT") == "1" else -1
+    """(kept for tools) the mode the policy gives without a size: VMS_X_LAYOUT=1 -> 1, else the library's choice"""
+    return 1 if current_x_layout_policy() == "coarse" else -1
 
 
 def x_layout_of(x, dstate):
@@ -459,7 +525,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
         else:
             # the reference-shaped tensor is a view of a wider buffer whose tail carries 128-element
             # sub-checkpoints for the backward kernel (include/vms_hip.h)
-            pitch = lib().vms_scan_x_pitch(ctypes.byref(P), x_mode_from_env() if for_backward else 1)
+            pitch = lib().vms_scan_x_pitch(ctypes.byref(P), x_mode_for(u, dstate, for_backward))
             x = torch.empty(batch, dim, n_chunks, pitch, device=u.device, dtype=torch.float32)[..., :dstate * 2]
             P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
             P.x_has_sub = x_layout_of(x, dstate)
