@@ -195,7 +195,8 @@ int vms_selective_scan_bwd(const vms_scan_bwd_params *p, void *stream);
  * Result = vms_selective_scan_bwd(a) followed by vms_selective_scan_bwd(b) with b's dz ADDED to a's: every gradient of a and
  * of b in its own tensors, the gradient z receives through both directions in a->dz (b->dz: NULL or the same tensor;
  * a->dz_accumulate as usual).  When the pair qualifies -- a left-to-right, b right-to-left, the same z and dout, equal
- * sizes / dtype / checkpoint layout, whole-vector rows, together at least one workgroup per CU, no forced split -- it is
+ * sizes / dtype / checkpoint layout, whole-vector rows, together at least one workgroup per CU, no forced split, a->dz_accumulate
+ * == 0 -- it is
  * ONE grid: a's workgroups write dz = dout (out_a + out_b) dsilu(z) (linear in the pre-gate outputs; rounded once, where
  * the two-call form rounds the first direction's part to `dtype` before adding the second's), b's none; otherwise the two calls run
  * back to back.  A direction of the suite's most common shape, (8, 768, 3136), is 192 workgroups for 256 CUs; both

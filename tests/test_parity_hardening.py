@@ -233,13 +233,17 @@ def test_module_scan_checkpoints_argument(monkeypatch):
         torch.manual_seed(1)
         m = Mamba(256, expand=1, bimamba_type="v2", scan_checkpoints=pol).to(DEV)
         x.grad = None
-        saved = []
-        with torch.autograd.graph.saved_tensors_hooks(lambda t: (saved.append(t.numel() * t.element_size()) or t), lambda t: t):
+        saved = {}   # storage -> bytes: the checkpoints are saved as the reference-shaped VIEW of their (16x larger) allocation
+
+        def pack(t):
+            saved[t.untyped_storage().data_ptr()] = t.untyped_storage().nbytes()
+            return t
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 y = m(x)
         y.backward(g)
         grads[pol] = [x.grad.clone()] + [p.grad.clone() for p in m.parameters()]
-        sizes[pol] = sum(saved)
+        sizes[pol] = sum(saved.values())
     for a, r in zip(grads["coarse"], grads["fine"]):
         check(a, r, 2e-2, "coarse vs fine checkpoints")
     ck = 2 * 2 * 256 * 1040 * 8                       # two directions x (8 B D L bytes of 8-element checkpoints)

@@ -733,7 +733,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             pz.load_stream(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl, v);
             if (DZM != 2 || out_z_b) pout.load_stream(outp_b, VMS_OFF(p.out_batch_stride, p.out_d_stride) + pl, v);
             if (DZM == 1) pout2.load_stream(out2_b, VMS_OFF(out2_batch_stride, out2_d_stride) + pl, v);
-            if (DZM != 2 && q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
+            if (DZM == 0 && q.dz_accumulate) pdzo.load_stream(dz_b, VMS_OFF(q.dz_batch_stride, q.dz_d_stride) + pl, v);
         }
         if constexpr (!XL) {
             const int e128 = cc * (CH / 128) - 1;
@@ -809,7 +809,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                     dy[i] *= silu;
                     if (DZM != 2 || out_z_b) ov[i] *= silu;
                 }
-                if (DZM != 2 && q.dz_accumulate) {  // dz += (vms_hip.h)
+                if (DZM == 0 && q.dz_accumulate) {  // dz += (vms_hip.h); the one-grid form of both directions writes a fresh dz
 #pragma unroll
                     for (int i = 0; i < K; ++i) dzv[i] += pdzo.at(i);
                 }
@@ -1393,7 +1393,7 @@ bool scan_bwd_pair_dual_fusable(const vms_scan_bwd_params& a, const vms_scan_bwd
     if (pa.seqlen % kBK != 0 || pa.segments > 1 || pb.segments > 1) return false;
     if (!pa.z || pa.z != pb.z || pa.z_batch_stride != pb.z_batch_stride || pa.z_d_stride != pb.z_d_stride) return false;
     if (a.dout != b.dout || a.dout_batch_stride != b.dout_batch_stride || a.dout_d_stride != b.dout_d_stride) return false;
-    if (!a.dz || !pa.out || !pb.out || pa.out == pb.out) return false;
+    if (!a.dz || a.dz_accumulate || !pa.out || !pb.out || pa.out == pb.out) return false;
     if (!scan_bwd_pair_eligible(a, true) || !scan_bwd_pair_eligible(b, true)) return false;
     auto xl = [](const vms_scan_fwd_params& p) {
         return p.x_has_sub == 3 && (int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
