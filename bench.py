@@ -50,19 +50,23 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # inner node's small parameters and in_proj's weight gradient (8 MB) follow in the last.  (32 MB, the earlier setting, put the
 # block's ~14 MB into ONE bucket: the all-reduce started after the last gradient -- VERDICT r3.)  VMS_DDP_BUCKET_MB overrides.
 DDP_BUCKET_MB = 4
-# HBM bytes per launch from the PMC passes of the same kernels at the same size (FETCH_SIZE x2 + WRITE_SIZE,
-# separate rocprofv3 --pmc runs, tools/traffic.py); a profile of the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r03z2_traffic.json")
-TRAFFIC_FALLBACK = os.path.join(ROOT, "profiles", "r02_traffic.json")
+# HBM bytes per call from the PMC passes of the same kernels at the config's size (FETCH_SIZE x2 + WRITE_SIZE, separate
+# rocprofv3 --pmc runs, main and carry kernels added up per entry point: tools/measure_cfg.sh, tools/pmc_table.py); a profile of
+# the committed build, not a live measurement
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_{config}_traffic.json")
 
 
-def profiled_traffic(kernel):
-    for path in (TRAFFIC_PROFILE, TRAFFIC_FALLBACK):
-        try:
-            with open(path) as f:
-                return json.load(f)[kernel]["hbm_bytes"], os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
-            continue
+def profiled_traffic(kernel, config="block"):
+    path = TRAFFIC_PROFILE.format(config=config)
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if kernel in t:
+            return t[kernel]["hbm_bytes"], os.path.relpath(path, ROOT)
+        if kernel == "vms_selective_scan_bwd_dual":   # a pair that ran as two launches (small grids): two single calls
+            return 2 * t["vms_selective_scan_bwd"]["hbm_bytes"], os.path.relpath(path, ROOT) + " (2 x the single call)"
+    except (OSError, KeyError, ValueError):
+        pass
     return None, None
 
 
@@ -519,9 +523,10 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         ms_per_step = elapsed / steps * 1e3
         tokens = world * b * l * steps
         d_inner = d_model * WORKLOADS[config][4]
-        # the DBM block scans its two halves in separate launches of d_inner channels each; every other config's scans
-        # cover (b, d_inner, l) per launch
-        ab = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l)
+        # the DBM block runs its two halves as ONE node on a batch of 2 b (vms_hip.h reverse_from) unless VMS_DBM_TWO_NODES=1;
+        # every other config's scans cover (b, d_inner, l) per launch
+        scan_b = 2 * b if config == "dbm" and os.environ.get("VMS_DBM_TWO_NODES") != "1" else b
+        ab = algorithmic_bytes(batch=scan_b, dim=d_inner, seqlen=l)
         kern = {}
         for name, ts in kernel_ms.items():
             avg = sum(ts) / len(ts)
@@ -532,7 +537,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             if name in ab:
                 kern[name]["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
-            vf = valu_floor_us(name, b, d_inner, l)
+            vf = valu_floor_us(name, scan_b, d_inner, l)
             if vf is not None:
                 kern[name]["valu_floor_us"] = vf
                 kern[name]["valu_frac"] = vf / (avg * 1e3)
@@ -570,7 +575,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         }
         if kern:
             dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
-            traffic, src = profiled_traffic(dom) if config == "block" else (None, None)
+            traffic, src = profiled_traffic(dom, config)
             res["roofline"] = {"kernel": dom, "bound": "hbm", "binding_resource": "valu" if "valu_frac" in kern[dom] else "hbm",
                                "valu_frac": kern[dom].get("valu_frac"), "achieved": kern[dom]["algorithmic_GBs"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
@@ -579,11 +584,11 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                                "algorithmic_bytes_per_launch": ab[dom], "avg_launch_ms": kern[dom]["avg_ms"]}
             if dom.startswith("vms_selective_scan") and res["config"]["x_layout"] == 3:
                 # the design's own extra traffic (8-element checkpoints, fp32): in `traffic`, not in `achieved`
-                res["roofline"]["checkpoint_bytes_per_launch"] = b * d_inner * (l // 8) * D_STATE * 4 * (2 if dom.endswith("_dual") else 1)
+                res["roofline"]["checkpoint_bytes_per_launch"] = scan_b * d_inner * (l // 8) * D_STATE * 4 * (2 if dom.endswith("_dual") else 1)
             if dom.endswith("_dual"):
                 res["roofline"]["launch"] = "one call = the backward scans of BOTH directions of the block (vms_selective_scan_bwd_dual)"
             if dom in ("vms_selective_scan_bwd", "vms_selective_scan_bwd_dual"):   # SURVEY 8d also counts an out_z rewrite (9 B D L s per direction) the blocks' nodes never ask for
-                ab8 = algorithmic_bytes(batch=b, dim=d_inner, seqlen=l, bwd_out_z=True)[dom]
+                ab8 = algorithmic_bytes(batch=scan_b, dim=d_inner, seqlen=l, bwd_out_z=True)[dom]
                 res["roofline"]["algorithmic_bytes_survey_8d"] = ab8
                 res["roofline"]["frac_survey_8d"] = ab8 / (kern[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         if on_gpu and world == 1 and projections and config == "block":

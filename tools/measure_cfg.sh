@@ -7,6 +7,7 @@
 tag=$1; shift
 if [ $# -eq 0 ]; then set -- stack long dbm; fi
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
+declare -A DUAL=( [block]=dual [stack]=dual [long]=dual [dbm]= )
 declare -A SHAPE=( [block]=8,1024,8192,16 [stack]=8,768,3136,16 [long]=1,768,65536,16 [dbm]=4,512,2304,16 )
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 B="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
@@ -14,19 +15,19 @@ D="GRBM_GUI_ACTIVE GRBM_COUNT"
 for cfg in "$@"; do
   cd $R
   python bench.py --config $cfg --no-cpu-baseline 2>/dev/null | tail -1 > $O/${cfg}_bench.json
-  KB_SHAPE=${SHAPE[$cfg]} python tools/kbench.py fwd bwd 2>&1 | grep -v amdgpu.ids > $O/${cfg}_kbench.txt
+  KB_SHAPE=${SHAPE[$cfg]} python tools/kbench.py fwd bwd ${DUAL[$cfg]} 2>&1 | grep -v amdgpu.ids > $O/${cfg}_kbench.txt
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $cfg --steps 10 --warmup 10 --no-projections --no-cpu-baseline > $O/${cfg}_prof.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $cfg --steps 10 --warmup 20 --no-projections --no-cpu-baseline > $O/${cfg}_prof.log 2>&1
   python $R/tools/prof_summary.py $O/prof/p_kernel_stats.csv 30 > $O/${cfg}_kernel_stats.md
   python $R/tools/step_trace.py $O/prof/p_kernel_trace.csv 10 > $O/${cfg}_step_trace.txt 2>/dev/null
   rm -rf $O/prof
   csvs=""
   for k in f:FETCH_SIZE w:WRITE_SIZE a:"$A" b:"$B" d:"$D"; do
     n=${k%%:*}; ctrs=${k#*:}
-    KB_SHAPE=${SHAPE[$cfg]} rocprofv3 --pmc $ctrs -d $O/pmc_${cfg}_$n -o p --output-format csv -- python $R/tools/kbench.py fwd bwd > $O/pmc_${cfg}_$n.log 2>&1 || tail -3 $O/pmc_${cfg}_$n.log
+    KB_SHAPE=${SHAPE[$cfg]} rocprofv3 --pmc $ctrs -d $O/pmc_${cfg}_$n -o p --output-format csv -- python $R/tools/kbench.py fwd bwd ${DUAL[$cfg]} > $O/pmc_${cfg}_$n.log 2>&1 || tail -3 $O/pmc_${cfg}_$n.log
     csvs="$csvs $O/pmc_${cfg}_$n/*counter_collection.csv"
   done
   python $R/tools/pmc_table.py --json $O/${cfg}_traffic.json $csvs > $O/${cfg}_pmc.md
   rm -rf $O/pmc_${cfg}_*
-  cut -c1-200 $O/${cfg}_bench.json; cat $O/${cfg}_kbench.txt; grep -E "^###|HBM traffic|VALU pipe|waves per SIMD" $O/${cfg}_pmc.md
+  cut -c1-200 $O/${cfg}_bench.json; cat $O/${cfg}_kbench.txt; grep -E "^###|HBM traffic|VALU pipe|waves per SIMD" $O/${cfg}_pmc.md; rm -f $O/${cfg}_prof.log
 done

@@ -12,12 +12,17 @@ import sys
 def short(name):
     m = re.search(r"vms::(\w+)", name)
     if not m:
-        return None
+        mm = re.search(r"_ZN3vms(\d+)", name)   # a name rocprofv3 left mangled
+        if not mm:
+            return None
+        n = int(mm.group(1))
+        rest = name[mm.end():]
+        return rest[:n] + "<" + rest[n:n + 24] + ">"
     k = m.group(1)
     t = re.search(r"<(.*)>", name)
     if t:
-        args = re.sub(r"__hip_bfloat16|hip_bfloat16", "bf16", t.group(1)).replace("(bool)", "").replace("(int)", "").replace(" ", "")
-        k += "<" + args[:40] + ">"
+        args = re.sub(r"__hip_bfloat16|hip_bfloat16|bool_Accum", "bf16", t.group(1).replace(" ", "")).replace("(bool)", "").replace("(int)", "")
+        k += "<" + args.split(">")[0][:40] + ">"
     return k
 
 
@@ -64,16 +69,33 @@ def main():
             print(f"* VALU wave-instructions per wave = {g('SQ_INSTS_VALU') / g('SQ_WAVES'):,.0f}")
             e["insts_valu"] = g("SQ_INSTS_VALU")
         if g("GRBM_GUI_ACTIVE"):
-            print(f"* GRBM_GUI_ACTIVE = {g('GRBM_GUI_ACTIVE'):,.0f} cycles per launch")
+            # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (checked against the kernel's duration: 12.04 M / 8 = 1.5 M
+            # cycles = 0.68 ms at 2.2 GHz for a 0.68 ms launch)
+            cyc = g("GRBM_GUI_ACTIVE") / 8.0
+            print(f"* GRBM_GUI_ACTIVE / 8 XCDs = {cyc:,.0f} cycles per launch")
+            e["gui_cycles"] = cyc
             if g("SQ_WAVE_CYCLES"):
-                print(f"* mean waves per SIMD while running = {4 * g('SQ_WAVE_CYCLES') / (1024 * g('GRBM_GUI_ACTIVE')):.2f}")
+                print(f"* mean waves per SIMD while running (4 x SQ_WAVE_CYCLES / 1024 SIMDs / cycles) = {4 * g('SQ_WAVE_CYCLES') / (1024 * cyc):.2f}")
             if g("SQ_ACTIVE_INST_VALU"):
-                print(f"* VALU pipe busy (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / GRBM_GUI_ACTIVE) = {4 * g('SQ_ACTIVE_INST_VALU') / (1024 * g('GRBM_GUI_ACTIVE')):.3f}")
+                print(f"* VALU pipe busy (4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs / cycles) = {4 * g('SQ_ACTIVE_INST_VALU') / (1024 * cyc):.3f}")
         print()
         if e:
             out[k] = e
     if jpath:
-        json.dump(out, open(jpath, "w"), indent=1, sort_keys=True)
+        # per C-ABI entry point: the kernels one call launches (main + carry), per-launch averages added up
+        entries = {}
+        for key, entry in (("scan_bwd_pair4_dual", "vms_selective_scan_bwd_dual"), ("scan_bwd", "vms_selective_scan_bwd"),
+                           ("scan_fwd", "vms_selective_scan_fwd")):
+            ks = [k for k in out if key in k and "hbm_bytes" in out[k] and not any(k in v["kernels"] for v in entries.values())]
+            if ks:
+                # template variants of one kernel (the two directions) are the same work: mean; different kernels of one call add up
+                bases = collections.defaultdict(list)
+                for k in ks:
+                    bases[k.split("<")[0]].append(out[k])
+                tot = lambda f: sum(sum(v[f] for v in vs) / len(vs) for vs in bases.values())
+                entries[entry] = {"hbm_bytes": tot("hbm_bytes"), "fetch_bytes": tot("fetch_bytes"), "write_bytes": tot("write_bytes"),
+                                  "kernels": ks}
+        json.dump(dict(entries, kernels=out), open(jpath, "w"), indent=1, sort_keys=True)
 
 
 main()
