@@ -603,7 +603,8 @@ template <int W> struct B4 {
 template <typename T, bool HZ, bool REV, int W, bool XL, int DZM = 0>
 __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry,
                                                     const int bid, const int nblk, const T* __restrict__ out2_b = nullptr,
-                                                    const int64_t out2_batch_stride = 0, const int64_t out2_d_stride = 0) {
+                                                    const int64_t out2_batch_stride = 0, const int64_t out2_d_stride = 0,
+                                                    const int sub_m = 1) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kBK, N = kBN, CH = kCH;
@@ -745,8 +746,10 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
     float g_in = 0.f, anx_in = 1.f;
     if (seg < n_seg - 1) {
-        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_seg) * N + j;
-        for (int s2 = n_seg - 1; s2 > seg; --s2) {
+        // the carry kernel leaves one (P, q) per SUB-range (sub_m per range, scan_bwd_carry_body): chain all of them to the right
+        const int n_tot = n_seg * sub_m;
+        const float2* cp = seg_carry + (((int64_t)b * p.dim + dc) * n_tot) * N + j;
+        for (int s2 = n_tot - 1; s2 >= (seg + 1) * sub_m; --s2) {
             const float2 pq = cp[(int64_t)s2 * N];
             g_in = fmaf(pq.x, g_in, pq.y);
         }
@@ -1040,14 +1043,15 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 // entry: the direction is workgroup-uniform, one branch selects the body.
 // XL: x carries the forward's 8-element checkpoints (x_has_sub == 3), < 2 GiB per batch entry (one buffer resource each)
 template <typename T, bool HZ, int RM, int W, bool XL>
-__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry) {
+__global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry,
+                                                                    const int sub_m) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
-        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
-        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
+        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
+        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
     } else {
-        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x);
+        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
     }
 }
 
@@ -1083,15 +1087,20 @@ __global__ __launch_bounds__(W* kWave) void scan_bwd_pair4_dual_kernel(const vms
 template <int CTRL>
 __device__ __forceinline__ float row_newbcast(float v) { return bdpp<0x150 + CTRL>(0.f, v); }
 
+// sub_m (round 4): every range is cut into sub_m SUB-ranges of chunks with a (P, q) each -- affine maps compose, so the carry
+// pass can be as parallel as the chip needs, whatever range count the main kernel's grid wants: at (1, 768, 65536) the 9 ranges x
+// 192 waves left this kernel at 1.5 waves per SIMD (79 VGPRs: 6 fit) and the vector ALUs 55 % busy (profiles/r04_long_pmc.md).
 template <typename T, bool HZ, bool REV>
-__device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q, const int n_seg, float2* __restrict__ seg_carry) {
+__device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q, const int n_seg, float2* __restrict__ seg_carry,
+                                                    const int sub_m) {
     const vms_scan_fwd_params& p = q.f;
     constexpr int K = kBK, N = kBN, CH = kCH;
     const int lane = threadIdx.x & 63;
     const int quad = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, r = lane >> 4;
-    const int wg_per_seg = gridDim.x / (n_seg - 1);
-    const int seg = 1 + blockIdx.x / wg_per_seg, wg = blockIdx.x % wg_per_seg;   // range 0 has nothing to its left
+    const int wg_per_sub = gridDim.x / ((n_seg - 1) * sub_m);
+    const int sub = sub_m + blockIdx.x / wg_per_sub, wg = blockIdx.x % wg_per_sub;   // range 0 has nothing to its left
+    const int seg = sub / sub_m, sub_k = sub - seg * sub_m;
     const int b = wg % p.batch;
     const int d0 = (wg / p.batch) * kBRows;
     const int d = d0 + quad * 4 + r;
@@ -1108,7 +1117,10 @@ __device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q
     const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride] * kLog2e;
     const int n_c = (L + CH - 1) / CH;
     const int cps = (n_c + n_seg - 1) / n_seg;
-    const int c_lo = seg * cps, c_hi = (c_lo + cps < n_c) ? c_lo + cps : n_c;
+    const int r_lo = seg * cps, r_hi = (r_lo + cps < n_c) ? r_lo + cps : n_c;         // the range, as the main kernel cuts it
+    const int cs = (cps + sub_m - 1) / sub_m;                                         // chunks per sub-range
+    const int c_lo = r_lo + sub_k * cs < r_hi ? r_lo + sub_k * cs : r_hi;
+    const int c_hi = c_lo + cs < r_hi ? c_lo + cs : r_hi;                            // empty (c_lo == c_hi): the identity map
     float gcar = 0.f, pacc = 1.f, anx = 1.f;   // lane j <-> state j
     if (c_hi < n_c) {
         const int lr = c_hi * CH;
@@ -1192,20 +1204,20 @@ __device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q
 #undef VMS_CARRY_STATE
 #undef VMS_EL
     }
-    if (row_ok) seg_carry[(((int64_t)b * p.dim + d) * n_seg + seg) * N + j] = float2{pacc, gcar};
+    if (row_ok) seg_carry[(((int64_t)b * p.dim + d) * (n_seg * sub_m) + sub) * N + j] = float2{pacc, gcar};
 #undef VMS_OFF
 }
 
 template <typename T, bool HZ, int RM>   // RM as for scan_bwd_pair4_kernel
 __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_carry_kernel(const vms_scan_bwd_params q, const int n_seg,
-                                                                        float2* __restrict__ seg_carry) {
+                                                                        float2* __restrict__ seg_carry, const int sub_m) {
     if constexpr (RM == 2) {
-        const int wg_per_seg = gridDim.x / (n_seg - 1);
-        const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
-        if (b >= q.f.reverse_from) scan_bwd_carry_body<T, HZ, true>(q, n_seg, seg_carry);
-        else scan_bwd_carry_body<T, HZ, false>(q, n_seg, seg_carry);
+        const int wg_per_sub = gridDim.x / ((n_seg - 1) * sub_m);
+        const int b = (int)(blockIdx.x % wg_per_sub) % q.f.batch;
+        if (b >= q.f.reverse_from) scan_bwd_carry_body<T, HZ, true>(q, n_seg, seg_carry, sub_m);
+        else scan_bwd_carry_body<T, HZ, false>(q, n_seg, seg_carry, sub_m);
     } else {
-        scan_bwd_carry_body<T, HZ, RM == 1>(q, n_seg, seg_carry);
+        scan_bwd_carry_body<T, HZ, RM == 1>(q, n_seg, seg_carry, sub_m);
     }
 }
 
@@ -1245,8 +1257,21 @@ int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
     return (n_c + cps - 1) / cps;   // no empty range
 }
 
+constexpr int kMaxSub = 4;   // sub-ranges per range of the carry pass
 int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q) {
-    return (int64_t)q.f.batch * q.f.dim * 16 * kBN * (int64_t)sizeof(float2);   // up to 16 ranges
+    return (int64_t)q.f.batch * q.f.dim * 16 * kMaxSub * kBN * (int64_t)sizeof(float2);   // up to 16 ranges x kMaxSub sub-ranges
+}
+// sub-ranges per range for the carry pass: enough 8-wave workgroups for ~6 waves per SIMD (what its 79 VGPRs admit), at least 4
+// chunks per sub-range
+static int scan_bwd_carry_sub(const vms_scan_bwd_params& q, int n_seg) {
+    const vms_scan_fwd_params& p = q.f;
+    const int n_c = (p.seqlen + kCH - 1) / kCH, cps = (n_c + n_seg - 1) / n_seg;
+    const int64_t waves1 = (int64_t)p.batch * ((p.dim + kBRows - 1) / kBRows) * kBQ * (n_seg - 1);
+    const int64_t want = 6 * 4 * (int64_t)device_cu_count();
+    int m = (int)((want + waves1 - 1) / waves1);
+    if (m > kMaxSub) m = kMaxSub;
+    while (m > 1 && (cps + m - 1) / m < 4) --m;   // (4, 512, 2304): 5-chunk ranges cut in 2-chunk pieces cost more than they hide
+    return m < 1 ? 1 : m;
 }
 
 // would scan_bwd_pair4_kernel<.., XL = true> serve the backward of this forward?  (the shape conditions of
@@ -1315,9 +1340,11 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
         n_seg = scan_bwd_pair_segments(q);
         carry = static_cast<float2*>(p.workspace);
     }
+    int sub_m = 1;
     if (n_seg > 1) {
-        dim3 cgrid(p.batch * tiles * (n_seg - 1));
-#define VMS_C(Z_, R_) hipLaunchKernelGGL((scan_bwd_carry_kernel<T, Z_, R_>), cgrid, block, 0, stream, q, n_seg, carry)
+        sub_m = scan_bwd_carry_sub(q, n_seg);
+        dim3 cgrid(p.batch * tiles * (n_seg - 1) * sub_m);
+#define VMS_C(Z_, R_) hipLaunchKernelGGL((scan_bwd_carry_kernel<T, Z_, R_>), cgrid, block, 0, stream, q, n_seg, carry, sub_m)
         if (mixed) { if (p.z) VMS_C(true, 2); else VMS_C(false, 2); }
         else if (p.reverse) { if (p.z) VMS_C(true, 1); else VMS_C(false, 1); }
         else { if (p.z) VMS_C(true, 0); else VMS_C(false, 0); }
@@ -1355,8 +1382,8 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const bool xl = p.x_has_sub == 3 && (int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
 #define VMS_L4(Z_, R_)                                                                                             \
     do {                                                                                                           \
-        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry); \
-        else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, false>), grid4, block4, smem4, stream, q, n_seg, carry);   \
+        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry, sub_m); \
+        else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, false>), grid4, block4, smem4, stream, q, n_seg, carry, sub_m);   \
     } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
