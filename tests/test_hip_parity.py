@@ -1601,7 +1601,7 @@ def test_block_full_size_configs2_block(oracle, monkeypatch):
 
 def test_block_full_size_configs4_long_video(oracle, monkeypatch):
     """configs[4]: the ViM block at (1, 65536, 768): both scans split into ranges of chunks INSIDE the block (24
-    workgroups otherwise), conv rows of 65,536 elements."""
+    workgroups otherwise; round 4: the forward as scan_fwd_sg_kernel, one pass), conv rows of 65,536 elements."""
     import vms_hip
     _vim_full_size(oracle, monkeypatch, 768, 1, 65536)
     import selective_scan_cuda
@@ -1610,7 +1610,8 @@ def test_block_full_size_configs4_long_video(oracle, monkeypatch):
     dl = torch.rand(1, 768, 65536, device=DEV).to(torch.bfloat16)
     Bm = torch.randn(1, 1, 16, 65536, device=DEV, dtype=torch.bfloat16)
     selective_scan_cuda.fwd(u, dl, -torch.rand(768, 16, device=DEV), Bm, Bm, None, None, None, True)
-    assert vms_hip.last_kernel() == "scan_fwd_pair_lds+split"
+    # 768 rows for 1,024 SIMDs: one pass with a row's states over the four waves of a workgroup (round 3: ranges of chunks)
+    assert vms_hip.last_kernel() == "scan_fwd_sg"
 
 
 def test_block_full_size_configs3_dbm(oracle, monkeypatch):

@@ -602,6 +602,286 @@ __global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_s
 }
 
 
+// =====================================================================================================================
+// Few rows, long sequences in ONE pass (round 4): the 16 states of a row spread over the 4 waves of a workgroup.
+//
+// With fewer rows than SIMDs -- batch 1, 768 channels, 65,536 tokens, BASELINE configs[4] -- the kernels above cut every row
+// into ranges of chunks and pay a carry pass for it: one more exp per (element, state), ~60 % of the main pass, whatever the
+// range count (profiles/r04_seg_sweep.txt: 446-535 us against ~290 for the main pass alone).  States are the other axis of
+// parallelism and need no second pass: a workgroup = ONE row, wave w = states 4w .. 4w+3.  What the states share is done
+// once per workgroup and passed through LDS:
+//   * prologue: wave w turns elements [256 w, 256 w + 256) of the 1024-element chunk (4 per lane, contiguous 512 B per wave)
+//     into delta = softplus(delta_raw + bias) and delta * u -> LDS; after a barrier every wave reads its lane's 16 + 16 values;
+//   * its four states exactly as scan_fwd_pair_kernel runs them (per-wave B / C, the next state's -- after the last: the next
+//     chunk's first -- requested while the current one computes);
+//   * y: every wave leaves its partial sum over 4 states in LDS; after a second barrier wave w adds the four partials of ITS
+//     256 elements, D u, the z gate, and stores them.
+// 8-element checkpoints (x_has_sub == 3): a wave's four states are one [state / 4] block of the layout; transposed through a
+// wave-private 2 KB park into two 1 KB-contiguous 16-byte stores, like scan_fwd_lds_kernel's.
+// LDS 32 KB per workgroup, <= 168 VGPRs: 3 workgroups per CU = 3 waves per SIMD at 768 rows.
+constexpr int kSW = 4;                                                            // waves per workgroup = state groups
+constexpr int kSgFloats = 2 * 1024 + kSW * 1024 + kSW * 2 * kLG * kWave;          // delta, delta u | y partials | parks
+#ifndef VMS_SG_MIN_ROWS
+#define VMS_SG_MIN_ROWS 2   /* rows * VMS_SG_MIN_ROWS >= SIMDs: below that even 4 waves per row leave SIMDs empty: ranges */
+#endif
+#ifndef VMS_SG_MAX_HALVES
+#define VMS_SG_MAX_HALVES 3 /* rows <= VMS_SG_MAX_HALVES * SIMDs / 2: (2, 768, 32768) = 1.5 rows per SIMD 456 -> 403 us; at 3 per SIMD a tie */
+#endif
+
+template <typename T, bool REV>
+struct Raw4 {   // 4 consecutive logical elements (REV: stored right-to-left)
+    vec_t<T, 4> v;
+    __device__ __forceinline__ void load(const T* __restrict__ base, uint32_t off, bool valid) {
+        v = *reinterpret_cast<const vec_t<T, 4>*>(base + (valid ? off : 0u));
+    }
+    __device__ __forceinline__ float at(int i) const { return static_cast<float>(v[REV ? 3 - i : i]); }
+};
+template <typename T, bool REV>
+__device__ __forceinline__ void store4_p(T* __restrict__ ptr, const float (&in)[4]) {
+    vec_t<T, 4> t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = static_cast<T>(in[REV ? 3 - e : e]);
+    *reinterpret_cast<vec_t<T, 4>*>(ptr) = t;
+}
+__device__ __forceinline__ void lds_barrier_p() {   // orders LDS traffic only: loads / stores in flight stay in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <typename T, bool HZ, bool REV>
+__device__ __forceinline__ void scan_fwd_sg_body(const vms_scan_fwd_params& p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int K = kPK, N = kPN, CS = kWave * K;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.x % p.batch;
+    const int d = blockIdx.x / p.batch;                  // grid = batch * dim: one row per workgroup
+    const int g = d / (p.dim / p.n_groups);
+    const int L = p.seqlen;
+
+    const T* const u_b = static_cast<const T*>(p.u);
+    const T* const dt_b = static_cast<const T*>(p.delta);
+    T* const out_b = static_cast<T*>(p.out);
+    const T* const z_b = static_cast<const T*>(p.z);
+    T* const outz_b = static_cast<T*>(p.out_z);
+    const uint32_t o_u = static_cast<uint32_t>((int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride);
+    const uint32_t o_dt = static_cast<uint32_t>((int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride);
+    const uint32_t o_out = static_cast<uint32_t>((int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride);
+    const uint32_t o_z = HZ ? static_cast<uint32_t>((int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride) : 0u;
+    const uint32_t o_oz = HZ ? static_cast<uint32_t>((int64_t)b * p.out_z_batch_stride + (int64_t)d * p.out_z_d_stride) : 0u;
+    const T* const Bv = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* const Cv = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
+    float* const xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * p.n_chunks * xpitch;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+    // lane n (< 16) keeps A[d][n] * log2(e) and the running state of recurrence n; this wave advances lanes 4w .. 4w+3
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)d * p.A_d_stride + (int64_t)(lane & 15) * p.A_dstate_stride] * kLog2e;
+    float hreg = 0.f;
+
+    lds_f4p* const D4 = (lds_f4p*)smem;                                // [delta | delta u][1024] by logical position in the chunk
+    lds_f4p* const Y4 = (lds_f4p*)(smem + 2 * 1024);                   // [wave][1024]
+    lds_f4p* const park4 = (lds_f4p*)(smem + 2 * 1024 + kSW * 1024) + w * (2 * kWave);   // [8-element index (128)][state % 4]
+    typedef uint32_t u32x4_p __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xck, 0, (int)(p.n_chunks * xpitch * 4), 0x00020000);
+
+    const int n_k = (L + CS - 1) / CS;
+    const int q_off = 256 * w + 4 * lane;                 // this lane's 4 prologue / epilogue elements inside a chunk
+    Raw4<T, REV> ru, rdt, rz, rold;                       // ... of the NEXT chunk, in flight while the current one computes
+    auto request_q = [&](int c) __attribute__((always_inline)) {
+        const int lq = c * CS + q_off;
+        const bool v = c < n_k && lq < L;
+        const uint32_t pq = REV ? L - lq - 4 : lq;
+        ru.load(u_b, o_u + pq, v);
+        rdt.load(dt_b, o_dt + pq, v);
+        if (HZ) {
+            rz.load(z_b, o_z + pq, v);
+            if (p.out_z_accumulate) rold.load(outz_b, o_oz + pq, v);
+        }
+    };
+    RawP<T, REV> rB0, rC0, rB1, rC1;
+    const int n_first = 4 * w;
+    request_q(0);
+    {
+        const int l0 = lane * K;
+        rB0.load(Bv + (int64_t)n_first * p.B_dstate_stride, REV ? L - l0 - K : l0, l0 < L);
+        rC0.load(Cv + (int64_t)n_first * p.C_dstate_stride, REV ? L - l0 - K : l0, l0 < L);
+    }
+    for (int c = 0; c < n_k; ++c) {
+        const int l0 = c * CS + lane * K;
+        const bool ok = l0 < L;
+        const uint32_t pl0 = REV ? L - l0 - K : l0;
+        const bool okn = l0 + CS < L;
+        const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
+        const int lq = c * CS + q_off;
+        const bool qok = lq < L;
+        const uint32_t pq = REV ? L - lq - 4 : lq;
+        // ---- prologue of this wave's quarter -> LDS
+        float Du4[4];
+        Raw4<T, REV> zc = rz, oldc = rold;
+        {
+            f4 dl4, du4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float t = rdt.at(i) + bias;
+                if (p.delta_softplus) t = softplusf_(t);
+                t = qok ? t : 0.f;                      // past the end: delta = 0 -> a = 1, b = 0 (identity)
+                const float uv = ru.at(i);
+                dl4[i] = t;
+                du4[i] = t * uv;
+                Du4[i] = Dd * uv;
+            }
+            D4[q_off / 4] = dl4;
+            D4[256 + q_off / 4] = du4;
+        }
+        request_q(c + 1);
+        lds_barrier_p();
+        f2 dl2[K / 2], du2[K / 2], y2[K / 2];
+        float sdl = 0.f;
+        {
+            f2 sd2 = f2{0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const f4 a = D4[4 * lane + v], bq = D4[256 + 4 * lane + v];
+                dl2[2 * v] = f2{a.x, a.y};
+                dl2[2 * v + 1] = f2{a.z, a.w};
+                du2[2 * v] = f2{bq.x, bq.y};
+                du2[2 * v + 1] = f2{bq.z, bq.w};
+                sd2 = sd2 + dl2[2 * v] + dl2[2 * v + 1];
+            }
+            sdl = sd2.x + sd2.y;
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) y2[k] = f2{0.f, 0.f};
+        }
+        float ck8[kLG], ck16[kLG];
+        auto do_state = [&](const int k4, const RawP<T, REV>& cB, const RawP<T, REV>& cC, RawP<T, REV>& nB,
+                            RawP<T, REV>& nC) __attribute__((always_inline)) {
+            const int n = n_first + k4;
+            {   // B / C of the next state -- after this wave's last state: its first state of the next chunk
+                const bool wrap = k4 == kLG - 1;
+                const int nn = wrap ? n_first : n + 1;
+                const uint32_t po = wrap ? pl0n : pl0;
+                const bool pok = wrap ? okn : ok;
+                nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
+                nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
+            }
+            const float An = readlane_f(A_mine, n);
+            const float hin = readlane_f(hreg, n);
+            const f2 An2 = f2{An, An};
+            f2 a2[K / 2], bx2[K / 2];
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                bx2[k] = du2[k] * f2{cB.at(2 * k), cB.at(2 * k + 1)};
+            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_ELP(a2, i), px, VMS_ELP(bx2, i));
+            float pa = fast_exp2(sdl * An);
+            wave_scan_fused_p(pa, px);
+            const float ea = dpp_mov<DPP_WAVE_SHR1, 0xf>(1.f, pa);
+            const float ex = dpp_mov<DPP_WAVE_SHR1, 0xf>(0.f, px);
+            float xs = fmaf(ea, hin, ex);
+            const float hend = fmaf(pa, hin, px);
+            if (p.x_has_sub == 1 && ((lane + 1) * K) % 128 == 0 && ok) {
+                const int i128 = (c * CS + (lane + 1) * K) / 128 - 1;
+                xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n] = hend;
+            }
+            const float hout = readlane_f(hend, 63);
+            if (lane == n) hreg = hout;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
+                VMS_ELP(bx2, i) = xs;
+            }
+            ck8[k4] = bx2[3].y;
+            ck16[k4] = bx2[7].y;
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) y2[k] = pk_fma_p(f2{cC.at(2 * k), cC.at(2 * k + 1)}, bx2[k], y2[k]);
+        };
+        do_state(0, rB0, rC0, rB1, rC1);
+        do_state(1, rB1, rC1, rB0, rC0);
+        do_state(2, rB0, rC0, rB1, rC1);
+        do_state(3, rB1, rC1, rB0, rC0);
+        // ---- this wave's partial y -> LDS
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            Y4[w * 256 + 4 * lane + v] = f4{y2[2 * v].x, y2[2 * v].y, y2[2 * v + 1].x, y2[2 * v + 1].y};
+        // ---- 8-element checkpoints of the wave's state group: lane l holds indices 2l (8th) and 2l + 1 (16th element); through the
+        // park lane l stores index l and index 64 + l: each store instruction covers 1 KB of whole lines (issued behind the next
+        // chunk's B / C requests, so the wait for those leaves the stores in flight)
+        if (p.x_has_sub == 3) {
+            park4[2 * lane] = f4{ck8[0], ck8[1], ck8[2], ck8[3]};
+            park4[2 * lane + 1] = f4{ck16[0], ck16[1], ck16[2], ck16[3]};
+            const f4 va = park4[lane], vb = park4[kWave + lane];
+            const int so = (int)(((c >> 1) * xpitch + 2 * N + (w * 256 + (c & 1) * 128) * 4) * 4);
+            const int la = c * CS + (lane >> 1) * K;
+            const uint32_t voa = la < L ? (uint32_t)lane * 16u : 0x80000000u;
+            const uint32_t vob = la + 32 * K < L ? (uint32_t)lane * 16u : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, kX8Aux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, kX8Aux);
+            asm volatile("s_nop 1" ::"v"(va), "v"(vb));   // the 16-byte-store write-data hazard (see scan_fwd_lds_body)
+        }
+        lds_barrier_p();
+        // ---- epilogue of this wave's quarter: y = sum of the four partials + D u, the z gate, the stores
+        {
+            const f4 s0 = Y4[q_off / 4], s1 = Y4[256 + q_off / 4], s2 = Y4[512 + q_off / 4], s3 = Y4[768 + q_off / 4];
+            float y[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = ((s0[i] + s1[i]) + (s2[i] + s3[i])) + Du4[i];
+            if (qok) store4_p<T, REV>(out_b + (o_out + pq), y);
+            if (HZ) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float zv = zc.at(i);
+                    y[i] *= zv * sigmoidf_(zv);
+                }
+                if (p.out_z_accumulate) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i] += oldc.at(i);
+                }
+                if (qok) store4_p<T, REV>(outz_b + (o_oz + pq), y);
+            }
+        }
+        // reference-shaped checkpoints every 1024 elements (vms_hip.h); lanes 4w .. 4w+3 of this wave hold its states
+        const bool last = c == n_k - 1;
+        const int pos = (c + 1) * CS;
+        if (lane < N && (lane >> 2) == w && (last || pos % 1024 == 0)) {
+            const int blk = last ? (L - 1) / 2048 : (pos - 1) / 2048;
+            const int r = (last ? L : pos) - blk * 2048;
+            float* xb = xck + (int64_t)blk * xpitch;
+            if (r <= 1024) xb[2 * lane] = hreg;
+            if (r == 2048 || last) xb[2 * lane + 1] = hreg;
+        }
+    }
+}
+
+template <typename T, bool HZ, int RM>   // RM as for scan_fwd_lds_kernel
+__global__ __launch_bounds__(kSW* kWave, 3) void scan_fwd_sg_kernel(const vms_scan_fwd_params p) {
+    if constexpr (RM == 2) {
+        const int b = (int)blockIdx.x % p.batch;
+        if (b >= p.reverse_from) scan_fwd_sg_body<T, HZ, true>(p);
+        else scan_fwd_sg_body<T, HZ, false>(p);
+    } else {
+        scan_fwd_sg_body<T, HZ, RM == 1>(p);
+    }
+}
+
+// rows between SIMDs / 2 and 1.5 SIMDs (4 SIMDs per CU): too few waves for the row-per-wave kernels, enough for >= 2 waves per
+// SIMD here (profiles/r04_sg_probe.txt: 256 rows a tie with 16 ranges, 128 rows 94 vs 160 us for the ranges); rows of >= 4
+// chunks (short rows -- the DBM block's 2,304 -- lose: 52 -> 72 us); whole-vector rows; one buffer resource per row
+bool scan_fwd_sg_wanted(const vms_scan_fwd_params& p) {
+    if (p.seqlen % kPK != 0 || p.x_has_sub == 2 || p.segments >= 1 || p.dtype == VMS_F32) return false;   // (fp32 rows: 64 more VGPRs of B / C)
+    const int64_t rows = (int64_t)p.batch * p.dim, simds = 4 * (int64_t)device_cu_count();
+    if (2 * rows > VMS_SG_MAX_HALVES * simds || rows * VMS_SG_MIN_ROWS < simds) return false;
+#ifndef VMS_SG_ANY_LEN
+    if (p.seqlen < 4 * kWave * kPK) return false;          // short rows: nothing to split anyway
+#endif
+    return (int64_t)p.n_chunks * (p.x_chunk_stride ? p.x_chunk_stride : 2 * kPN) * 4 < ((int64_t)1 << 31);
+}
+
 // ---- state carries of a sequence-split forward --------------------------------------------------------------------
 // (P, q) per (row, state) and range of chunks: the state leaving the range is P x_in + q, P = exp2(A sum(delta)),
 // q = the recurrence run from x = 0.  The forward kernel without its C / y / z half (~60 % of its work).
@@ -695,6 +975,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_car
 // per range; p.segments >= 1 forces a count (vms_hip.h)
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
     if (p.seqlen % kPK != 0) return 1;
+    if (scan_fwd_sg_wanted(p)) return 1;   // served in one pass by scan_fwd_sg_kernel: no ranges, no workspace
     const int n_k = (p.seqlen + kWave * kPK - 1) / (kWave * kPK);
     const int64_t waves = (int64_t)p.batch * p.dim;
     const int64_t simds = 4 * (int64_t)device_cu_count();
@@ -735,9 +1016,10 @@ bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec) {
 // reverse_from served by ONE launch: whole-vector rows whose workgroups share a B / C group (the LDS kernel), no sequence split
 bool scan_fwd_pair_native_mixed(const vms_scan_fwd_params& p) {
     if (!(p.reverse_from > 0 && p.reverse_from < p.batch) || p.reverse) return false;
-    if (p.seqlen % kPK != 0 || (p.dim / p.n_groups) % kLW != 0 || p.x_has_sub == 2) return false;
     vms_scan_fwd_params t = p;
     t.reverse_from = 0;
+    if (scan_fwd_sg_wanted(t)) return true;   // one row per workgroup: no group condition
+    if (p.seqlen % kPK != 0 || (p.dim / p.n_groups) % kLW != 0 || p.x_has_sub == 2) return false;
     return scan_fwd_pair_segments(t) <= 1;
 }
 
@@ -746,6 +1028,19 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     const int tiles = (p.dim + kPRows - 1) / kPRows;
     dim3 grid(p.batch * tiles), block(kPRows * kWave);
     const bool rag = p.seqlen % kPK != 0;
+    if (scan_fwd_sg_wanted(p)) {   // few rows, long sequences: the states of a row over the waves of a workgroup, one pass
+        const dim3 grid_s(p.batch * p.dim), block_s(kSW * kWave);
+        const size_t smem_s = sizeof(float) * kSgFloats;
+        const bool mixed_s = p.reverse_from > 0 && p.reverse_from < p.batch;
+#define VMS_LS(Z_, R_) hipLaunchKernelGGL((scan_fwd_sg_kernel<T, Z_, R_>), grid_s, block_s, smem_s, stream, p)
+        if (mixed_s) { if (p.z) VMS_LS(true, 2); else VMS_LS(false, 2); }
+        else if (p.reverse) { if (p.z) VMS_LS(true, 1); else VMS_LS(false, 1); }
+        else { if (p.z) VMS_LS(true, 0); else VMS_LS(false, 0); }
+#undef VMS_LS
+        VMS_LAUNCH_CHECK();
+        set_last_kernel(mixed_s ? "scan_fwd_sg+mixed" : "scan_fwd_sg");
+        return VMS_OK;
+    }
     int n_seg = 1;
     float2* carry = nullptr;
     if (p.workspace != nullptr && p.workspace_bytes >= scan_fwd_pair_ws_bytes(p) && p.x_has_sub != 2) {
