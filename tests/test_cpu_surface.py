@@ -256,7 +256,21 @@ def test_projection_nodes_match_plain_autograd():
     for a, e in zip(got, want):
         torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
     assert got[0].stride(2) == 1   # (B, C, L) with a unit seqlen stride: what the scan backward reads
-    assert _k_splits(8 * 8192) == 8 and _k_splits(197) == 1 and _k_splits(3 * 8192 + 8192 * 13) == 16
+    # y in the scan's channel-slowest layout (strides (L, B L, 1)): the weight gradient takes K slices of the flattened rows
+    import mamba_ssm.ops.projections as proj
+    y_cs = torch.randn(C, B, L).permute(1, 0, 2).requires_grad_()
+    old = proj._k_splits
+    proj._k_splits = lambda k, r, c: 4                      # 120 rows in 4 slices of 30 (the rule wants >= 1024 rows per slice)
+    try:
+        got3 = torch.autograd.grad(out_proj_fn(y_cs, wo, bo), (y_cs, wo, bo), go)
+    finally:
+        proj._k_splits = old
+    want3 = torch.autograd.grad(torch.nn.functional.linear(y_cs.transpose(1, 2), wo, bo), (y_cs, wo, bo), go)
+    for a, e in zip(got3, want3):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+    # slices x 256-wide output tiles ~ one workgroup per CU, >= 1024 rows per slice, the count divides K
+    assert _k_splits(8 * 8192) == 8 and _k_splits(197) == 1 and _k_splits(65536, 1536, 768) == 16
+    assert _k_splits(8 * 3136, 1536, 768) == 14 and _k_splits(65536, 1024, 1024) == 16 and _k_splits(4608, 2048, 512) == 4
 
 
 @pytest.mark.parametrize("name", ["stack_ln", "stack_rms_fp32res"])

@@ -677,7 +677,19 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
         proj_wgrad(dt_in, ddelta, dw1);
         ddt_proj_w = dw1.t().to(wdt);                                                       // (d, R)
     } else {
-        ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
+        // (d, R) = sum over batch AND positions of ddelta dt_in^T.  With a small batch the library runs ONE skinny GEMM per entry
+        // with K = seqlen (batch 1, 65,536 positions: 24 workgroups, 105 us): cut K into slices -- more, shorter GEMMs -- and
+        // sum them with the batch
+        const int64_t L = ddelta.size(2);
+        int64_t ks = 1;
+        while (b * ks < 8 && L % (2 * ks) == 0 && L / (2 * ks) >= 2048) ks *= 2;
+        if (ks > 1 && ddelta.stride(2) == 1 && dt_in.stride(2) == 1) {
+            const Tensor dd4 = ddelta.unflatten(2, {ks, L / ks}).permute({0, 2, 1, 3});          // (b, ks, d, L / ks)
+            const Tensor di4 = dt_in.unflatten(2, {ks, L / ks}).permute({0, 2, 3, 1});           // (b, ks, L / ks, R)
+            ddt_proj_w = at::sum(at::matmul(dd4, di4), at::IntArrayRef({0, 1}), false, wdt);
+        } else {
+            ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
+        }
     }
     {   // (b, R, l) = W_dt^T ddelta, written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
         Tensor d_dt = dx_dbl.narrow(1, 0, R);

@@ -27,12 +27,19 @@ def _autocast_dtype():
     return torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
 
 
-def _k_splits(k_total, target=8192, most=16):
-    """Number of K slices for a weight-gradient GEMM whose output is small: ~target rows per slice."""
-    s = max(1, min(most, k_total // target))
-    while s > 1 and k_total % s:
-        s -= 1
-    return s
+def _k_splits(k_total, rows_out=2048, cols_out=1024, most=32):
+    """Number of K slices for a weight-gradient GEMM (K = batch * seqlen, output rows_out x cols_out): the library tiles the
+    small output 256 x 256, so slices x tiles should come to about one workgroup per CU -- 8 slices for in_proj at d_model 1024
+    (32 tiles), 16 for 1024 x 1024 or 1536 x 768, 14 for the latter at 8 x 3136 rows (tools/gemm_wgrad_split.py,
+    profiles/r04_wgrad_splits.txt: (25088, 1536 x 768) 101 us with the 2 slices of the earlier rule, 73 with 14; (65536, 1536 x
+    768) 197 -> 153 us) -- with at least 1024 rows per slice, and the count must divide K."""
+    tiles = -(-rows_out // 256) * -(-cols_out // 256)
+    want = max(1, min(most, round(256 / tiles), k_total // 1024))
+    best = 1
+    for s in range(1, most + 1):
+        if k_total % s == 0 and abs(s - want) < abs(best - want):
+            best = s
+    return best
 
 
 def _interleave_halves(t, dim):
@@ -124,7 +131,7 @@ class InProjFn(torch.autograd.Function):
                 w = _interleave_halves(wt, 0).reshape(channels, d_model) if ctx.stack_halves else wt
                 dhidden = (g2.to(w.dtype).t() @ w).view(batch, seqlen, d_model).to(hidden.dtype)
         if ctx.needs_input_grad[1]:
-            s = _k_splits(rows)
+            s = _k_splits(rows, channels, d_model)
             if x2.dtype != g2.dtype:
                 x2 = x2.to(g2.dtype)
             dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model))
@@ -181,7 +188,16 @@ class OutProjFn(torch.autograd.Function):
                 # one K slice per batch entry, summed in the parameter's dtype; produced as (d_model, C) = the parameter's own
                 # layout (the transposed product's .t() view cost autograd a 10 us copy when it stored the gradient, and this
                 # operand order is the library's faster one here: tools/gemm_outproj_wgrad.py, 154 -> 138 us with the sum)
-                dweight = torch.bmm(dout.transpose(1, 2), y.transpose(1, 2)).sum(0, dtype=ctx.w_dtype)
+                b_, c_, l_ = y.shape
+                if y.stride(2) == 1 and y.stride(0) == l_ and y.stride(1) == b_ * l_ and dout.is_contiguous():
+                    # y in the scan's channel-slowest layout IS the (C, B L) matrix: K slices of the flattened rows, as many as
+                    # fill the chip (batch 1 at 65,536 positions was ONE 768 x 768 GEMM with K = 65,536: 196 -> 94 us)
+                    rows = b_ * l_
+                    ks = _k_splits(rows, dout.shape[2], c_)
+                    dweight = torch.bmm(dout.reshape(ks, rows // ks, -1).transpose(1, 2),
+                                        y.permute(1, 0, 2).reshape(c_, ks, rows // ks).permute(1, 2, 0)).sum(0, dtype=ctx.w_dtype)
+                else:
+                    dweight = torch.bmm(dout.transpose(1, 2), y.transpose(1, 2)).sum(0, dtype=ctx.w_dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 dbias = dout.sum(dim=(0, 1))
             return dy, dweight, dbias, None, None
