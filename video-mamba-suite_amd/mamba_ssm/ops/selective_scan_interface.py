@@ -166,14 +166,21 @@ def _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias):
     return ext
 
 
-def _mfma_proj():
-    """VMS_MFMA_PROJ=1: the node's small x_proj / dt_proj GEMMs run on the hand-written matrix-core kernels
-    (csrc/inner_proj.hip) where they apply.  Off by default: replacing the library GEMMs one for one measured no gain inside
-    the block step (4.79-4.81 vs 4.74 ms, profiles/r03_small_gemms.md) -- the passes over the 134 MB activations are what
-    costs, not the kernels that make them; tests compare the two paths."""
-    # bit 1 (default on; VMS_NO_FUSED_TAIL=1 clears it): the backward's tail -- dx_proj.weight, dconv1d_out += W_x^T dx_dbl and
-    # the conv1d backward -- as ONE pass over the activations (vms_proj_conv_bwd) instead of three kernels and seven
-    return (1 if os.environ.get("VMS_MFMA_PROJ") == "1" else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2)
+def _mfma_proj(d_inner=None, dt_rank=None):
+    """proj_flags of the compiled node.  Bit 1: the node's small dt_proj products -- delta = W_dt x_dbl[:R] and its weight
+    gradient -- on the hand-written matrix-core kernels (csrc/inner_proj.hip) instead of the library's GEMMs.  At the benchmark
+    shape (d_inner 1024, dt_rank 64) the two are at parity (4.20-4.25 vs 4.26 ms per block step, profiles/r03_small_gemms.md, r04y);
+    where dt_rank is not a multiple of 64 or d_inner not one of 256 -- every d_model 768 / 512 / 384 config of the suite -- the
+    library picks poor tiles (38 and 36 us per call at (8, 768, 3136) for 1.9 GFLOP over 39 MB) and the hand-written ones win:
+    12-layer stack 20.3 -> 19.5 ms, long video 3.90 -> 3.88 (profiles/r04_mfma_proj_ab.txt).  VMS_MFMA_PROJ=1 / 0 forces.
+    Bit 2 (default on; VMS_NO_FUSED_TAIL=1 clears it): the backward's tail -- dx_proj.weight, dconv1d_out += W_x^T dx_dbl and the
+    conv1d backward -- as ONE pass over the activations (vms_proj_conv_bwd) instead of three kernels and seven."""
+    env = os.environ.get("VMS_MFMA_PROJ")
+    if env in ("0", "1"):
+        mfma = env == "1"
+    else:
+        mfma = d_inner is not None and (d_inner % 256 != 0 or dt_rank % 64 != 0)
+    return (1 if mfma else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2)
 
 
 def _for_backward(ctx):
@@ -300,7 +307,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         D = D.contiguous() if D is not None else None
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
-            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj() | _x_flags(ctx, xz, d_state),
+            out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj(d_inner, R) | _x_flags(ctx, xz, d_state),
             conv_out, x_dbl)
         ctx.reverse_from = int(reverse_from)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
@@ -382,7 +389,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
         dxz, dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = _inner_ext_module().inner_bwd(
             dout, xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out,
             bool(ctx.delta_softplus), ctx.reverse, dxz_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_BWD_SEGMENTS"),
-            getattr(ctx, "reverse_from", 0), ctx.w_dtype == torch.float32, _mfma_proj())
+            getattr(ctx, "reverse_from", 0), ctx.w_dtype == torch.float32, _mfma_proj(d_inner, R))
         return dict(dxz=dxz, dconv_w=dconv_w.unsqueeze(1), dconv_b=dconv_b, dx_proj_weight=dx_proj_weight,
                     ddelta_proj_weight=ddelta_proj_weight, dout_proj_weight=None, dout_proj_bias=None, dA=dA, dA_b=None,
                     dB=None, dC=None, dD=dD, ddelta_bias=ddelta_bias, dB_proj_bias=None, dC_proj_bias=None)
@@ -482,7 +489,8 @@ def _inner_backward_dual(first, second, dout):
             delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
         packs.append([conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out])
     r = ext.inner_bwd_dual(dout, xz, packs[0], packs[1], bool(first.delta_softplus), _vms.scan_impl_from_env(),
-                           _vms.segments_from_env("VMS_BWD_SEGMENTS"), first.w_dtype == torch.float32, _mfma_proj())
+                           _vms.segments_from_env("VMS_BWD_SEGMENTS"), first.w_dtype == torch.float32,
+                           _mfma_proj(packs[0][0].shape[0], packs[0][3].shape[1]))
     dxz = r[0]
 
     def as_dict(v):
