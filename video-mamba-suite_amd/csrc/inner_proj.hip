@@ -703,10 +703,12 @@ template <typename T, int MB>
 static int launch_wgrad(const vms_proj_wgrad_params& p, hipStream_t stream) {
     const int n_tiles = (p.seqlen + kTL - 1) / kTL;
     const int n_blocks = (p.n + 127) / 128;
-    // ~2 workgroups per CU; a workgroup ends with m x 128 atomics, so keep its range >= 16 tiles (1024 positions) when the row allows
+    // ~2 workgroups per CU; a workgroup ends with m x 128 atomics, so keep its range >= 8 tiles (512 positions) when the row
+    // allows (16 until round 4: right at (8, 1024, 8192), but (8, 768, 3136) then ran 192 workgroups: 22.8 us, 17.8 with 8; (4, 512,
+    // 2304) 11.7 -> 7.4 us; profiles/r04_small_proj_sweep.txt)
     const int64_t want = 2 * (int64_t)device_cu_count();
     int tpw = (int)(((int64_t)n_tiles * n_blocks * p.batch + want - 1) / want);
-    if (tpw < 16) tpw = 16;
+    if (tpw < 8) tpw = 8;
     if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
     if (tpw > n_tiles) tpw = n_tiles;
     const dim3 grid((n_tiles + tpw - 1) / tpw, n_blocks, p.batch), block(kPT);
@@ -737,6 +739,12 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
     const int64_t want = 2 * (int64_t)device_cu_count();
     int tpw = (int)(((int64_t)n_tiles * d_tiles * p.batch + want - 1) / want);
     if (tpw < 8) tpw = 8;
+    if (tpw > n_tiles) tpw = n_tiles;
+    // two workgroups are resident per CU: a grid a little above 2 per CU -- the padding to whole XCD groups can push it there --
+    // runs a second, nearly empty round ((1, 768, 65536): 24 tiles per workgroup = 576 workgroups 125 us, 16 = 768 or 32 = 384
+    // 93-98 us): longer ranges until the grid fits one round
+    auto grid_of = [&](int t) { return 8 * (int64_t)((((n_tiles + t - 1) / t) * p.batch + 7) / 8) * d_tiles; };
+    while (tpw < n_tiles && grid_of(tpw) > want && 2 * grid_of(tpw) < 3 * want) ++tpw;
     if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
     if (tpw > n_tiles) tpw = n_tiles;
     const int n_rng = (n_tiles + tpw - 1) / tpw;
