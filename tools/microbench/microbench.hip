@@ -1,5 +1,5 @@
 // microbench.hip -- VALU / transcendental / DPP issue rates on gfx950, to size the scan kernels.
-// build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/build/microbench
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/microbench.hip -o tools/build/microbench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>

@@ -1,6 +1,6 @@
 // microbench3.hip -- ceiling of the "lane = row, states in registers, B/C in SGPRs" scan loop on gfx950.
 // Each wave = 64 rows x T elements x 16 states, sequential over T; B/C are wave-uniform (scalar loads).
-// build: hipcc --offload-arch=gfx950 -O3 tools/microbench3.hip -o tools/build/microbench3
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/microbench3.hip -o tools/build/microbench3
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include <stdio.h>

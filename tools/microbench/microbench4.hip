@@ -1,7 +1,7 @@
 // microbench4.hip -- "lane = row" scan loop, two ways of feeding the wave-uniform B/C values:
 //   S: scalar loads (s_load_dwordx8, fp32 B/C) software-prefetched one state ahead (inline asm)
 //   L: fp32 B/C tile staged in LDS once per workgroup, broadcast ds_read_b128
-// build: hipcc --offload-arch=gfx950 -O3 tools/microbench4.hip -o tools/build/microbench4
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/microbench4.hip -o tools/build/microbench4
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -1,7 +1,7 @@
 // microbench5.hip -- issue-cost experiments for the scan's instruction mix on gfx950 (pure asm bodies).
 // Every variant runs 8 waves/SIMD (2048 blocks x 256 threads... 8192 waves x REPS rounds), reports nominal
 // cycles (@2.4 GHz) per "group" and the measured shader clock.
-// build: hipcc --offload-arch=gfx950 -O3 tools/microbench5.hip -o tools/build/microbench5
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/microbench5.hip -o tools/build/microbench5
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -1,6 +1,6 @@
 // microbench6.hip -- latency of DEPENDENT VALU chains on gfx950 at 1 and 2 waves per SIMD:
 // cycles per instruction of one wave when every instruction depends on the one ILP positions earlier.
-// build: hipcc --offload-arch=gfx950 -O3 tools/microbench6.hip -o tools/build/microbench6
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench/microbench6.hip -o tools/build/microbench6
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)

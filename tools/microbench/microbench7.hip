@@ -1,5 +1,5 @@
 // microbench7: cost of v_permlane32_swap / v_permlane16_swap / DPP adds / ds_bpermute next to packed math (gfx950)
-// build: hipcc -O3 --offload-arch=gfx950 tools/microbench7.hip -o tools/build/microbench7 ; run: tools/build/microbench7
+// build: hipcc -O3 --offload-arch=gfx950 tools/microbench/microbench7.hip -o tools/build/microbench7 ; run: tools/build/microbench7
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP8(x) x x x x x x x x

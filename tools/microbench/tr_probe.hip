@@ -1,6 +1,6 @@
 // tr_probe.hip -- semantics of ds_read_b64_tr_b16 on gfx950: which LDS elements does lane l receive when lane i of a 16-lane
 // group supplies the address of row i / 4, column group i % 4 of a [4][16] matrix of 16-bit elements with a free row stride?
-// hipcc --offload-arch=gfx950 -O2 tools/tr_probe.hip -o tools/build/tr_probe && tools/build/tr_probe
+// hipcc --offload-arch=gfx950 -O2 tools/microbench/tr_probe.hip -o tools/build/tr_probe && tools/build/tr_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -12,7 +12,7 @@
 //     as fused v_fmac_f32_dpp / v_mul_f32_dpp pairs; nothing crosses a DPP row.
 //   * a workgroup = 16 waves = 8 row quads x 2 state halves = 32 rows.  The state split exists
 //     for occupancy: one wave can issue a VALU instruction only every ~8.5 cycles on this chip
-//     (tools/microbench.hip), so the kernel needs 4 waves per SIMD, and (8, 8192, 1024, 16) has
+//     (tools/microbench/microbench.hip), so the kernel needs 4 waves per SIMD, and (8, 8192, 1024, 16) has
 //     only 2048 row quads for 1024 SIMDs.
 //   * the reduction of dB / dC over rows -- 134M fp32 atomics with 1024-way contention in the
 //     reference (bwd_kernel.cuh:297-316) -- is done by the matrix pipe, which is otherwise idle:

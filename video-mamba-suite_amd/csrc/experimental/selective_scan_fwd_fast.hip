@@ -7,7 +7,7 @@
 // What differs from the generic kernel (DESIGN.md "scan forward, fast path"):
 //   * still one wave per (batch, dim) row, 64 lanes x 16 elements per 1024-element chunk -- 8192
 //     rows at the headline size give 8 waves per SIMD to draw from, which this chip needs (one wave
-//     issues a VALU instruction only every ~8.5 cycles, tools/microbench.hip);
+//     issues a VALU instruction only every ~8.5 cycles, tools/microbench/microbench.hip);
 //   * the 64-lane scan of the lane aggregates is 6 steps of DPP-fused VOP2 pairs
 //     (v_fmac_f32_dpp / v_mul_f32_dpp) in one asm block: 12 instructions instead of ~36;
 //   * the lane aggregate's "a" component is exp2(A * sum(delta)) (1 mul + 1 exp) instead of a

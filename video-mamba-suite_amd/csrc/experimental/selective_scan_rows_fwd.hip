@@ -11,7 +11,7 @@
 //   * the 16 states are processed as 8 PAIRS with packed fp32 ops (v_pk_mul_f32 / v_pk_fma_f32):
 //     per (element, state pair) = pk_mul, 2 x v_exp_f32, pk_mul, pk_fma, pk_fma.  On gfx950 a packed op
 //     issues in 4 cycles for 2 lanes-ops also next to transcendentals, where scalar fp32 ops
-//     degrade from ~2.2 to ~3.8 cycles (tools/microbench5.hip, profiles/r01_microbench_issue.txt);
+//     degrade from ~2.2 to ~3.8 cycles (tools/microbench/microbench5.hip, profiles/r01_microbench_issue.txt);
 //   * parallelism along the sequence comes from 128-element chunks: pass 1 computes every chunk's local
 //     end state and sum of delta, a tiny carry kernel chains them (and writes the checkpoints the
 //     backward pass starts from), pass 2 redoes the recurrence from the true chunk-start state and

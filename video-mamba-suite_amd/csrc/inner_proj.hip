@@ -114,7 +114,7 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
         }
     };
     // transposing read: lane i of a 16-lane group supplies the address of row i / 4, columns 4 (i % 4) .. + 3 of a [4][16] block
-    // and receives column i of its 4 rows (tools/tr_probe.hip).  Groups 0 / 1 = columns 0-15 / 16-31 of k rows 8 h .. 8 h + 3 (+ 4)
+    // and receives column i of its 4 rows (tools/microbench/tr_probe.hip).  Groups 0 / 1 = columns 0-15 / 16-31 of k rows 8 h .. 8 h + 3 (+ 4)
     const int i16 = lane & 15, g16 = lane >> 4;
     const lds_s16* const tb = in_lds + (8 * (g16 >> 1) + (i16 >> 2)) * kRowE + 16 * (g16 & 1) + 4 * (i16 & 3);
     // epilogue pieces of a 32 x 32 half tile: lane -> row (lane >> 2) + 16 pp, columns 8 (lane & 3) .. + 7
@@ -444,7 +444,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
         for (int ps = 0; ps < NPASS; ++ps)
             *reinterpret_cast<lds_s16x8*>(in_lds + ((tid >> 3) + 32 * ps) * kRowE + 8 * (tid & 7)) = stg[ps];
     };
-    // transposing reads (tools/tr_probe.hip): lane i of a 16-lane group supplies row i / 4, columns 4 (i % 4) .. + 3 of a
+    // transposing reads (tools/microbench/tr_probe.hip): lane i of a 16-lane group supplies row i / 4, columns 4 (i % 4) .. + 3 of a
     // [4][16] block and receives column i of its 4 rows.  16x16x32 operands: lane -> (row / column lane & 15, k = 8 (lane >> 4) .. + 7)
     const int i16 = lane & 15, g16 = lane >> 4;
     const lds_s16* const tb = in_lds + (8 * g16 + (i16 >> 2)) * kRowE + 4 * (i16 & 3);

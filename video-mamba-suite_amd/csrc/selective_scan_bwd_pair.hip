@@ -18,7 +18,7 @@
 // c = C dy, g a x, the du / ddelta / dA / dB / dC contributions) is computed on PAIRS of consecutive elements
 // with v_pk_mul_f32 / v_pk_fma_f32; only the four recurrences along the elements stay scalar chains.  This
 // kernel has 2048 waves at (8, 8192, 1024, 16) = 2 per SIMD, and a wave issues one instruction every ~8.5
-// cycles whatever it is (tools/microbench.hip): instruction COUNT is what the run time follows, and the
+// cycles whatever it is (tools/microbench/microbench.hip): instruction COUNT is what the run time follows, and the
 // pairing takes it from ~32 to ~20 per (element, state) without growing the register footprint (pairing
 // the STATES instead needs 64-bit versions of every per-element array: 350 VGPRs, measured slower).
 // du / ddelta are accumulated as S1_i = sum_n g B, S2_i = sum_n A g a x_{i-1} and combined once per chunk;

@@ -8,7 +8,7 @@
 // What is new: everything that is independent across the 16 elements of a lane (the exp arguments,
 // b = delta u B, the contraction y += C x) runs on PAIRS of consecutive elements with v_pk_mul_f32 /
 // v_pk_fma_f32; the two recurrences along the elements stay scalar fma chains.  Measured on gfx950
-// (tools/microbench5.hip, profiles/r01_microbench_issue.txt): next to v_exp_f32 a scalar fp32 VALU op costs
+// (tools/microbench/microbench5.hip, profiles/r01_microbench_issue.txt): next to v_exp_f32 a scalar fp32 VALU op costs
 // ~3.8 cycles of issue, a packed op 4.0 for twice the work.  (Pairing the STATES instead -- also tried --
 // packs the chains too but doubles every per-element array: it has to drop to 8 elements per lane, which
 // doubles the cross-lane scan cost per element, and came out slower.)  Loads carry no select (a lane past the

@@ -5,7 +5,7 @@ with `rearrange(in_proj.weight @ rearrange(hidden, "b l d -> d (b l)"), "d (b l)
 (mamba_ssm/modules/mamba_simple.py:144-149) and leaves both backward GEMMs to autograd, which runs the
 weight gradient as ONE (channels x d_model) GEMM with K = batch * seqlen -- 32 output tiles for 256 CUs.
 Here the weight gradients are split along K into a batched GEMM plus a sum (2.4x faster at
-(8, 8192, 1024) on MI355X: tools/gemm_wgrad.py, tools/gemm_outproj.py), and out_proj consumes and
+(8, 8192, 1024) on MI355X: tools/gemm_wgrad.py, tools/attic/gemm_outproj.py), and out_proj consumes and
 produces (batch, channels, seqlen) directly, so that no transpose copy sits between it and the scan.
 Only library GEMMs (hipBLASLt through torch) are used; autocast behaves as for nn.Linear.
 
@@ -187,7 +187,7 @@ class OutProjFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 # one K slice per batch entry, summed in the parameter's dtype; produced as (d_model, C) = the parameter's own
                 # layout (the transposed product's .t() view cost autograd a 10 us copy when it stored the gradient, and this
-                # operand order is the library's faster one here: tools/gemm_outproj_wgrad.py, 154 -> 138 us with the sum)
+                # operand order is the library's faster one here: tools/attic/gemm_outproj_wgrad.py, 154 -> 138 us with the sum)
                 b_, c_, l_ = y.shape
                 if y.stride(2) == 1 and y.stride(0) == l_ and y.stride(1) == b_ * l_ and dout.is_contiguous():
                     # y in the scan's channel-slowest layout IS the (C, B L) matrix: K slices of the flattened rows, as many as
