@@ -250,3 +250,25 @@ def test_module_scan_checkpoints_argument(monkeypatch):
     assert sizes["fine"] - sizes["coarse"] > 0.8 * ck, sizes
     assert sizes[None] == sizes["fine"]               # "auto" on an almost empty device: the fast layout
     assert vms_hip.current_x_layout_policy() == "auto"
+
+
+def test_auto_policy_backs_off_when_the_device_fills(monkeypatch):
+    """"auto": 8-element checkpoints only while at most a quarter of the device's memory is allocated (a stack sized
+    for the reference's 4 MB x must not run out of memory here)"""
+    import vms_hip
+    monkeypatch.delenv("VMS_X_LAYOUT", raising=False)
+    shp = (8, 1024, 8192, 16, DEV)
+    torch.cuda.empty_cache()
+    assert vms_hip.x_mode_for_shape(*shp) == -1
+    total = torch.cuda.get_device_properties(0).total_memory
+    ballast = torch.empty(int(0.27 * total), dtype=torch.uint8, device=DEV)   # allocated, never touched
+    try:
+        assert vms_hip.x_mode_for_shape(*shp) == 1
+        with vms_hip.x_layout_policy("fine"):
+            assert vms_hip.x_mode_for_shape(*shp) == -1
+    finally:
+        del ballast
+        torch.cuda.empty_cache()
+    assert vms_hip.x_mode_for_shape(*shp) == -1
+    # a scan whose checkpoints alone would take more than 1/8 of the free memory stays coarse even on an empty device
+    assert vms_hip.x_mode_for_shape(64, 8192, 131072, 16, DEV) == 1

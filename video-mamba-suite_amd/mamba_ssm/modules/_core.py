@@ -23,7 +23,7 @@ from torch import Tensor
 
 import vms_hip as _vms
 from causal_conv1d import causal_conv1d_fn, causal_conv1d_update
-from mamba_ssm.ops.selective_scan_interface import (NegExpPairFn, bimamba_inner_fn_no_out_proj, mamba_inner_fn,
+from mamba_ssm.ops.selective_scan_interface import (NegExpFn, NegExpPairFn, bimamba_inner_fn_no_out_proj, mamba_inner_fn,
                                                      mamba_inner_fn_no_out_proj,
                                                     selective_scan_fn)
 from mamba_ssm.ops.projections import in_proj_fn, out_proj_fn
@@ -276,7 +276,7 @@ class MambaCore(nn.Module):
             # (the reference stacks a flipped copy of the second half, mamba_new.py:192-213, and flips its output back)
             batch = hidden_states.shape[0]
             xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True)    # (2 B, 2 d, L)
-            A = -torch.exp(self.A_log.float())
+            A = NegExpFn.apply(self.A_log)
             out = mamba_inner_fn_no_out_proj(
                 xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
                 self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,

@@ -33,6 +33,8 @@ def _k_splits(k_total, rows_out=2048, cols_out=1024, most=32):
     (32 tiles), 16 for 1024 x 1024 or 1536 x 768, 14 for the latter at 8 x 3136 rows (tools/gemm_wgrad_split.py,
     profiles/r04_wgrad_splits.txt: (25088, 1536 x 768) 101 us with the 2 slices of the earlier rule, 73 with 14; (65536, 1536 x
     768) 197 -> 153 us) -- with at least 1024 rows per slice, and the count must divide K."""
+    if k_total <= 8192:      # a GEMM this small takes the same ~27 us sliced or not ((4608, 2048 x 512): 30.5 / 27.3 / 27.6 us for
+        return 1             # 1 / 4 / 8 slices) and the sum of the slices is one more kernel in a launch-bound step (the DBM block)
     tiles = -(-rows_out // 256) * -(-cols_out // 256)
     want = max(1, min(most, round(256 / tiles), k_total // 1024))
     best = 1

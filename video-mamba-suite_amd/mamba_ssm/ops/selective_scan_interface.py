@@ -546,6 +546,26 @@ class NegExpPairFn(torch.autograd.Function):
         return da, db, None, None
 
 
+class NegExpFn(torch.autograd.Function):
+    """A_log -> -exp(A_log.float()) with one launch forward (vms_param_prep VMS_PREP_NEG_EXP) and one backward, where
+    `-torch.exp(x.float())` costs 2 + 2 small kernels: the DBM block's step is ~30 kernels of a few microseconds each."""
+
+    @staticmethod
+    def forward(ctx, a_log):
+        if a_log.is_cuda and a_log.dtype == torch.float32 and a_log.is_contiguous() and a_log.dim() == 2:
+            out = torch.empty_like(a_log)
+            _vms.param_prep([(a_log.detach(), out, _vms.PREP_NEG_EXP)])
+        else:
+            out = -torch.exp(a_log.float())
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        return g * a   # d(-exp(x)) = -exp(x) dx
+
+
 _DUAL_CONV = os.environ.get("VMS_NO_DUAL_CONV", "0") != "1"   # =1: one conv1d launch per direction (A/B, tests)
 
 
