@@ -80,22 +80,35 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p
     }
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row groups
     if (q.op != VMS_PREP_CAST_T) {
-#pragma unroll 4
+        // all 16 loads first (clamped addresses, no branch around them): one round trip instead of 16 -- the -exp(A_log) tiles,
+        // 16 columns wide, used to set this kernel's duration (12 us for a 32 KB job; round 4)
+        float v[kTile / 4];
+#pragma unroll
         for (int k = 0; k < kTile / 4; ++k) {
             const int r = r0 + ty + 4 * k, c = c0 + tx;
-            if (r < q.rows && c < q.cols) {
-                float v = ld_f(q.src, (int64_t)r * q.src_row_stride + c, q.src_dtype);
-                if (q.op == VMS_PREP_NEG_EXP) v = -expf(v);
-                st_f(q.dst, (int64_t)r * q.dst_row_stride + c, q.dst_dtype, v);
-            }
+            const bool ok = r < q.rows && c < q.cols;
+            v[k] = ld_f(q.src, ok ? (int64_t)r * q.src_row_stride + c : 0, q.src_dtype);
+        }
+#pragma unroll
+        for (int k = 0; k < kTile / 4; ++k) {
+            const int r = r0 + ty + 4 * k, c = c0 + tx;
+            if (r < q.rows && c < q.cols)
+                st_f(q.dst, (int64_t)r * q.dst_row_stride + c, q.dst_dtype, q.op == VMS_PREP_NEG_EXP ? -expf(v[k]) : v[k]);
         }
         return;
     }
     // dst (cols, rows) <- src (rows, cols)
-#pragma unroll 4
-    for (int k = 0; k < kTile / 4; ++k) {
-        const int r = r0 + ty + 4 * k, c = c0 + tx;
-        tile[ty + 4 * k][tx] = (r < q.rows && c < q.cols) ? ld_f(q.src, (int64_t)r * q.src_row_stride + c, q.src_dtype) : 0.f;
+    {
+        float v[kTile / 4];
+#pragma unroll
+        for (int k = 0; k < kTile / 4; ++k) {
+            const int r = r0 + ty + 4 * k, c = c0 + tx;
+            const bool ok = r < q.rows && c < q.cols;
+            const float f = ld_f(q.src, ok ? (int64_t)r * q.src_row_stride + c : 0, q.src_dtype);
+            v[k] = ok ? f : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kTile / 4; ++k) tile[ty + 4 * k][tx] = v[k];
     }
     __syncthreads();
 #pragma unroll 4
