@@ -407,3 +407,29 @@ def test_checkpoint_layout_policy(monkeypatch):
     from mamba_ssm.modules.mamba_new import Mamba as DBM
     assert Mamba(32, expand=1, bimamba_type="v2", scan_checkpoints="coarse").scan_checkpoints == "coarse"
     assert DBM(32, expand=1).scan_checkpoints is None
+
+
+def test_in_proj_weight_gradient_is_ready_before_the_input_gradient():
+    """in_proj's weight gradient is the last parameter gradient of a block's backward: produced by its own autograd node AHEAD of
+    the input-gradient GEMM, the reducer's all-reduce of the last DDP bucket overlaps that GEMM instead of trailing the step"""
+    import torch
+    from mamba_ssm.ops.projections import in_proj_fn
+    torch.manual_seed(0)
+    x = torch.randn(2, 12, 8, requires_grad=True)
+    w = torch.randn(10, 8, requires_grad=True)
+    b = torch.randn(10, requires_grad=True)
+    order = []
+    w.register_hook(lambda g: order.append("weight"))
+    b.register_hook(lambda g: order.append("bias"))
+    x.register_hook(lambda g: order.append("input"))
+    in_proj_fn(x, w, b).square().sum().backward()
+    assert order.index("weight") < order.index("input") and order.index("bias") < order.index("input"), order
+    ref = (w @ x.detach().reshape(24, 8).t()).view(10, 2, 12).permute(1, 0, 2) + b[:, None]
+    xr = x.detach().clone().requires_grad_()
+    wr, br = w.detach().clone().requires_grad_(), b.detach().clone().requires_grad_()
+    ((wr @ xr.reshape(24, 8).t()).view(10, 2, 12).permute(1, 0, 2) + br[:, None]).square().sum().backward()
+    for a, e in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        torch.testing.assert_close(a, e, rtol=1e-5, atol=1e-5)
+    # an input that needs no gradient: one node, as before
+    x2 = torch.randn(2, 12, 8)
+    in_proj_fn(x2, w, b).sum().backward()
