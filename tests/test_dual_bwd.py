@@ -135,3 +135,48 @@ def test_block_backward_dual_vs_two_launches(monkeypatch, shape):
     check(dx1, dx0, 2e-2, "block dx: dual vs two launches")
     for k in g0:
         check(g1[k], g0[k], 2e-2, f"block {k}: dual vs two launches")
+
+
+def test_dual_with_groups(monkeypatch):
+    """two B / C groups: a 16-row workgroup of the 4-wave grid never straddles a group ((dim / n_groups) % 32 == 0)"""
+    import selective_scan_cuda as ssc
+    import vms_hip
+    b, d, L, G = 8, 768, 272, 2
+    a, bb = list(_dir_inputs(b, d, L, torch.bfloat16, 30)), list(_dir_inputs(b, d, L, torch.bfloat16, 31))
+    for t in (a, bb):
+        t[3] = torch.randn(b, G, 16, L, device=DEV).to(torch.bfloat16)
+        t[4] = torch.randn(b, G, 16, L, device=DEV).to(torch.bfloat16)
+    z = torch.randn(b, d, L, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(b, d, L, device=DEV).to(torch.bfloat16)
+    fw = [ssc.fwd(*t[:6], z, t[6], True, reverse=(i == 1)) for i, t in enumerate((a, bb))]
+    dz_ref = torch.empty_like(z)
+    ra = ssc.bwd(*a[:6], z, a[6], dout, fw[0][1], fw[0][0], dz_ref, True, False, keep_fp32=True)
+    rb = ssc.bwd(*bb[:6], z, bb[6], dout, fw[1][1], fw[1][0], dz_ref, True, False, reverse=True, keep_fp32=True, accumulate_dz=True)
+    da, db = ssc.bwd_dual((*a[:6], a[6], fw[0][1], fw[0][0]), (*bb[:6], bb[6], fw[1][1], fw[1][0]), z, dout, torch.empty_like(z), True, keep_fp32=True)
+    assert vms_hip.last_kernel() == "scan_bwd_pair4_dual_w4"
+    for got, ref in ((da, ra), (db, rb)):
+        for k, name in enumerate(NAMES):
+            assert rel_err(got[k], ref[k]) <= (0.0 if name in ("du", "ddelta") else 2e-5), name
+    check(da[7], ra[7], 2 ** -7, "dz")
+
+
+def test_split_backward_mixed_directions_with_carry_sub_ranges(monkeypatch):
+    """reverse_from + a sequence split whose carry pass runs over sub-ranges (long rows, few of them): == the two single-direction
+    problems, each split on its own"""
+    import selective_scan_cuda as ssc
+    import vms_hip
+    b, d, L = 2, 64, 32768
+    u, delta, A, B, C, D, bias = _dir_inputs(b, d, L, torch.bfloat16, 40)
+    z = torch.randn(b, d, L, device=DEV).to(torch.bfloat16)
+    dout = torch.randn(b, d, L, device=DEV).to(torch.bfloat16)
+    out, x, _ = ssc.fwd(u, delta, A, B, C, D, z, bias, True, reverse_from=1)
+    g = ssc.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, keep_fp32=True, reverse_from=1)
+    assert vms_hip.last_kernel() == "scan_bwd_pair4+mixed+split", vms_hip.last_kernel()
+    parts = []
+    for i, rev in ((0, False), (1, True)):
+        s = slice(i, i + 1)
+        o, xx, _ = ssc.fwd(u[s], delta[s], A, B[s], C[s], D, z[s], bias, True, reverse=rev)
+        parts.append(ssc.bwd(u[s], delta[s], A, B[s], C[s], D, z[s], bias, dout[s], xx, o, None, True, False, reverse=rev, keep_fp32=True))
+    for k, name in enumerate(NAMES + ["dz"]):
+        ref = torch.cat([parts[0][k], parts[1][k]]) if name in ("du", "ddelta", "dB", "dC", "dz") else parts[0][k] + parts[1][k]
+        check(g[k], ref, 1e-2 if name in ("du", "ddelta", "dz") else 1e-3, f"mixed split {name}")

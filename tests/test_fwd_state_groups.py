@@ -115,3 +115,28 @@ def test_state_group_forward_vs_oracle(oracle):
     check(out[:, rows], o["out"], TOL[torch.bfloat16], "out rows vs oracle")
     check(out_z[:, rows], o["out_z"], TOL[torch.bfloat16], "out_z rows vs oracle")
     check(x[:, rows, -1, 1::2], o["last_state"], 1e-3, "last_state vs oracle")
+
+
+def test_state_group_forward_with_the_reference_shaped_x():
+    """A C caller's dense x (pitch 2 * dstate, no finer checkpoints: vms_hip.h x_has_sub == 0) through the state-group kernel"""
+    import vms_hip
+    b, d, L = 1, 768, 4096
+    u, delta, A, B, C, D, z, bias, _ = _problem(b, d, L, torch.bfloat16, seed=21)
+    res = {}
+    for tag, seg in (("sg", None), ("rows", "1")):
+        out, out_z = torch.empty_like(delta), torch.empty_like(z)
+        x = torch.full((b, d, 2, 32), float("nan"), device=DEV)
+        if seg:
+            import os
+            os.environ["VMS_FWD_SEGMENTS"] = seg
+        try:
+            vms_hip.scan_fwd(u, delta, A, B, C, D, z, bias, out, out_z, x, True)
+        finally:
+            if seg:
+                del os.environ["VMS_FWD_SEGMENTS"]
+        res[tag] = (out, out_z, x, vms_hip.last_kernel())
+    assert res["sg"][3] == "scan_fwd_sg" and res["rows"][3].startswith("scan_fwd_pair"), (res["sg"][3], res["rows"][3])
+    assert torch.equal(res["sg"][2], res["rows"][2]) and not torch.isnan(res["sg"][2]).any()
+    for i in (0, 1):
+        a, r = res["sg"][i].float(), res["rows"][i].float()
+        assert (a - r).abs().max().item() <= 2 ** -7 * r.abs().max().item()
