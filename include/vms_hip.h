@@ -21,7 +21,7 @@
  *        mamba/mamba_ssm/ops/triton/selective_state_update.py:16-154
  *   vms_layer_norm_fwd / _bwd <- the Triton kernels of mamba_ssm.ops.triton.layernorm
  *        mamba/mamba_ssm/ops/triton/layernorm.py:51-377
- *   vms_proj_apply / vms_proj_wgrad <- the small x_proj / dt_proj GEMMs MambaInnerFn runs through torch
+ *   vms_proj_apply / vms_proj_wgrad / vms_proj_kred <- the small x_proj / dt_proj GEMMs MambaInnerFn runs through torch
  *        mamba/mamba_ssm/ops/selective_scan_interface.py:182, 275-279
  *
  * Conventions
@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 9
+#define VMS_ABI_VERSION 10
 
 typedef enum {
     VMS_OK = 0,
@@ -379,6 +379,29 @@ typedef struct {
 int vms_proj_apply(const vms_proj_apply_params *p, void *stream);
 int vms_proj_wgrad(const vms_proj_wgrad_params *p, void *stream);
 
+/* vms_proj_kred (ABI v10): the inner node's two skinny products whose contraction runs over the CHANNELS --
+ *     x_dbl        = F.linear(rearrange(conv1d_out, "b d l -> (b l) d"), x_proj_weight)   (:181)  m = dt_rank + 2 d_state
+ *     dx_dbl[:, :R] = einsum("dB,dr->Br", ddelta, delta_proj_weight)                       (:276)  m = dt_rank
+ *   out[b][m][l] = sum_{k < K} w[m][k] * in[b][k][l]          m <= 96, any K
+ *   in: (batch, k, seqlen), out: (batch, m, seqlen) in `dtype` (bf16 / fp16), unit seqlen stride; w: (m, k) in `dtype` with a unit
+ *   stride along k (x_proj.weight) OR along m (dt_proj.weight (d_inner, dt_rank) read as its transpose: w_row_stride = 1,
+ *   w_k_stride = dt_rank).  fp32 accumulation on the matrix cores, one rounding to `dtype`.
+ *   w2 / in2 / out2 (all or none): a second problem of the same shape and strides in the same launch -- the other direction of
+ *   a bidirectional block. */
+typedef struct {
+    int32_t batch, m, k, seqlen;
+    int32_t dtype;
+    int32_t tile;             /* positions per workgroup: 64, 128 or 256; 0 = chosen from the grid size (a tuning knob) */
+    const void *w, *in;
+    void *out;
+    const void *w2, *in2;
+    void *out2;
+    int64_t w_row_stride, w_k_stride;
+    int64_t in_batch_stride, in_k_stride;          /* elements; multiples of 8 */
+    int64_t out_batch_stride, out_row_stride;
+} vms_proj_kred_params;
+int vms_proj_kred(const vms_proj_kred_params *p, void *stream);
+
 /* vms_proj_conv_bwd: selective_scan_interface.py:278-283 in one pass over the activations --
  *     dx_proj_weight  = einsum("Br,Bd->rd", dx_dbl, conv1d_out)                      -> dw_x (k, dim) fp32, ADDED to (atomics)
  *     dconv1d_out     = addmm(du, x_proj_weight.t(), dx_dbl.t())                     (never stored: fp32 on chip)
@@ -455,6 +478,7 @@ int vms_sizeof_state_update_params(void);
 int vms_sizeof_proj_apply_params(void);
 int vms_sizeof_proj_wgrad_params(void);
 int vms_sizeof_proj_conv_bwd_params(void);
+int vms_sizeof_proj_kred_params(void);
 
 #ifdef __cplusplus
 }

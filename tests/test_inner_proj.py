@@ -109,6 +109,94 @@ def test_proj_checks():
                        torch.empty(1, 64, 64, device=DEV, dtype=torch.bfloat16), False)
 
 
+# (batch, m, k, seqlen): x_proj (m = dt_rank + 2 d_state, k = d_inner) and dt_proj^T (m = dt_rank) of the BASELINE configs; ragged tiles
+# (seqlen % 64, k % 64, m % 16 != 0), sub-tile problems
+KRED_SHAPES = [(8, 96, 1024, 8192), (8, 64, 1024, 8192), (2, 80, 768, 3136), (2, 48, 768, 3136), (2, 64, 512, 2304), (1, 56, 384, 3152),
+               (1, 24, 384, 3152), (1, 80, 768, 8192), (3, 17, 200, 72), (2, 96, 40, 8), (1, 5, 136, 200), (2, 33, 64, 264)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", KRED_SHAPES)
+@pytest.mark.parametrize("tile", [0, 64, 128, 256])
+def test_proj_kred_vs_matmul(shape, dtype, tile):
+    """out[b, m, l] = sum_k w[m, k] in[b, k, l] with w stored (m, k) (x_proj.weight): every tile width, fp32 accumulation, one rounding."""
+    vms = _vms()
+    b, m, k, L = shape
+    torch.manual_seed(m + k)
+    w = (torch.randn(m, k, device=DEV) * k ** -0.5).to(dtype)
+    x = torch.randn(b, k, L, device=DEV).to(dtype)
+    out = torch.full((b, m, L), float("nan"), device=DEV, dtype=dtype)
+    vms.proj_kred(w, x, out, tile=tile)
+    assert vms.lib().vms_last_kernel().decode() == "proj_kred"
+    want = w.double() @ x.double()
+    err = (out.double() - want).abs().max().item()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert err <= eps * want.abs().max().item() * 1.01 + 1e-6, f"max abs err {err:.3e}"
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 1024, 8192), (2, 48, 768, 3136), (2, 32, 512, 2304), (1, 24, 384, 3152), (3, 8, 200, 72), (2, 96, 136, 264)])
+@pytest.mark.parametrize("tile", [0, 64, 256])
+def test_proj_kred_transposed_weight(shape, tile):
+    """The weight stored (k, m) -- dt_proj.weight (d_inner, dt_rank) used as its transpose -- and the views the backward passes: in =
+    ddelta in the scan's channel-slowest layout, out = the first rows of dx_dbl."""
+    vms = _vms()
+    b, m, k, L = shape
+    torch.manual_seed(m * k)
+    w_dt = (torch.randn(k, m, device=DEV) * k ** -0.5).bfloat16()          # (d_inner, dt_rank)
+    ddelta = torch.randn(k, b, L, device=DEV).bfloat16().permute(1, 0, 2)   # strides (L, b L, 1)
+    dx_dbl = torch.zeros(b, m + 32, L, device=DEV, dtype=torch.bfloat16)
+    vms.proj_kred(w_dt.t(), ddelta, dx_dbl[:, :m, :], tile=tile)
+    assert vms.lib().vms_last_kernel().decode() == "proj_kred_t"
+    want = w_dt.t().double() @ ddelta.double()
+    assert (dx_dbl[:, :m, :].double() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() * 1.01 + 1e-6
+    assert dx_dbl[:, m:, :].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("shape", [(8, 96, 1024, 8192), (2, 80, 768, 3136), (1, 56, 384, 136)])
+def test_proj_kred_dual(shape):
+    """Two problems of one shape in one launch == the two single launches, bit for bit."""
+    vms = _vms()
+    b, m, k, L = shape
+    torch.manual_seed(7)
+    ws = [(torch.randn(m, k, device=DEV) * k ** -0.5).bfloat16() for _ in range(2)]
+    xs = [torch.randn(b, k, L, device=DEV).bfloat16() for _ in range(2)]
+    single = [torch.empty(b, m, L, device=DEV, dtype=torch.bfloat16) for _ in range(2)]
+    for w, x, o in zip(ws, xs, single):
+        vms.proj_kred(w, x, o)
+    dual = [torch.empty(b, m, L, device=DEV, dtype=torch.bfloat16) for _ in range(2)]
+    vms.proj_kred(ws[0], xs[0], dual[0], ws[1], xs[1], dual[1])
+    assert vms.lib().vms_last_kernel().decode() == "proj_kred+dual"
+    for o, d2 in zip(single, dual):
+        assert torch.equal(o, d2)
+    ext = vms.ext()
+    if ext is not None:
+        xa, xb = ext.x_proj_dual(ws[0], xs[0], ws[1], xs[1], True)
+        assert torch.equal(xa, single[0]) and torch.equal(xb, single[1])
+        la, lb = ext.x_proj_dual(ws[0], xs[0], ws[1], xs[1], False)      # the library's GEMMs: same values to the output format's rounding
+        assert (la.float() - xa.float()).abs().max().item() <= 2.0 ** -7 * xa.float().abs().max().item()
+
+
+def test_proj_kred_checks():
+    vms = _vms()
+    w = torch.randn(48, 128, device=DEV).bfloat16()
+    x = torch.randn(1, 128, 64, device=DEV).bfloat16()
+    assert vms.proj_kred_eligible(w, x, torch.empty(1, 48, 64, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError):   # fp32 is left to the library GEMM
+        vms.proj_kred(w.float(), x.float(), torch.empty(1, 48, 64, device=DEV))
+    with pytest.raises(RuntimeError):   # m > 96
+        vms.proj_kred(torch.randn(112, 128, device=DEV).bfloat16(), x, torch.empty(1, 112, 64, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError):   # seqlen % 8
+        vms.proj_kred(w, x[:, :, :60].contiguous(), torch.empty(1, 48, 60, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError):   # a weight view with no unit stride
+        vms.proj_kred(torch.randn(48, 256, device=DEV).bfloat16()[:, ::2], x, torch.empty(1, 48, 64, device=DEV, dtype=torch.bfloat16))
+    P = vms.ProjKredParams()            # the library's own checks (status code + message)
+    assert vms.lib().vms_proj_kred(None, None) != 0
+    P.batch, P.m, P.k, P.seqlen, P.dtype = 1, 200, 128, 64, vms.dtype_code(x)
+    P.w, P.inp, P.out = w.data_ptr(), x.data_ptr(), x.data_ptr()
+    import ctypes
+    assert vms.lib().vms_proj_kred(ctypes.byref(P), None) != 0 and b"m <= 96" in vms.lib().vms_last_error()
+
+
 @pytest.mark.parametrize("shape", [(2, 640, 256, 16), (2, 1024, 96, 8), (1, 2304, 512, 16), (2, 200, 768, 16)])
 @pytest.mark.parametrize("variant", ["fused_tail", "mfma_proj", "both"])
 @pytest.mark.parametrize("reverse", [False, True])
@@ -136,8 +224,11 @@ def test_inner_node_variants_vs_library(shape, variant, reverse, monkeypatch):
     def run(env):
         for k in ("VMS_MFMA_PROJ", "VMS_NO_FUSED_TAIL"):
             monkeypatch.delenv(k, raising=False)
+        import mamba_ssm.ops.selective_scan_interface as ssi
+        monkeypatch.setattr(ssi, "_PROJ_KRED", "NO_KRED" not in env)   # the library-GEMM node also runs x_proj / dt_proj^T on the library
         for k in env:
-            monkeypatch.setenv(k, "1")
+            if k != "NO_KRED":
+                monkeypatch.setenv(k, "1")
         xz = xz0.clone().requires_grad_()
         for t in params:
             t.grad = None
@@ -151,7 +242,7 @@ def test_inner_node_variants_vs_library(shape, variant, reverse, monkeypatch):
     # the C-ABI level tests above assert the kernel names)
     env = {"fused_tail": (), "mfma_proj": ("VMS_MFMA_PROJ", "VMS_NO_FUSED_TAIL"), "both": ("VMS_MFMA_PROJ",)}[variant]
     got = run(env)
-    want = run(("VMS_NO_FUSED_TAIL",))
+    want = run(("VMS_NO_FUSED_TAIL", "NO_KRED"))
     names = ["out", "dxz", "dconv_w", "dconv_b", "dx_proj_w", "ddt_proj_w", "dA", "dD", "dbias"]
     for n, a, w in zip(names, got, want):
         err = (a - w).abs().max().item() / max(w.abs().max().item(), 1e-6)

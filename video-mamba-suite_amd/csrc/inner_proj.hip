@@ -664,6 +664,153 @@ __global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_co
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// proj_kred:  out[b][m][l] = sum_{k < K} W[m][k] in[b][k][l]     m <= 96 rows, K = the channel count (hundreds .. thousands)
+// ---------------------------------------------------------------------------------------------------------------------
+// The two skinny products of the inner node whose CONTRACTION runs over the channels: forward  x_dbl = x_proj.weight @ conv1d_out
+// (SSI:181: m = dt_rank + 2 d_state), backward  dx_dbl[:R] = dt_proj.weight^T @ ddelta (SSI:276: m = dt_rank).  One pass over the
+// (batch, channels, seqlen) activation, an output a tenth of its size: a pure HBM stream with the matrix cores attached, which
+// the library's general kernels run at 1.7-2.5x the memory floor for these shapes (profiles/r04_proj_kred.md).
+// A workgroup owns TL = 64 / 128 / 256 positions of one batch entry and walks the channels 64 at a time: the activation block
+// (64 channels x TL positions, full 128-byte lines) and the weight block (m x 64) go global -> registers -> LDS once per
+// workgroup; the 4 waves split the tile 2 (position halves) x 2 (row halves), the activation block becomes the MFMA B operand
+// through ds_read_b64_tr_b16 (the channels are its STRIDED axis), the weight block the A operand -- by 16-byte reads when it is
+// stored (m, k) with k contiguous (x_proj.weight), by transposing reads when it is stored (k, m) (dt_proj.weight used as its
+// transpose: WT).  fp32 accumulators (16x16x32 MFMA) stay in registers over the whole channel loop; results leave as 16-bit rows.
+// A second problem of the same shape (w2 / in2 / out2: the other direction of a bidirectional block) rides in the same grid.
+template <typename T, int MH, int NL, bool WT>
+__global__ __launch_bounds__(kPT, (NL <= 2 ? 4 : NL <= 4 ? 3 : 2)) void proj_kred_kernel(const vms_proj_kred_params p) {
+    constexpr int TL = 32 * NL;                       // positions per workgroup: 2 halves x NL 16-wide blocks
+    constexpr int KB = 64;                            // channels per step
+    constexpr int INP = TL == 64 ? 72 : TL + 16;      // pitch of the activation block, elements: 4 consecutive rows x 32 bytes on distinct banks
+    constexpr int MP = 32 * MH;                       // rows padded: 2 halves x MH 16-row blocks
+    constexpr int WP = WT ? MP + 8 : KB + 8;          // pitch of the weight block, elements
+    constexpr int PPR = TL / 8, RPP = kPT / PPR;      // activation block: 16-byte pieces per row, rows per pass of the workgroup (NL passes)
+    constexpr int PW = MP / 8;                        // WT: pieces per k row of the weight block
+    typedef __attribute__((address_space(3))) short lds_s16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int wl = wave & 1, wm = wave >> 1;
+    const int dir = (int)blockIdx.z >= p.batch ? 1 : 0, b = (int)blockIdx.z - dir * p.batch;
+    const int L = p.seqlen, K = p.k, M = p.m;
+    const int l0 = blockIdx.x * TL;
+    const T* const in_b = static_cast<const T*>(dir ? p.in2 : p.in) + (int64_t)b * p.in_batch_stride;
+    T* const out_b = static_cast<T*>(dir ? p.out2 : p.out) + (int64_t)b * p.out_batch_stride;
+    lds_s16* const in_lds = (lds_s16*)reinterpret_cast<short*>(smem);                      // [KB][INP]
+    lds_s16* const w_lds = in_lds + KB * INP;                                              // [MP][WP] or, WT, [KB][WP]
+
+    // Every load of the loop goes through a buffer resource with an out-of-range offset for what must not be read (channels
+    // beyond K, positions beyond seqlen, blocks beyond the last): such loads return 0 and touch no memory, so no load sits under a
+    // branch and the compiler counts them -- the blocks two steps ahead stay in flight across the barriers (s_waitcnt vmcnt(N)).
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_b), 0, (int)(((int64_t)(K - 1) * p.in_k_stride + L) * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(static_cast<const T*>(dir ? p.w2 : p.w)), 0, (int)(((int64_t)(M - 1) * p.w_row_stride + (int64_t)(K - 1) * p.w_k_stride + 1) * 2), kPBufFlags);
+    constexpr int kOOB = -1;
+    struct Stage { s16x8 i[NL], w[MH]; };
+    const int ipc = tid % PPR, irow = tid / PPR;
+    auto stage_load = [&](Stage& st, int kb) __attribute__((always_inline)) {
+        const int l = l0 + 8 * ipc;
+#pragma unroll
+        for (int ps = 0; ps < NL; ++ps) {
+            const int k = kb * KB + irow + RPP * ps;
+            st.i[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rs, k < K && l < L ? (int)(((int64_t)k * p.in_k_stride + l) * 2) : kOOB, 0, 0));
+        }
+#pragma unroll
+        for (int ps = 0; ps < MH; ++ps) {
+            if (WT) {     // row k of the block = 8 PW consecutive m
+                const int idx = tid + kPT * ps, rk = idx / PW, m = 8 * (idx % PW), k = kb * KB + rk;
+                st.w[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, k < K && m < M ? (int)(((int64_t)k * p.w_k_stride + m) * 2) : kOOB, 0, 0));
+            } else {      // row m of the block = 64 consecutive k
+                const int m = (tid >> 3) + 32 * ps, k = kb * KB + 8 * (tid & 7);
+                st.w[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, m < M && k < K ? (int)(((int64_t)m * p.w_row_stride + k) * 2) : kOOB, 0, 0));
+            }
+        }
+    };
+    auto stage_store = [&](const Stage& st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < NL; ++ps)
+            *reinterpret_cast<lds_s16x8*>(in_lds + (irow + RPP * ps) * INP + 8 * ipc) = st.i[ps];
+#pragma unroll
+        for (int ps = 0; ps < MH; ++ps) {
+            if (WT) {
+                const int idx = tid + kPT * ps;
+                *reinterpret_cast<lds_s16x8*>(w_lds + (idx / PW) * WP + 8 * (idx % PW)) = st.w[ps];
+            } else {
+                *reinterpret_cast<lds_s16x8*>(w_lds + ((tid >> 3) + 32 * ps) * WP + 8 * (tid & 7)) = st.w[ps];
+            }
+        }
+    };
+
+    f32x4 acc[MH][NL];
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) acc[mh][nl] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposing reads (see proj_apply): lane i of a 16-lane group supplies row i / 4, columns 4 (i % 4) .. + 3 of a [4][16] block and
+    // receives column i of its 4 rows.  16x16x32 operands: lane -> (row / column lane & 15, k = 8 (lane >> 4) .. + 7)
+    const lds_s16* const tb = in_lds + (8 * g16 + (i16 >> 2)) * INP + wl * (TL / 2) + 4 * (i16 & 3);
+    const int m0w = wm * 16 * MH;
+    const lds_s16* const ta = WT ? w_lds + (8 * g16 + (i16 >> 2)) * WP + m0w + 4 * (i16 & 3) : w_lds + (m0w + i16) * WP + 8 * g16;
+
+    auto compute = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KB / 32; ++s) {
+            s16x8 af[MH];
+#pragma unroll
+            for (int mh = 0; mh < MH; ++mh) {
+                if (WT) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s) * WP + 16 * mh));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(ta + (32 * s + 4) * WP + 16 * mh));
+                    af[mh] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    af[mh] = *reinterpret_cast<const lds_s16x8*>(ta + 16 * mh * WP + 32 * s);
+                }
+            }
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s) * INP + 16 * nl));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(tb + (32 * s + 4) * INP + 16 * nl));
+                const s16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int mh = 0; mh < MH; ++mh) acc[mh][nl] = Mfma16<T>::run(af[mh], bf, acc[mh][nl]);
+            }
+        }
+    };
+
+    const int nkb = (K + KB - 1) / KB;
+    Stage sa, sb;     // blocks kb and kb + 1: two steps of requests in flight
+    stage_load(sa, 0);
+    stage_load(sb, 1);
+    for (int kb = 0; kb < nkb; kb += 2) {
+        stage_store(sa);
+        __syncthreads();          // blocks kb are in LDS
+        stage_load(sa, kb + 2);
+        compute();
+        __syncthreads();          // every wave has read blocks kb
+        if (kb + 1 < nkb) {       // (workgroup-uniform; no load under it)
+            stage_store(sb);
+            __syncthreads();
+        }
+        stage_load(sb, kb + 3);
+        if (kb + 1 < nkb) {
+            compute();
+            __syncthreads();
+        }
+    }
+    // C layout: column = lane & 15 (position), row = 4 (lane >> 4) + register (output row)
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = m0w + 16 * mh + 4 * g16 + v, l = l0 + wl * (TL / 2) + 16 * nl + i16;
+                if (m < M && l < L) out_b[(int64_t)m * p.out_row_stride + l] = static_cast<T>(acc[mh][nl][v]);
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -727,6 +874,47 @@ static int dispatch_wgrad(const vms_proj_wgrad_params& p, hipStream_t stream) {
         case 3: return launch_wgrad<T, 3>(p, stream);
         default: return launch_wgrad<T, 4>(p, stream);
     }
+}
+
+template <typename T, int MH, int NL, bool WT>
+static int launch_kred(const vms_proj_kred_params& p, hipStream_t stream) {
+    constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = WT ? MP + 8 : KB + 8;
+    const int ndir = p.in2 ? 2 : 1;
+    const dim3 grid((p.seqlen + TL - 1) / TL, 1, p.batch * ndir), block(kPT);
+    const size_t smem = (size_t)KB * INP * 2 + (size_t)(WT ? KB : MP) * WP * 2;
+    hipLaunchKernelGGL((proj_kred_kernel<T, MH, NL, WT>), grid, block, smem, stream, p);
+    VMS_LAUNCH_CHECK();
+    set_last_kernel(ndir == 2 ? (WT ? "proj_kred_t+dual" : "proj_kred+dual") : (WT ? "proj_kred_t" : "proj_kred"));
+    return VMS_OK;
+}
+
+template <typename T, int MH, bool WT>
+static int dispatch_kred_tile(const vms_proj_kred_params& p, hipStream_t stream) {
+    // 128 positions per workgroup once that still gives every CU 1.5 workgroups, else 64 (the weight block is re-read from L2 once
+    // per tile: 1.5x the activation's bytes at 64 positions, 0.75x at 128); 256 measured slower than 128 on every grid that allows
+    // it (one workgroup per CU: (8, 1024, 8192) both directions 59 vs 53 us; profiles/r04_proj_kred.md) and is kept as a knob (`tile`)
+    const int ndir = p.in2 ? 2 : 1;
+    int tile = p.tile;
+    if (tile != 64 && tile != 128 && tile != 256)
+        tile = 2 * (int64_t)p.batch * ndir * ((p.seqlen + 127) / 128) >= 3 * (int64_t)device_cu_count() ? 128 : 64;
+    switch (tile) {
+        case 256: return launch_kred<T, MH, 8, WT>(p, stream);
+        case 128: return launch_kred<T, MH, 4, WT>(p, stream);
+        default: return launch_kred<T, MH, 2, WT>(p, stream);
+    }
+}
+
+template <typename T>
+static int dispatch_kred(const vms_proj_kred_params& p, hipStream_t stream) {
+    const bool wt = p.w_k_stride != 1;
+    const int mh = ((p.m + 15) / 16 + 1) / 2;
+#define VMS_KRED(MH_) (wt ? dispatch_kred_tile<T, MH_, true>(p, stream) : dispatch_kred_tile<T, MH_, false>(p, stream))
+    switch (mh) {
+        case 1: return VMS_KRED(1);
+        case 2: return VMS_KRED(2);
+        default: return VMS_KRED(3);
+    }
+#undef VMS_KRED
 }
 
 template <typename T, int KS>
@@ -820,6 +1008,27 @@ extern "C" int vms_proj_wgrad(const vms_proj_wgrad_params* pp, void* stream) {
     return p.dtype == VMS_BF16 ? dispatch_wgrad<bf16_t>(p, s) : dispatch_wgrad<f16_t>(p, s);
 }
 
+extern "C" int vms_proj_kred(const vms_proj_kred_params* pp, void* stream) {
+    VMS_CHECK(pp != nullptr, "null parameter block");
+    const vms_proj_kred_params& p = *pp;
+    VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_kred: 16-bit activations only (bf16 / fp16)");
+    VMS_CHECK(p.batch > 0 && p.k > 0 && p.seqlen > 0, "empty problem");
+    VMS_CHECK(p.m >= 1 && p.m <= 96, "proj_kred: 1 <= m <= 96");
+    VMS_CHECK(p.w && p.in && p.out, "w, in and out are required");
+    VMS_CHECK((p.w2 != nullptr) == (p.in2 != nullptr) && (p.in2 != nullptr) == (p.out2 != nullptr), "proj_kred: w2, in2 and out2 come together");
+    VMS_CHECK(p.seqlen % 8 == 0 && p.in_batch_stride % 8 == 0 && p.in_k_stride % 8 == 0 && aligned16(p.in) && (!p.in2 || aligned16(p.in2)),
+              "proj_kred: seqlen and the strides of in (elements) must be multiples of 8, in 16-byte aligned");
+    // the weight moves in 16-byte pieces along its contiguous axis: (m, k) with k contiguous, or (k, m) with m contiguous
+    VMS_CHECK((p.w_k_stride == 1 && p.w_row_stride % 8 == 0 && p.k % 8 == 0) || (p.w_row_stride == 1 && p.w_k_stride % 8 == 0 && p.m % 8 == 0),
+              "proj_kred: w needs a unit stride along k (k and the row stride multiples of 8) or along m (m and the k stride multiples of 8)");
+    VMS_CHECK(aligned16(p.w) && (!p.w2 || aligned16(p.w2)), "proj_kred: w must be 16-byte aligned");
+    VMS_CHECK(((int64_t)(p.k - 1) * p.in_k_stride + p.seqlen) * 2 < ((int64_t)1 << 31) && p.in_k_stride >= 0 && p.w_row_stride >= 0 && p.w_k_stride >= 0 &&
+                  ((int64_t)(p.m - 1) * p.w_row_stride + (int64_t)(p.k - 1) * p.w_k_stride + 1) * 2 < ((int64_t)1 << 31),
+              "proj_kred: a batch entry of in and w must each span < 2 GiB (one buffer resource each), strides >= 0");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return p.dtype == VMS_BF16 ? dispatch_kred<bf16_t>(p, s) : dispatch_kred<f16_t>(p, s);
+}
+extern "C" int vms_sizeof_proj_kred_params(void) { return (int)sizeof(vms_proj_kred_params); }
 extern "C" int vms_sizeof_proj_apply_params(void) { return (int)sizeof(vms_proj_apply_params); }
 extern "C" int vms_sizeof_proj_wgrad_params(void) { return (int)sizeof(vms_proj_wgrad_params); }
 

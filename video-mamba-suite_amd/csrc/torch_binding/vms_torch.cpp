@@ -551,6 +551,50 @@ void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw) {
     call("vms_proj_wgrad", vms_proj_wgrad, P, p);
 }
 
+// out[b, m, l] = sum_k w[m, k] in[b, k, l]  (vms_hip.h vms_proj_kred): x_dbl = x_proj_w @ conv_out, dx_dbl[:R] = dt_proj_w^T @ ddelta
+bool proj_kred_eligible(const Tensor& w, const Tensor& in, const Tensor& out) {
+    if (!(proj_ok16(in) && out.is_cuda() && out.dim() == 3 && out.stride(2) == 1 && out.scalar_type() == in.scalar_type() && w.is_cuda() &&
+          w.dim() == 2 && w.scalar_type() == in.scalar_type()))
+        return false;
+    const int64_t m = w.size(0), k = w.size(1);
+    if (!(m >= 1 && m <= 96 && in.size(1) == k && out.size(0) == in.size(0) && out.size(1) == m && out.size(2) == in.size(2))) return false;
+    if (reinterpret_cast<uintptr_t>(w.data_ptr()) & 15) return false;
+    if (((k - 1) * in.stride(1) + in.size(2)) * 2 >= ((int64_t)1 << 31)) return false;   // a batch entry is addressed through one buffer resource
+    return (w.stride(1) == 1 && w.stride(0) % 8 == 0 && k % 8 == 0) || (w.stride(0) == 1 && w.stride(1) % 8 == 0 && m % 8 == 0);
+}
+void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT& w2, const OptT& in2, const OptT& out2, int64_t tile) {
+    TORCH_CHECK(proj_kred_eligible(w, in, out), "proj_kred: 16-bit w (m <= 96, k), in (batch, k, seqlen), out (batch, m, seqlen) of one dtype "
+                "expected; unit seqlen strides, seqlen / strides multiples of 8, 16-byte aligned, w contiguous along k or m");
+    vms_proj_kred_params P{};
+    P.batch = (int)in.size(0); P.m = (int)w.size(0); P.k = (int)w.size(1); P.seqlen = (int)in.size(2);
+    P.dtype = dtype_code(in); P.tile = (int)tile;
+    P.w = w.data_ptr(); P.in = in.data_ptr(); P.out = out.data_ptr();
+    P.w_row_stride = w.stride(0); P.w_k_stride = w.stride(1);
+    P.in_batch_stride = in.stride(0); P.in_k_stride = in.stride(1);
+    P.out_batch_stride = out.stride(0); P.out_row_stride = out.stride(1);
+    if (w2.has_value()) {
+        TORCH_CHECK(in2.has_value() && out2.has_value() && proj_kred_eligible(*w2, *in2, *out2) && w2->sizes() == w.sizes() &&
+                    in2->sizes() == in.sizes() && w2->strides() == w.strides() && in2->strides() == in.strides() && out2->strides() == out.strides(),
+                    "proj_kred: the second problem must have the first one's shapes, strides and dtype");
+        P.w2 = w2->data_ptr(); P.in2 = in2->data_ptr(); P.out2 = out2->data_ptr();
+    }
+    call("vms_proj_kred", vms_proj_kred, P, in);
+}
+// x_dbl of both directions of a bidirectional block as one launch (or two library GEMMs when the kernel declines)
+std::vector<Tensor> x_proj_dual(const Tensor& w_a, const Tensor& conv_out_a, const Tensor& w_b, const Tensor& conv_out_b, bool use_kred) {
+    c10::DeviceGuard guard(conv_out_a.device());
+    if (use_kred && conv_out_a.dim() == 3) {
+        Tensor xa = at::empty({conv_out_a.size(0), w_a.size(0), conv_out_a.size(2)}, conv_out_a.options());
+        Tensor xb = at::empty_like(xa);
+        if (proj_kred_eligible(w_a, conv_out_a, xa) && proj_kred_eligible(w_b, conv_out_b, xb) && w_a.sizes() == w_b.sizes() &&
+            w_a.strides() == w_b.strides() && conv_out_a.sizes() == conv_out_b.sizes() && conv_out_a.strides() == conv_out_b.strides()) {
+            proj_kred(w_a, conv_out_a, xa, w_b, conv_out_b, xb, 0);
+            return {xa, xb};
+        }
+    }
+    return {at::matmul(w_a, conv_out_a), at::matmul(w_b, conv_out_b)};
+}
+
 bool proj_conv_bwd_eligible(const Tensor& x, const Tensor& du_like, const Tensor& dx_dbl_like, const Tensor& w_x, const Tensor& conv_w,
                             const OptT& conv_b, const Tensor& dx) {
     const int64_t k = dx_dbl_like.size(1);
@@ -605,7 +649,14 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     // conv_out_given: this direction's conv1d output, already computed (both directions of a block by one conv_fwd_dual)
     Tensor conv_out = conv_out_given.has_value() ? *conv_out_given : conv_fwd(x, conv_w, conv_b, true, reverse, reverse_from);
     // x_dbl_given: x_proj_w @ conv_out, already computed (right behind the conv1d that wrote conv_out, while it is in the Infinity Cache)
-    Tensor x_dbl = x_dbl_given.has_value() ? *x_dbl_given : at::matmul(x_proj_w, conv_out);   // (b, R + 2N, l): rows R.. are B, the last N are C
+    Tensor x_dbl;                                                        // (b, R + 2N, l): rows R.. are B, the last N are C
+    if (x_dbl_given.has_value()) {
+        x_dbl = *x_dbl_given;
+    } else {
+        x_dbl = at::empty({conv_out.size(0), R + 2 * N, conv_out.size(2)}, conv_out.options());
+        if ((proj_flags & 16) && proj_kred_eligible(x_proj_w, conv_out, x_dbl)) proj_kred(x_proj_w, conv_out, x_dbl, OptT(), OptT(), OptT(), 0);
+        else at::matmul_out(x_dbl, x_proj_w, conv_out);
+    }
     Tensor delta;                                                        // (b, d, l) = dt_proj_w @ x_dbl[:, :R]
     {
         const Tensor dt_in = x_dbl.narrow(1, 0, R);
@@ -626,7 +677,7 @@ struct InnerBwd {
     OptT conv_b, D_, delta_bias_;
     PaddedBC bc;
     int64_t b, d, R, N, K2, n_scan, n_conv, n_proj;
-    bool acc, use_mfma_proj, mfma_wg, fused_tail, reverse;
+    bool acc, use_mfma_proj, use_kred, mfma_wg, fused_tail, reverse;
     int64_t reverse_from;
     at::ScalarType wdt;
 };
@@ -636,6 +687,7 @@ InnerBwd inner_bwd_begin(const Tensor& xz, const Tensor& conv_w, const OptT& con
                          const Tensor& delta, bool reverse, const OptT& dxz_into, int64_t reverse_from, bool wgrad_fp32, int64_t proj_flags) {
     InnerBwd I;
     I.use_mfma_proj = (proj_flags & 1) != 0;
+    I.use_kred = (proj_flags & 16) != 0;
     I.wdt = wgrad_fp32 ? at::kFloat : x_proj_w.scalar_type();   // the parameters' dtype: autograd has nothing to cast
     I.b = xz.size(0); I.d = conv_w.size(0); I.R = dt_proj_w.size(1); I.N = A.size(1);
     I.xz = xz; I.conv_w = conv_w; I.conv_b = conv_b; I.x_proj_w = x_proj_w; I.dt_proj_w = dt_proj_w; I.conv_out = conv_out; I.x_dbl = x_dbl;
@@ -693,7 +745,8 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
     }
     {   // (b, R, l) = W_dt^T ddelta, written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
         Tensor d_dt = dx_dbl.narrow(1, 0, R);
-        at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
+        if (I.use_kred && proj_kred_eligible(dt_proj_w.t(), ddelta, d_dt)) proj_kred(dt_proj_w.t(), ddelta, d_dt, OptT(), OptT(), OptT(), 0);
+        else at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
     }
     if (I.fused_tail) {
         // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
@@ -816,6 +869,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("inner_fwd", &inner_fwd, py::arg("xz"), py::arg("conv_w"), py::arg("conv_b"), py::arg("x_proj_w"), py::arg("dt_proj_w"), py::arg("A"),
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
           py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());
+    m.def("proj_kred", &proj_kred, py::arg("w"), py::arg("inp"), py::arg("out"), py::arg("w2") = py::none(), py::arg("inp2") = py::none(),
+          py::arg("out2") = py::none(), py::arg("tile") = 0);
+    m.def("x_proj_dual", &x_proj_dual);
     m.def("inner_bwd", &inner_bwd);
     m.def("inner_bwd_dual", &inner_bwd_dual);
     m.def("scan_bwd_dual", &scan_bwd_dual);

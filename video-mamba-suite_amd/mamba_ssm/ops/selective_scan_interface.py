@@ -166,6 +166,11 @@ def _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias):
     return ext
 
 
+# Bit 16 of proj_flags: x_dbl = x_proj.weight @ conv1d_out and dx_dbl[:R] = dt_proj.weight^T @ ddelta -- the node's two products
+# that contract over the channels -- as one streaming pass on the matrix cores (vms_proj_kred) instead of library GEMMs.
+_PROJ_KRED = os.environ.get("VMS_PROJ_KRED", "1") != "0"
+
+
 def _mfma_proj(d_inner=None, dt_rank=None):
     """proj_flags of the compiled node.  Bit 1: the node's small dt_proj products -- delta = W_dt x_dbl[:R] and its weight
     gradient -- on the hand-written matrix-core kernels (csrc/inner_proj.hip) instead of the library's GEMMs.  At the benchmark
@@ -180,7 +185,7 @@ def _mfma_proj(d_inner=None, dt_rank=None):
         mfma = env == "1"
     else:
         mfma = d_inner is not None and (d_inner % 256 != 0 or dt_rank % 64 != 0)
-    return (1 if mfma else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2)
+    return (1 if mfma else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2) | (16 if _PROJ_KRED else 0)
 
 
 def _for_backward(ctx):
@@ -635,7 +640,12 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         conv_outs = _dual_conv(xz, params[0], params[1], params[n], params[n + 1])
         # x_proj of both directions right behind it, while both outputs are (partly) in the 256 MB Infinity Cache: the second
         # direction's x_proj otherwise reads its operand from HBM after the first direction's scan (40 instead of 30 us)
-        x_dbls = [torch.matmul(params[i * n + 2], conv_outs[i]) if conv_outs[i] is not None else None for i in range(2)]
+        # (both as ONE launch of vms_proj_kred when the compiled binding is loaded)
+        ext = _vms.ext() if conv_outs[0] is not None else None
+        if ext is not None and hasattr(ext, "x_proj_dual"):
+            x_dbls = ext.x_proj_dual(params[2], conv_outs[0], params[n + 2], conv_outs[1], _PROJ_KRED)
+        else:
+            x_dbls = [torch.matmul(params[i * n + 2], conv_outs[i]) if conv_outs[i] is not None else None for i in range(2)]
         for i in range(2):
             cw, cb, xw, dw, A, D, dbias = params[i * n:(i + 1) * n]
             sub = _SubCtx()

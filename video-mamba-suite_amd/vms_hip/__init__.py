@@ -124,6 +124,15 @@ class ProjWgradParams(ctypes.Structure):
     )
 
 
+class ProjKredParams(ctypes.Structure):
+    _fields_ = (
+        [(n, _i32) for n in ("batch", "m", "k", "seqlen", "dtype", "tile")]
+        + [(n, _vp) for n in ("w", "inp", "out", "w2", "inp2", "out2")]
+        + [(n, _i64) for n in ("w_row_stride", "w_k_stride", "in_batch_stride", "in_k_stride", "out_batch_stride",
+                               "out_row_stride")]
+    )
+
+
 class ProjConvBwdParams(ctypes.Structure):
     _fields_ = (
         [(n, _i32) for n in ("batch", "dim", "k", "seqlen", "width", "dtype", "wdtype", "reverse", "reverse_from",
@@ -162,12 +171,13 @@ EXPORTS = (
     "vms_param_prep", "vms_sizeof_prep_params",
     "vms_causal_conv1d_fwd_dual", "vms_sizeof_conv_fwd_dual_params",
     "vms_selective_scan_bwd_dual", "vms_scan_bwd_dual_fused",
+    "vms_proj_kred", "vms_sizeof_proj_kred_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
 # VMS_SCAN_IMPL = generic | fast | pair | rows, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
 # per call, and travel in the parameter block.
-ABI_VERSION = 9   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
+ABI_VERSION = 10   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
 IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS = 0, 1, 2, 3, 4
 BUILD_EXPERIMENTAL = 1
 _IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS}
@@ -276,7 +286,8 @@ def lib():
                          ("conv_fwd", ConvFwdParams), ("conv_bwd", ConvBwdParams),
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
                          ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams),
-                         ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams), ("conv_fwd_dual", ConvFwdDualParams)):
+                         ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams), ("conv_fwd_dual", ConvFwdDualParams),
+                         ("proj_kred", ProjKredParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -730,6 +741,44 @@ def proj_wgrad(p, q, dw, tiles_per_wg=0):
     P.q_batch_stride, P.q_row_stride = q.stride(0), q.stride(1)
     P.dw_row_stride = dw.stride(0)
     _call("vms_proj_wgrad", P, p)
+
+
+def proj_kred_eligible(w, inp, out):
+    """Does vms_proj_kred take out[b, m, l] = sum_k w[m, k] inp[b, k, l]?  (16-bit tensors of one dtype, unit seqlen strides, seqlen
+    and the strides of inp multiples of 8, 16-byte aligned bases, m <= 96, w contiguous along k or along m in whole 16-byte pieces)"""
+    if not (inp.is_cuda and inp.dtype in (torch.bfloat16, torch.float16) and w.dtype == inp.dtype and out.dtype == inp.dtype
+            and inp.dim() == 3 and out.dim() == 3 and w.dim() == 2 and inp.stride(2) == 1 and out.stride(2) == 1):
+        return False
+    m, k = w.shape
+    if not (1 <= m <= 96 and tuple(inp.shape[1:2]) == (k,) and tuple(out.shape) == (inp.shape[0], m, inp.shape[2])):
+        return False
+    if inp.shape[2] % 8 or inp.stride(0) % 8 or inp.stride(1) % 8 or inp.data_ptr() % 16 or w.data_ptr() % 16:
+        return False
+    if ((k - 1) * inp.stride(1) + inp.shape[2]) * 2 >= 2 ** 31:   # a batch entry is addressed through one buffer resource
+        return False
+    return (w.stride(1) == 1 and w.stride(0) % 8 == 0 and k % 8 == 0) or (w.stride(0) == 1 and w.stride(1) % 8 == 0 and m % 8 == 0)
+
+
+def proj_kred(w, inp, out, w2=None, inp2=None, out2=None, tile=0):
+    """out[b, m, l] = sum_k w[m, k] inp[b, k, l]  (vms_hip.h vms_proj_kred: x_dbl = x_proj.weight @ conv1d_out, dx_dbl[:R] =
+    dt_proj.weight^T @ ddelta); w2 / inp2 / out2: a second problem of the same shape and strides in the same launch."""
+    if not proj_kred_eligible(w, inp, out):
+        raise RuntimeError("proj_kred: 16-bit w (m <= 96, k), inp (batch, k, seqlen), out (batch, m, seqlen) of one dtype expected; unit "
+                           "seqlen strides, seqlen / strides multiples of 8, 16-byte aligned, w contiguous along k or m")
+    P = ProjKredParams()
+    P.batch, P.k, P.seqlen = inp.shape
+    P.m = w.shape[0]
+    P.dtype, P.tile = dtype_code(inp), int(tile)
+    P.w, P.inp, P.out = _ptr(w), _ptr(inp), _ptr(out)
+    P.w_row_stride, P.w_k_stride = w.stride(0), w.stride(1)
+    P.in_batch_stride, P.in_k_stride = inp.stride(0), inp.stride(1)
+    P.out_batch_stride, P.out_row_stride = out.stride(0), out.stride(1)
+    if w2 is not None:
+        if not (proj_kred_eligible(w2, inp2, out2) and w2.shape == w.shape and inp2.shape == inp.shape and w2.stride() == w.stride()
+                and inp2.stride() == inp.stride() and out2.stride() == out.stride() and inp2.dtype == inp.dtype):
+            raise RuntimeError("proj_kred: the second problem must have the first one's shapes, strides and dtype")
+        P.w2, P.inp2, P.out2 = _ptr(w2), _ptr(inp2), _ptr(out2)
+    _call("vms_proj_kred", P, inp)
 
 
 def proj_conv_bwd(x, du, dx_dbl, w_x, conv_w, conv_b, dx, dconv_w, dconv_b, dw_x, reverse=False, reverse_from=0,
