@@ -399,6 +399,13 @@ typedef struct {
     int64_t w_row_stride, w_k_stride;
     int64_t in_batch_stride, in_k_stride;          /* elements; multiples of 8 */
     int64_t out_batch_stride, out_row_stride;
+    /* optional side job of the backward call (selective_scan_interface.py:258-271: dx_dbl[:, R:] = dB, dC): the fp32 sums the scan's
+     * backward left in its [zeroed] accumulators are rounded to `dtype` into the rows of `out` that FOLLOW the m product rows --
+     * out[b][m + g * cast_rows + n][l] = cast_src[g * cast_group_stride + b * cast_batch_stride + n * cast_row_stride + l],
+     * g < cast_groups, n < cast_rows (unit seqlen stride, 16-byte aligned rows).  NULL = no such rows.  cast_src2: the same for out2. */
+    const float *cast_src, *cast_src2;
+    int32_t cast_rows, cast_groups;
+    int64_t cast_group_stride, cast_batch_stride, cast_row_stride;
 } vms_proj_kred_params;
 int vms_proj_kred(const vms_proj_kred_params *p, void *stream);
 

@@ -176,6 +176,30 @@ def test_proj_kred_dual(shape):
         assert (la.float() - xa.float()).abs().max().item() <= 2.0 ** -7 * xa.float().abs().max().item()
 
 
+@pytest.mark.parametrize("shape", [(8, 64, 1024, 1024, 16), (2, 48, 768, 3136, 16), (1, 24, 384, 3152, 16), (3, 8, 200, 72, 4), (2, 32, 512, 264, 64)])
+@pytest.mark.parametrize("tile", [0, 64, 256])
+def test_proj_kred_cast_rows(shape, tile):
+    """The backward call's side job: the scan's fp32 dB / dC sums rounded into the rows of dx_dbl behind d_dt (both bindings)."""
+    vms = _vms()
+    b, R, d, L, N = shape
+    torch.manual_seed(R + d)
+    w_dt = (torch.randn(d, R, device=DEV) * d ** -0.5).bfloat16()
+    ddelta = torch.randn(d, b, L, device=DEV).bfloat16().permute(1, 0, 2)
+    dbc = torch.randn(2, b, N, L, device=DEV)                               # dB then dC, as the scan's backward leaves them
+    want_dt = (w_dt.t().double() @ ddelta.double())
+    for how in ("ctypes", "ext"):
+        dx_dbl = torch.full((b, R + 2 * N + 8, L), 7.0, device=DEV, dtype=torch.bfloat16)
+        if how == "ctypes":
+            vms.proj_kred(w_dt.t(), ddelta, dx_dbl[:, :R, :], tile=tile, cast_src=dbc)
+        else:
+            if vms.ext() is None:
+                continue
+            vms.ext().proj_kred(w_dt.t(), ddelta, dx_dbl[:, :R, :], tile=tile, cast_src=dbc)
+        assert (dx_dbl[:, :R, :].double() - want_dt).abs().max().item() <= 2.0 ** -8 * want_dt.abs().max().item() * 1.01 + 1e-6
+        assert torch.equal(dx_dbl[:, R:R + N, :], dbc[0].bfloat16()) and torch.equal(dx_dbl[:, R + N:R + 2 * N, :], dbc[1].bfloat16())
+        assert (dx_dbl[:, R + 2 * N:, :] == 7.0).all()
+
+
 def test_proj_kred_checks():
     vms = _vms()
     w = torch.randn(48, 128, device=DEV).bfloat16()

@@ -808,6 +808,22 @@ __global__ __launch_bounds__(kPT, (NL <= 2 ? 4 : NL <= 4 ? 3 : 2)) void proj_kre
                 const int m = m0w + 16 * mh + 4 * g16 + v, l = l0 + wl * (TL / 2) + 16 * nl + i16;
                 if (m < M && l < L) out_b[(int64_t)m * p.out_row_stride + l] = static_cast<T>(acc[mh][nl][v]);
             }
+    // side job: the rows that follow the product in `out` <- the scan backward's fp32 dB / dC sums of this tile's positions
+    const float* const cs = dir ? p.cast_src2 : p.cast_src;
+    if (cs) {
+        const int n_rows = p.cast_rows * p.cast_groups;
+        for (int idx = tid; idx < n_rows * (TL / 4); idx += kPT) {
+            const int r = idx / (TL / 4), l = l0 + 4 * (idx % (TL / 4));
+            if (l < L) {
+                const int g = r / p.cast_rows, n = r - g * p.cast_rows;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(cs + (int64_t)g * p.cast_group_stride + (int64_t)b * p.cast_batch_stride + (int64_t)n * p.cast_row_stride + l);
+                vec_t<T, 4> o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = static_cast<T>(v[e]);
+                *reinterpret_cast<vec_t<T, 4>*>(out_b + (int64_t)(M + r) * p.out_row_stride + l) = o;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1022,6 +1038,12 @@ extern "C" int vms_proj_kred(const vms_proj_kred_params* pp, void* stream) {
     VMS_CHECK((p.w_k_stride == 1 && p.w_row_stride % 8 == 0 && p.k % 8 == 0) || (p.w_row_stride == 1 && p.w_k_stride % 8 == 0 && p.m % 8 == 0),
               "proj_kred: w needs a unit stride along k (k and the row stride multiples of 8) or along m (m and the k stride multiples of 8)");
     VMS_CHECK(aligned16(p.w) && (!p.w2 || aligned16(p.w2)), "proj_kred: w must be 16-byte aligned");
+    VMS_CHECK(!p.cast_src2 || (p.cast_src && p.in2), "proj_kred: cast_src2 comes with cast_src and the second problem");
+    VMS_CHECK(!p.cast_src || (p.cast_rows > 0 && p.cast_groups > 0 && aligned16(p.cast_src) && (!p.cast_src2 || aligned16(p.cast_src2)) &&
+                              p.cast_group_stride % 4 == 0 && p.cast_batch_stride % 4 == 0 && p.cast_row_stride % 4 == 0 &&
+                              p.out_row_stride % 4 == 0 && p.out_batch_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(p.out) & 7) == 0 &&
+                              (!p.out2 || (reinterpret_cast<uintptr_t>(p.out2) & 7) == 0)),
+              "proj_kred: cast rows need cast_rows, cast_groups > 0, 16-byte aligned fp32 rows (strides multiples of 4) and 8-byte aligned rows of out");
     VMS_CHECK(((int64_t)(p.k - 1) * p.in_k_stride + p.seqlen) * 2 < ((int64_t)1 << 31) && p.in_k_stride >= 0 && p.w_row_stride >= 0 && p.w_k_stride >= 0 &&
                   ((int64_t)(p.m - 1) * p.w_row_stride + (int64_t)(p.k - 1) * p.w_k_stride + 1) * 2 < ((int64_t)1 << 31),
               "proj_kred: a batch entry of in and w must each span < 2 GiB (one buffer resource each), strides >= 0");

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kNormWaves* kWave) void norm_fwd_gen_kernel(const v
 
 // ---- backward, register resident ----------------------------------------------------------------------------
 // s = saved pre-norm sum (dtype TS), dy (TX), optional dres_out (TS) -> dx (TX), optional dres_in (TS),
-// dw_partial / db_partial [gridDim.x * kNormWaves][cols] fp32 (one row per wave, always fully written)
+// dw_partial / db_partial [gridDim.x][cols] fp32 (one row per workgroup, always fully written)
 template <typename TX, typename TS, bool RMS, int K>
 __global__ __launch_bounds__(kNormWaves* kWave) void norm_bwd_vec_kernel(const vms_norm_bwd_params q) {
     const vms_norm_params& p = q.f;
@@ -223,31 +223,55 @@ __global__ __launch_bounds__(kNormWaves* kWave) void norm_bwd_vec_kernel(const v
             }
         }
     }
-    const int64_t prow = (int64_t)blockIdx.x * kNormWaves + wave;
+    // the workgroup's four per-wave sums become ONE partial row (summed through LDS: a quarter of the partial bytes to write here
+    // and to sum afterwards -- (8, 3136, 768): 8,192 rows x 768 floats = 25 MB per array, more than a third of the kernel's traffic)
+    __shared__ float red[(kNormWaves - 1) * K * E * 64];
+    const int64_t prow = blockIdx.x;
+    auto emit = [&](float (&acc)[K][E], float* dst) __attribute__((always_inline)) {
+        if (wave > 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int c0 = (lane + 64 * k) * E;
-        if (c0 < N) {
-            st_chunk<float, E>(q.dw_partial + prow * N + c0, dwa[k]);
-            if (q.db_partial) st_chunk<float, E>(q.db_partial + prow * N + c0, dba[k]);
+            for (int k = 0; k < K; ++k)
+#pragma unroll
+                for (int e = 0; e < E; ++e) red[((wave - 1) * K * E + k * E + e) * 64 + lane] = acc[k][e];
         }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const int c0 = (lane + 64 * k) * E;
+                float o[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    o[e] = acc[k][e];
+#pragma unroll
+                    for (int w2 = 0; w2 < kNormWaves - 1; ++w2) o[e] += red[(w2 * K * E + k * E + e) * 64 + lane];
+                }
+                if (c0 < N) st_chunk<float, E>(dst + prow * N + c0, o);
+            }
+        }
+    };
+    emit(dwa, q.dw_partial);
+    if (q.db_partial) {      // (uniform)
+        __syncthreads();     // the first pass's reads of `red` are done
+        emit(dba, q.db_partial);
     }
 }
 
 template <typename TX, typename TS, bool RMS>
-__global__ __launch_bounds__(kNormWaves* kWave) void norm_bwd_gen_kernel(const vms_norm_bwd_params q) {
+__global__ __launch_bounds__(kWave) void norm_bwd_gen_kernel(const vms_norm_bwd_params q) {
     const vms_norm_params& p = q.f;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int N = p.cols;
     const float inv_n = 1.f / N;
     const float* w = static_cast<const float*>(p.weight);
-    const int64_t prow = (int64_t)blockIdx.x * kNormWaves + wave;
+    const int64_t prow = blockIdx.x;     // launched with ONE wave per workgroup: a partial row per workgroup, as the vector kernel leaves
+    (void)wave;
     for (int c = lane; c < N; c += 64) {
         q.dw_partial[prow * N + c] = 0.f;
         if (q.db_partial) q.db_partial[prow * N + c] = 0.f;
     }
-    for (int64_t row = prow; row < p.rows; row += (int64_t)gridDim.x * kNormWaves) {
+    for (int64_t row = prow; row < p.rows; row += (int64_t)gridDim.x) {
         const TS* s = static_cast<const TS*>(q.s) + row * q.s_row_stride;
         const TX* dy = static_cast<const TX*>(q.dy) + row * q.dy_row_stride;
         const TS* dro = q.dres_out ? static_cast<const TS*>(q.dres_out) + row * q.dres_out_row_stride : nullptr;
@@ -317,9 +341,9 @@ template <typename TX, typename TS, bool RMS>
 static int norm_bwd_launch(const vms_norm_bwd_params& q, bool vec, hipStream_t s) {
     constexpr int E = 16 / sizeof(TX);
     const vms_norm_params& p = q.f;
-    dim3 grid(q.n_partials / kNormWaves), block(kNormWaves * kWave);
+    dim3 grid(q.n_partials), block(kNormWaves * kWave);
     const int pieces = (p.cols / E + 63) / 64;
-    if (!vec || pieces > 4) hipLaunchKernelGGL((norm_bwd_gen_kernel<TX, TS, RMS>), grid, block, 0, s, q);
+    if (!vec || pieces > 4) hipLaunchKernelGGL((norm_bwd_gen_kernel<TX, TS, RMS>), grid, dim3(kWave), 0, s, q);
     else if (pieces <= 1) hipLaunchKernelGGL((norm_bwd_vec_kernel<TX, TS, RMS, 1>), grid, block, 0, s, q);
     else if (pieces <= 2) hipLaunchKernelGGL((norm_bwd_vec_kernel<TX, TS, RMS, 2>), grid, block, 0, s, q);
     else hipLaunchKernelGGL((norm_bwd_vec_kernel<TX, TS, RMS, 4>), grid, block, 0, s, q);
@@ -369,7 +393,7 @@ extern "C" int vms_layer_norm_fwd(const vms_norm_params* pp, void* stream) {
 
 extern "C" int vms_layer_norm_bwd_partials(const vms_norm_params* pp) {
     if (pp == nullptr || pp->rows <= 0) return 0;
-    return norm_grid(pp->rows) * kNormWaves;
+    return norm_grid(pp->rows);     // one partial row per workgroup
 }
 
 extern "C" int vms_layer_norm_bwd(const vms_norm_bwd_params* qq, void* stream) {

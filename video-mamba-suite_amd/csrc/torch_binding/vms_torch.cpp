@@ -562,7 +562,9 @@ bool proj_kred_eligible(const Tensor& w, const Tensor& in, const Tensor& out) {
     if (((k - 1) * in.stride(1) + in.size(2)) * 2 >= ((int64_t)1 << 31)) return false;   // a batch entry is addressed through one buffer resource
     return (w.stride(1) == 1 && w.stride(0) % 8 == 0 && k % 8 == 0) || (w.stride(0) == 1 && w.stride(1) % 8 == 0 && m % 8 == 0);
 }
-void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT& w2, const OptT& in2, const OptT& out2, int64_t tile) {
+// cast_src: fp32 (groups, batch, rows, seqlen), rounded into the groups * rows rows that follow out's m rows in its parent tensor
+void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT& w2, const OptT& in2, const OptT& out2, int64_t tile,
+               const OptT& cast_src = OptT()) {
     TORCH_CHECK(proj_kred_eligible(w, in, out), "proj_kred: 16-bit w (m <= 96, k), in (batch, k, seqlen), out (batch, m, seqlen) of one dtype "
                 "expected; unit seqlen strides, seqlen / strides multiples of 8, 16-byte aligned, w contiguous along k or m");
     vms_proj_kred_params P{};
@@ -577,6 +579,13 @@ void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT&
                     in2->sizes() == in.sizes() && w2->strides() == w.strides() && in2->strides() == in.strides() && out2->strides() == out.strides(),
                     "proj_kred: the second problem must have the first one's shapes, strides and dtype");
         P.w2 = w2->data_ptr(); P.in2 = in2->data_ptr(); P.out2 = out2->data_ptr();
+    }
+    if (cast_src.has_value()) {
+        const Tensor& c = *cast_src;
+        TORCH_CHECK(c.scalar_type() == at::kFloat && c.dim() == 4 && c.stride(3) == 1 && c.size(1) == in.size(0) && c.size(3) == in.size(2),
+                    "proj_kred: cast_src must be fp32 (groups, batch, rows, seqlen) with a unit seqlen stride");
+        P.cast_src = c.data_ptr<float>(); P.cast_groups = (int)c.size(0); P.cast_rows = (int)c.size(2);
+        P.cast_group_stride = c.stride(0); P.cast_batch_stride = c.stride(1); P.cast_row_stride = c.stride(2);
     }
     call("vms_proj_kred", vms_proj_kred, P, in);
 }
@@ -673,7 +682,7 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
 
 // The node's backward around its scan: what is decided and allocated before the scan (begin) and everything after it (finish).
 struct InnerBwd {
-    Tensor xz, x, z, dxz, dx, dz, Bv, Cv, dt_in, zeros, conv_w, x_proj_w, dt_proj_w, conv_out, x_dbl, A;
+    Tensor xz, x, z, dxz, dx, dz, Bv, Cv, dt_in, zeros, zeros_spare, conv_w, x_proj_w, dt_proj_w, conv_out, x_dbl, A;
     OptT conv_b, D_, delta_bias_;
     PaddedBC bc;
     int64_t b, d, R, N, K2, n_scan, n_conv, n_proj;
@@ -684,7 +693,8 @@ struct InnerBwd {
 
 InnerBwd inner_bwd_begin(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                          const Tensor& A, const OptT& D_, const OptT& delta_bias_, const Tensor& conv_out, const Tensor& x_dbl,
-                         const Tensor& delta, bool reverse, const OptT& dxz_into, int64_t reverse_from, bool wgrad_fp32, int64_t proj_flags) {
+                         const Tensor& delta, bool reverse, const OptT& dxz_into, int64_t reverse_from, bool wgrad_fp32, int64_t proj_flags,
+                         bool zeros_for_two = false, const OptT& zeros_given = OptT()) {
     InnerBwd I;
     I.use_mfma_proj = (proj_flags & 1) != 0;
     I.use_kred = (proj_flags & 16) != 0;
@@ -706,7 +716,17 @@ InnerBwd inner_bwd_begin(const Tensor& xz, const Tensor& conv_w, const OptT& con
     I.n_proj = I.mfma_wg ? (I.R + (I.R + 2 * I.N)) * I.d : 0;
     I.K2 = I.R + 2 * I.N;
     I.fused_tail = (proj_flags & 2) && proj_conv_bwd_eligible(I.x, conv_out, x_dbl, x_proj_w, conv_w, conv_b, I.dx);
-    I.zeros = at::zeros({I.n_scan + I.n_conv + I.n_proj + (I.fused_tail ? I.K2 * I.d : 0)}, xz.options().dtype(at::kFloat));
+    // zeros_for_two: ONE fill for both directions of a bidirectional block (the second direction's begin takes `zeros_spare`)
+    const int64_t n_zero = I.n_scan + I.n_conv + I.n_proj + (I.fused_tail ? I.K2 * I.d : 0), n_pad = (n_zero + 63) / 64 * 64;   // 256-byte slices
+    if (zeros_given.has_value() && zeros_given->numel() >= n_zero) {
+        I.zeros = zeros_given->narrow(0, 0, n_zero);
+    } else if (zeros_for_two) {
+        const Tensor both = at::zeros({2 * n_pad}, xz.options().dtype(at::kFloat));
+        I.zeros = both.narrow(0, 0, n_zero);
+        I.zeros_spare = both.narrow(0, n_pad, n_pad);
+    } else {
+        I.zeros = at::zeros({n_zero}, xz.options().dtype(at::kFloat));
+    }
     I.bc = pad_bc(I.Bv, I.Cv, reverse, reverse_from > 0);
     return I;
 }
@@ -720,9 +740,12 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
     const auto wdt = I.wdt;
     Tensor dconv_out = *g[0], ddelta = *g[1];
     Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
-    // dB and dC sit back to back in the zero-filled buffer (scan_bwd carves dA, dB, dC, ...): one cast kernel for both
-    dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)})
-        .copy_(zeros.narrow(0, I.A.numel(), 2 * I.Bv.numel()).view({2, b, N, dx_dbl.size(2)}).permute({1, 0, 2, 3}));
+    // dB and dC sit back to back in the zero-filled buffer (scan_bwd carves dA, dB, dC, ...): rounded into their rows of dx_dbl by the
+    // kernel that writes its first R rows (vms_proj_kred's cast rows), or by one cast kernel for both
+    const Tensor dbc = zeros.narrow(0, I.A.numel(), 2 * I.Bv.numel()).view({2, b, N, dx_dbl.size(2)});
+    Tensor d_dt = dx_dbl.narrow(1, 0, R);                                                   // (b, R, l) = W_dt^T ddelta
+    const bool kred_dt = I.use_kred && proj_kred_eligible(dt_proj_w.t(), ddelta, d_dt) && dx_dbl.size(2) % 4 == 0;
+    if (!kred_dt) dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)}).copy_(dbc.permute({1, 0, 2, 3}));
     Tensor ddt_proj_w, dx_proj_w;
     if (I.mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
         Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({R, d});                  // (R, d) = ddt_proj_w^T
@@ -743,11 +766,9 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
             ddt_proj_w = at::sum(at::matmul(ddelta, dt_in.transpose(1, 2)), {0}, false, wdt);   // (d, R)
         }
     }
-    {   // (b, R, l) = W_dt^T ddelta, written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
-        Tensor d_dt = dx_dbl.narrow(1, 0, R);
-        if (I.use_kred && proj_kred_eligible(dt_proj_w.t(), ddelta, d_dt)) proj_kred(dt_proj_w.t(), ddelta, d_dt, OptT(), OptT(), OptT(), 0);
-        else at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
-    }
+    // written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
+    if (kred_dt) proj_kred(dt_proj_w.t(), ddelta, d_dt, OptT(), OptT(), OptT(), 0, dbc);
+    else at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
     if (I.fused_tail) {
         // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
         Tensor dwx = zeros.narrow(0, n_scan + n_conv + n_proj, K2 * d).view({K2, d});
@@ -801,9 +822,9 @@ std::vector<OptT> inner_bwd_dual(const Tensor& dout_, const Tensor& xz, const st
     const Tensor dout = dout_.stride(-1) == 1 ? dout_ : dout_.contiguous();
     auto T = [](const OptT& t) -> const Tensor& { TORCH_CHECK(t.has_value(), "inner_bwd_dual: missing tensor"); return *t; };
     InnerBwd Ia = inner_bwd_begin(xz, T(a[0]), a[1], T(a[2]), T(a[3]), T(a[4]), a[5], a[6], T(a[7]), T(a[8]), T(a[9]), /*reverse=*/false,
-                                  OptT(), 0, wgrad_fp32, proj_flags);
+                                  OptT(), 0, wgrad_fp32, proj_flags, /*zeros_for_two=*/true);
     InnerBwd Ib = inner_bwd_begin(xz, T(b[0]), b[1], T(b[2]), T(b[3]), T(b[4]), b[5], b[6], T(b[7]), T(b[8]), T(b[9]), /*reverse=*/true,
-                                  Ia.dxz, 0, wgrad_fp32, proj_flags);
+                                  Ia.dxz, 0, wgrad_fp32, proj_flags, false, Ia.zeros_spare);
     std::vector<std::vector<OptT>> g = scan_bwd_dual(
         Ia.conv_out, T(a[9]), Ia.A, Ia.bc.B, Ia.bc.C, Ia.D_, Ia.delta_bias_, a[10], T(a[11]), Ia.zeros.narrow(0, 0, Ia.n_scan), Ia.Bv, Ia.Cv,
         Ib.conv_out, T(b[9]), Ib.A, Ib.bc.B, Ib.bc.C, Ib.D_, Ib.delta_bias_, b[10], T(b[11]), Ib.zeros.narrow(0, 0, Ib.n_scan), Ib.Bv, Ib.Cv,
@@ -870,7 +891,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
           py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());
     m.def("proj_kred", &proj_kred, py::arg("w"), py::arg("inp"), py::arg("out"), py::arg("w2") = py::none(), py::arg("inp2") = py::none(),
-          py::arg("out2") = py::none(), py::arg("tile") = 0);
+          py::arg("out2") = py::none(), py::arg("tile") = 0, py::arg("cast_src") = py::none());
     m.def("x_proj_dual", &x_proj_dual);
     m.def("inner_bwd", &inner_bwd);
     m.def("inner_bwd_dual", &inner_bwd_dual);

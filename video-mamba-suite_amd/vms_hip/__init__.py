@@ -130,6 +130,9 @@ class ProjKredParams(ctypes.Structure):
         + [(n, _vp) for n in ("w", "inp", "out", "w2", "inp2", "out2")]
         + [(n, _i64) for n in ("w_row_stride", "w_k_stride", "in_batch_stride", "in_k_stride", "out_batch_stride",
                                "out_row_stride")]
+        + [(n, _vp) for n in ("cast_src", "cast_src2")]
+        + [(n, _i32) for n in ("cast_rows", "cast_groups")]
+        + [(n, _i64) for n in ("cast_group_stride", "cast_batch_stride", "cast_row_stride")]
     )
 
 
@@ -759,9 +762,11 @@ def proj_kred_eligible(w, inp, out):
     return (w.stride(1) == 1 and w.stride(0) % 8 == 0 and k % 8 == 0) or (w.stride(0) == 1 and w.stride(1) % 8 == 0 and m % 8 == 0)
 
 
-def proj_kred(w, inp, out, w2=None, inp2=None, out2=None, tile=0):
+def proj_kred(w, inp, out, w2=None, inp2=None, out2=None, tile=0, cast_src=None, cast_src2=None):
     """out[b, m, l] = sum_k w[m, k] inp[b, k, l]  (vms_hip.h vms_proj_kred: x_dbl = x_proj.weight @ conv1d_out, dx_dbl[:R] =
-    dt_proj.weight^T @ ddelta); w2 / inp2 / out2: a second problem of the same shape and strides in the same launch."""
+    dt_proj.weight^T @ ddelta); w2 / inp2 / out2: a second problem of the same shape and strides in the same launch.
+    cast_src: fp32 (groups, batch, rows, seqlen) -> rounded into the groups * rows rows that follow `out`'s m rows in its parent
+    tensor (the backward's dB / dC next to its d_dt: `out` must be the first m rows of a (batch, m + groups * rows, seqlen) tensor)."""
     if not proj_kred_eligible(w, inp, out):
         raise RuntimeError("proj_kred: 16-bit w (m <= 96, k), inp (batch, k, seqlen), out (batch, m, seqlen) of one dtype expected; unit "
                            "seqlen strides, seqlen / strides multiples of 8, 16-byte aligned, w contiguous along k or m")
@@ -778,6 +783,16 @@ def proj_kred(w, inp, out, w2=None, inp2=None, out2=None, tile=0):
                 and inp2.stride() == inp.stride() and out2.stride() == out.stride() and inp2.dtype == inp.dtype):
             raise RuntimeError("proj_kred: the second problem must have the first one's shapes, strides and dtype")
         P.w2, P.inp2, P.out2 = _ptr(w2), _ptr(inp2), _ptr(out2)
+    if cast_src is not None:
+        if not (cast_src.dtype == torch.float32 and cast_src.dim() == 4 and cast_src.stride(3) == 1 and cast_src.shape[1] == inp.shape[0]
+                and cast_src.shape[3] == inp.shape[2]):
+            raise RuntimeError("proj_kred: cast_src must be fp32 (groups, batch, rows, seqlen) with a unit seqlen stride")
+        P.cast_src, P.cast_groups, P.cast_rows = _ptr(cast_src), cast_src.shape[0], cast_src.shape[2]
+        P.cast_group_stride, P.cast_batch_stride, P.cast_row_stride = cast_src.stride(0), cast_src.stride(1), cast_src.stride(2)
+        if cast_src2 is not None:
+            if cast_src2.shape != cast_src.shape or cast_src2.stride() != cast_src.stride() or cast_src2.dtype != torch.float32:
+                raise RuntimeError("proj_kred: cast_src2 must have cast_src's shape and strides")
+            P.cast_src2 = _ptr(cast_src2)
     _call("vms_proj_kred", P, inp)
 
 
