@@ -265,6 +265,36 @@ def test_complex_scan_reverse_and_accumulate(oracle, L, itype):
     assert crel_err(dz_acc, dzb.float() + r2[7].float()) <= tol
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [300, 2055])
+def test_complex_scan_reverse_from(oracle, L, itype):
+    """reverse_from with a complex A (round 4): batch entries >= reverse_from right-to-left, the others left-to-right, in one launch
+    == the two sub-batches as separate calls (identical arithmetic per row; the batch sums within the bar)."""
+    import selective_scan_cuda
+    torch.manual_seed(5)
+    b, d, n, rf = 3, 6, 8, 1
+    u, delta = torch.randn(b, d, L, device=DEV, dtype=itype), (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
+    z, dout = torch.randn(b, d, L, device=DEV, dtype=itype), torch.randn(b, d, L, device=DEV, dtype=itype)
+    A = torch.complex(-0.5 * torch.rand(d, n, device=DEV), torch.randn(d, n, device=DEV))
+    B, C = torch.randn(b, 1, n, 2 * L, device=DEV, dtype=itype), torch.randn(b, 1, n, 2 * L, device=DEV, dtype=itype)
+    D, bias = torch.randn(d, device=DEV), torch.rand(d, device=DEV)
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse_from=rf)
+    lo, hi = slice(0, rf), slice(rf, b)
+    parts = [selective_scan_cuda.fwd(u[s], delta[s], A, B[s], C[s], D, z[s], bias, True, reverse=rv) for s, rv in ((lo, False), (hi, True))]
+    assert torch.equal(out, torch.cat([parts[0][0], parts[1][0]])) and torch.equal(out_z, torch.cat([parts[0][2], parts[1][2]]))
+    assert torch.equal(x, torch.cat([parts[0][1], parts[1][1]]))
+    r = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse_from=rf)
+    rs = [selective_scan_cuda.bwd(u[s], delta[s], A, B[s], C[s], D, z[s], bias, dout[s], p[1], p[0], None, True, False, reverse=rv)
+          for s, rv, p in ((lo, False, parts[0]), (hi, True, parts[1]))]
+    tol = TOL[itype]
+    for i, name in enumerate(("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz")):
+        if name in ("dA", "dD", "ddelta_bias"):
+            assert crel_err(r[i], rs[0][i] + rs[1][i]) <= tol, name
+        else:
+            want = torch.cat([rs[0][i], rs[1][i]])
+            assert crel_err(r[i], want) <= (0 if name in ("du", "ddelta", "dz") else tol), name
+
+
 @pytest.mark.parametrize("L", [1024, 2600, 4096 + 512])
 def test_complex_scan_checkpoint_slots(oracle, L):
     """x of a complex scan: slot [c][2n + 1] = the state after 2048-chunk c (the reference's slot, last_state = x[:, :, -1, 1::2]),
@@ -302,8 +332,8 @@ def test_complex_scan_extension_checks():
         selective_scan_cuda.fwd(u, u, A, B[..., :16].contiguous(), B, None, None, None, False)
     with pytest.raises(RuntimeError):   # constant B in the weight type
         selective_scan_cuda.fwd(u, u, A, torch.randn(4, 8, device=DEV), B, None, None, None, False)
-    with pytest.raises(RuntimeError):   # per-batch-entry directions are real-A only
-        selective_scan_cuda.fwd(u, u, A, B, B, None, None, None, False, reverse_from=1)
+    with pytest.raises(RuntimeError):   # reverse_from beyond the batch
+        selective_scan_cuda.fwd(u, u, A, B, B, None, None, None, False, reverse_from=2)
     L = 1024
     u2, B2 = torch.randn(1, 4, L, device=DEV), torch.randn(1, 1, 8, 2 * L, device=DEV)
     with pytest.raises(RuntimeError):   # the backward needs the forward's checkpoints beyond one 512-element chunk

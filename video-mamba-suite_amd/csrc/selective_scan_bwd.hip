@@ -373,10 +373,9 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     const vms_scan_fwd_params& p = q.f;
     if (int rc = validate_scan_common(p)) return rc;
     VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
-    VMS_CHECK(!p.is_complex || p.reverse_from == 0, "complex A: reverse_from is not available");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
-        const bool native = scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q);
+        const bool native = p.is_complex || (scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q));
         if (p.reverse_from < p.batch && !native) {
             vms_scan_bwd_params lo, hi;
             scan_bwd_sub_batches(q, lo, hi);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(kCRows* kWave) void cscan_fwd_kernel(const vms_scan
     if (d >= p.dim) return;
     const int g = d / (p.dim / p.n_groups);
     const int L = p.seqlen, N = p.dstate;
-    const bool rev = p.reverse != 0;
+    const bool rev = p.reverse != 0 || (p.reverse_from > 0 && b >= p.reverse_from);   // per batch entry (workgroup-uniform)
     volatile lds_f32* h = (lds_f32*)smem + wave * 2 * N;   // running complex state per n (wave-private)
     for (int n = lane; n < 2 * N; n += kWave) h[n] = 0.f;
     const int64_t xpitch = 2 * (p.x_chunk_stride ? p.x_chunk_stride : 2 * (int64_t)N);   // floats
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kCBRows* kWave) void cscan_bwd_kernel(const vms_sca
     const bool same_group = (d0 / dpg) == (d_last / dpg);
     const int Lr = row_ok ? p.seqlen : 0;
     const int L = p.seqlen, N = p.dstate;
-    const bool rev = p.reverse != 0;
+    const bool rev = p.reverse != 0 || (p.reverse_from > 0 && b >= p.reverse_from);   // per batch entry (workgroup-uniform)
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef __attribute__((address_space(3))) v2f lds_c2;
     lds_c2* const slab = (lds_c2*)smem;
@@ -575,7 +575,6 @@ int dispatch_cbwd(const vms_scan_bwd_params& q, bool vec, hipStream_t s) {
 #undef VMS_CCASES
 
 int validate_complex(const vms_scan_fwd_params& p) {
-    VMS_CHECK(p.reverse_from == 0, "complex A: reverse_from is not available");
     VMS_CHECK(p.x_has_sub == 0 || p.x_has_sub == 1, "complex A: x_has_sub must be 0 or 1");
     VMS_CHECK(p.x_has_sub == 0 || p.x_chunk_stride >= 6 * (int64_t)p.dstate,
               "complex A: x_has_sub == 1 needs an x pitch >= 6 * dstate complex elements");

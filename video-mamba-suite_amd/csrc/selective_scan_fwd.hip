@@ -267,14 +267,14 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     VMS_CHECK(pp != nullptr, "null params");
     const vms_scan_fwd_params& p = *pp;
     if (int rc = validate_scan_common(p)) return rc;
-    VMS_CHECK(!p.is_complex || p.reverse_from == 0, "complex A: reverse_from is not available");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
         VMS_CHECK(p.x_has_sub != 2, "reverse_from is not available with the rows layout");
         if (p.reverse_from < p.batch) {
             // one launch when the paired LDS kernel takes the problem as it is; otherwise the two sub-batches as two problems
-            const bool native = scan_impl_level(p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, scan_fwd_vec_ok(p)) &&
-                                scan_fwd_pair_native_mixed(p);
+            // (the complex kernels take the direction per batch entry as it is)
+            const bool native = p.is_complex || (scan_impl_level(p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, scan_fwd_vec_ok(p)) &&
+                                                 scan_fwd_pair_native_mixed(p));
             if (!native) return scan_fwd_mixed(p, stream);
         }
     }

@@ -131,8 +131,8 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
 def _fwd_complex(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse, out_z_into, reverse_from):
     """complex A (selective_scan.cpp:282-287): x is complex64 (batch, dim, n_chunks, 2 * dstate) as the reference allocates it
     (:313), here the view of a (.., 6 * dstate) buffer whose tail holds the state after every 512 elements for bwd."""
-    _check(reverse_from == 0, "reverse_from is not available with a complex A")
     batch, dim, seqlen, dstate, _, _ = _common_checks(u, delta, A, B, C, D_, z_, delta_bias_)
+    _check(0 <= reverse_from <= batch and not (reverse and reverse_from), "reverse_from must be in [0, batch] with reverse off")
     n_chunks = (seqlen + 2047) // 2048
     out = torch.empty_like(delta)
     out_z = torch.empty_like(z_) if z_ is not None else None
@@ -143,7 +143,7 @@ def _fwd_complex(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse
                "out_z_into must be (batch, dim, seqlen), input dtype, unit last stride")
         out_z = out_z_into
     x = torch.empty(batch, dim, n_chunks, 6 * dstate, device=u.device, dtype=torch.complex64)[..., :2 * dstate]
-    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, out_z_into is not None, 0, 0)
+    _k.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, out, out_z, x, delta_softplus, reverse, out_z_into is not None, 0, int(reverse_from))
     return [out, x] + ([out_z] if z_ is not None else [])
 
 
@@ -240,7 +240,6 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     ext = _k.ext() if not A.is_complex() else None   # complex A: the checks / allocations below, launch through ctypes
     impl = _k.scan_impl_from_env()
     if A.is_complex():
-        _check(reverse_from == 0, "reverse_from is not available with a complex A")
         bc_pad = 0
     if ext is not None and impl < _k.IMPL_ROWS:
         if bc_pad is None:
