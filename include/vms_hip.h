@@ -409,6 +409,24 @@ typedef struct {
 } vms_proj_kred_params;
 int vms_proj_kred(const vms_proj_kred_params *p, void *stream);
 
+/* vms_conv_xproj_dual (ABI v10): the head of a bidirectional block's forward in one pass over x --
+ *     conv1d_out   = causal_conv1d_fwd(x, conv1d.weight, conv1d.bias, silu)            (:170-176)   for both parameter sets,
+ *     x_dbl        = F.linear(rearrange(conv1d_out, "b d l -> (b l) d"), x_proj.weight)  (:181)       the second set right-to-left
+ * c = the parameter block of vms_causal_conv1d_fwd_dual (out / out_b: the two conv1d outputs, bit-identical to that call's);
+ * x_dbl / x_dbl_b (batch, m, seqlen) = w_x @ out / w_x_b @ out_b as vms_proj_kred computes them (w_x, w_x_b: (m, dim), unit stride
+ * along dim, m <= 96).  16-bit activations (bf16 / fp16), conv weights in fp32 or the activations' dtype, SiLU on, unit seqlen
+ * strides, seqlen / dim / strides multiples of 8; anything else: the two separate calls. */
+typedef struct {
+    vms_conv_fwd_dual_params c;
+    const void *w_x, *w_x_b;
+    void *x_dbl, *x_dbl_b;
+    int32_t m;
+    int32_t tile;             /* positions per workgroup: 64 or 128; 0 = chosen from the grid size */
+    int64_t wx_row_stride;
+    int64_t xdbl_batch_stride, xdbl_row_stride;
+} vms_conv_xproj_dual_params;
+int vms_conv_xproj_dual(const vms_conv_xproj_dual_params *p, void *stream);
+
 /* vms_proj_conv_bwd: selective_scan_interface.py:278-283 in one pass over the activations --
  *     dx_proj_weight  = einsum("Br,Bd->rd", dx_dbl, conv1d_out)                      -> dw_x (k, dim) fp32, ADDED to (atomics)
  *     dconv1d_out     = addmm(du, x_proj_weight.t(), dx_dbl.t())                     (never stored: fp32 on chip)
@@ -486,6 +504,7 @@ int vms_sizeof_proj_apply_params(void);
 int vms_sizeof_proj_wgrad_params(void);
 int vms_sizeof_proj_conv_bwd_params(void);
 int vms_sizeof_proj_kred_params(void);
+int vms_sizeof_conv_xproj_dual_params(void);
 
 #ifdef __cplusplus
 }

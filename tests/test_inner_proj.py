@@ -200,6 +200,77 @@ def test_proj_kred_cast_rows(shape, tile):
         assert (dx_dbl[:, R + 2 * N:, :] == 7.0).all()
 
 
+# (batch, dim, seqlen, m, width)
+CXP_SHAPES = [(8, 1024, 8192, 96, 4), (2, 768, 3136, 80, 4), (1, 384, 3152, 56, 4), (2, 200, 72, 17, 3), (3, 64, 8, 33, 2), (1, 136, 264, 96, 4)]
+
+
+@pytest.mark.parametrize("dtype,wdtype,has_bias", [(torch.bfloat16, torch.float32, True), (torch.bfloat16, torch.bfloat16, True),
+                                                    (torch.float16, torch.float32, False)])
+@pytest.mark.parametrize("shape", CXP_SHAPES)
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_conv_xproj_dual_vs_separate(shape, dtype, wdtype, has_bias, tile):
+    """vms_conv_xproj_dual == vms_causal_conv1d_fwd_dual followed by vms_proj_kred (both directions), bit for bit: the same conv
+    arithmetic tap for tap, the same order of matrix-core steps per output."""
+    vms = _vms()
+    b, d, L, m, width = shape
+    torch.manual_seed(d + L)
+    xz = torch.randn(b, 2 * d, L, device=DEV).to(dtype)
+    x = xz[:, :d, :]                                        # the view the block passes (batch stride 2 d L)
+    cw, cwb = [(torch.randn(d, width, device=DEV) * 0.4).to(wdtype) for _ in range(2)]
+    cb, cbb = [(torch.randn(d, device=DEV) * 0.2).to(wdtype) if has_bias else None for _ in range(2)]
+    wx, wxb = [(torch.randn(m, d, device=DEV) * d ** -0.5).to(dtype) for _ in range(2)]
+    ref_o, ref_ob = torch.empty(b, d, L, device=DEV, dtype=dtype), torch.empty(b, d, L, device=DEV, dtype=dtype)
+    vms.conv_fwd_dual(x, cw, cb, ref_o, cwb, cbb, ref_ob, True)
+    ref_x, ref_xb = torch.empty(b, m, L, device=DEV, dtype=dtype), torch.empty(b, m, L, device=DEV, dtype=dtype)
+    vms.proj_kred(wx, ref_o, ref_x, wxb, ref_ob, ref_xb)
+    o, ob = torch.full_like(ref_o, float("nan")), torch.full_like(ref_ob, float("nan"))
+    xd, xdb = torch.full_like(ref_x, float("nan")), torch.full_like(ref_xb, float("nan"))
+    assert vms.conv_xproj_dual_eligible(x, cw, cb, cwb, cbb, wx, wxb)
+    vms.conv_xproj_dual(x, cw, cb, o, cwb, cbb, ob, wx, wxb, xd, xdb, tile=tile)
+    assert vms.lib().vms_last_kernel().decode().startswith("conv_xproj_dual")
+    assert torch.equal(o, ref_o) and torch.equal(ob, ref_ob), "conv1d outputs differ from vms_causal_conv1d_fwd_dual"
+    assert torch.equal(xd, ref_x) and torch.equal(xdb, ref_xb), "x_dbl differs from vms_proj_kred on the same conv1d outputs"
+    ext = vms.ext()
+    if ext is not None and tile == 0:
+        r = ext.conv_xproj_dual(x, cw, cb, cwb, cbb, wx, wxb)
+        assert len(r) == 4 and all(torch.equal(a, w) for a, w in zip(r, (ref_o, ref_ob, ref_x, ref_xb)))
+        # what the kernel declines comes back empty (fp32 activations, m > 96)
+        assert len(ext.conv_xproj_dual(x.float(), cw.float(), None, cwb.float(), None, wx.float(), wxb.float())) == 0
+
+
+def test_bidirectional_node_fused_head_vs_separate(monkeypatch):
+    """The bidirectional node with the fused head (conv1d + x_proj of both directions in one launch) == the node on the separate
+    launches: outputs and all gradients identical (same values feed the same kernels)."""
+    import vms_hip
+    import mamba_ssm.ops.selective_scan_interface as ssi
+    if vms_hip.ext() is None:
+        pytest.skip("compiled binding not built")
+    b, L, d, N = 2, 640, 256, 16
+    R = d // 16
+    torch.manual_seed(11)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, device=DEV) * sc).requires_grad_()
+    xz0 = torch.randn(b, 2 * d, L, device=DEV).bfloat16()
+    sets = [(mk(d, 1, 4, sc=0.3), mk(d, sc=0.1), mk(R + 2 * N, d, sc=d ** -0.5), mk(d, R, sc=R ** -0.5),
+             (-torch.rand(d, N, device=DEV) - 0.2).requires_grad_(), mk(d), mk(d, sc=0.3)) for _ in range(2)]
+    g = torch.randn(b, d, L, device=DEV)
+
+    def run(fused):
+        monkeypatch.setattr(ssi, "_CONV_XPROJ", fused)
+        xz = xz0.clone().requires_grad_()
+        for st in sets:
+            for t in st:
+                t.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = ssi.bimamba_inner_fn_no_out_proj(xz, sets[0], sets[1], checkpoint_lvl=0)
+        out.backward(g.to(out.dtype))
+        return [out.detach(), xz.grad] + [t.grad.clone() for st in sets for t in st]
+
+    got, want = run(True), run(False)
+    for i, (a, w) in enumerate(zip(got, want)):
+        err = (a.float() - w.float()).abs().max().item() / max(w.float().abs().max().item(), 1e-6)
+        assert err <= 1e-3, f"tensor {i}: rel err {err:.3e}"     # identical forward values; atomics' order in the batch sums
+
+
 def test_proj_kred_checks():
     vms = _vms()
     w = torch.randn(48, 128, device=DEV).bfloat16()

@@ -827,6 +827,226 @@ __global__ __launch_bounds__(kPT, (NL <= 2 ? 4 : NL <= 4 ? 3 : 2)) void proj_kre
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// conv_xproj_dual: both directions' causal_conv1d (+ SiLU) of a bidirectional block AND both x_proj products, one pass over x
+// ---------------------------------------------------------------------------------------------------------------------
+// The forward of a ViM block runs  conv1d_out = silu(conv1d(x)) (SSI:170-176) and x_dbl = x_proj.weight @ conv1d_out (:181) for
+// each direction: vms_causal_conv1d_fwd_dual writes the two conv1d outputs from one pass over x and vms_proj_kred reads both
+// back for the two products.  Here the workgroup layout of proj_kred (TL positions of one batch entry, channels 64 at a time) also
+// computes the convolutions: a thread's 16-byte piece of x (8 positions of one channel, neighbours' halos through DPP, the
+// tile's edges from memory) becomes the piece of BOTH conv1d outputs -- the arithmetic of conv_fwd_dual_kernel, tap for tap, so
+// the outputs are bit-identical -- which it stores to HBM and into the two LDS tiles the matrix cores then read as B operands.
+// conv1d_out is never read back: 402 MB instead of 671 at (8, 1024, 8192), one launch instead of two.
+template <typename T, typename WT_, int MH, int NL>
+__global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_xproj_dual_params q) {
+    const vms_conv_fwd_params& p = q.c.f;
+    constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = KB + 8;
+    constexpr int PPR = TL / 8, RPP = kPT / PPR;
+    constexpr int TPP = 8;                            // floats per (direction, channel) record of conv taps: 4 taps, bias, 3 unused
+    typedef __attribute__((address_space(3))) short lds_s16;
+    typedef unsigned int u32;
+    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g16 = lane >> 4;
+    const int wl = wave & 1, wm = wave >> 1;
+    const int b = blockIdx.z;
+    const int L = p.seqlen, K = p.dim, M = q.m;
+    const int l0 = blockIdx.x * TL;
+    lds_s16* const in_a = (lds_s16*)reinterpret_cast<short*>(smem);                        // [KB][INP] conv1d_out, left-to-right set
+    lds_s16* const in_b = in_a + KB * INP;                                                 // [KB][INP] right-to-left set
+    lds_s16* const w_a = in_b + KB * INP;                                                  // [MP][WP] x_proj.weight block
+    lds_s16* const w_b = w_a + MP * WP;
+    lds_f32* const tp = (lds_f32*)reinterpret_cast<float*>(smem + (2 * KB * INP + 2 * MP * WP) * 2);   // [2 buffers][2 directions][KB][TPP]
+
+    const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(static_cast<const T*>(p.x) + (int64_t)b * p.x_batch_stride), 0, (int)(((int64_t)(K - 1) * p.x_c_stride + L) * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t oa_rs = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride, 0, (int)(((int64_t)(K - 1) * p.out_c_stride + L) * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t ob_rs = __builtin_amdgcn_make_buffer_rsrc(
+        static_cast<T*>(q.c.out_b) + (int64_t)b * q.c.out_b_batch_stride, 0, (int)(((int64_t)(K - 1) * q.c.out_b_c_stride + L) * 2), kPBufFlags);
+    const int w_bytes = (int)(((int64_t)(M - 1) * q.wx_row_stride + K) * 2);
+    const __amdgpu_buffer_rsrc_t wa_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w_x), 0, w_bytes, kPBufFlags);
+    const __amdgpu_buffer_rsrc_t wb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w_x_b), 0, w_bytes, kPBufFlags);
+    // conv taps / biases: thread t < 128 owns (direction t >> 6, channel t & 63) of the block; a missing bias is a resource of size 0
+    const int t_dir = (tid >> 6) & 1, t_ch = tid & 63;
+    const int64_t cw_c = t_dir ? q.c.weight_b_c_stride : p.weight_c_stride, cw_w = t_dir ? q.c.weight_b_width_stride : p.weight_width_stride;
+    const __amdgpu_buffer_rsrc_t cw_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(t_dir ? q.c.weight_b : p.weight), 0, (int)(((int64_t)(K - 1) * cw_c + (int64_t)(p.width - 1) * cw_w + 1) * sizeof(WT_)), kPBufFlags);
+    const void* const cbp = t_dir ? q.c.bias_b : p.bias;
+    const __amdgpu_buffer_rsrc_t cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(cbp), 0, cbp ? K * (int)sizeof(WT_) : 0, kPBufFlags);
+    constexpr int kOOB = -1;
+
+    struct XStage { s16x8 m[NL]; u32x2 el[NL], er[NL]; };     // a thread's pieces of x: 8 positions + what precedes / follows the tile's edge
+    struct WStage { s16x8 wa[MH], wb[MH]; float tp[5]; };
+    const int ipc = tid % PPR, irow = tid / PPR;
+    auto x_load = [&](XStage& st, int kb) __attribute__((always_inline)) {
+        const int l = l0 + 8 * ipc;
+#pragma unroll
+        for (int ps = 0; ps < NL; ++ps) {
+            const int k = kb * KB + irow + RPP * ps;
+            const bool ok = k < K && l < L;
+            const int off = (int)(((int64_t)k * p.x_c_stride + l) * 2);
+            st.m[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? off : kOOB, 0, 0));
+            // positions l - 4 .. l - 1 (the tile's first piece) and l + 8 .. l + 11 (its last): zeros outside the row
+            st.el[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, ok && ipc == 0 && l > 0 ? off - 8 : kOOB, 0, 0));
+            st.er[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, ok && ipc == PPR - 1 && l + 8 < L ? off + 16 : kOOB, 0, 0));
+        }
+    };
+    auto tap_val = [&](int off_elems, const __amdgpu_buffer_rsrc_t& rs, bool ok) __attribute__((always_inline)) -> float {
+        if constexpr (sizeof(WT_) == 4) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, ok ? off_elems * 4 : kOOB, 0, 0));
+        } else {
+            const unsigned short h = __builtin_amdgcn_raw_buffer_load_b16(rs, ok ? off_elems * 2 : kOOB, 0, 0);
+            return static_cast<float>(__builtin_bit_cast(WT_, h));
+        }
+    };
+    // W blocks of step kb, conv taps of step kb_t
+    auto w_load = [&](WStage& st, int kb, int kb_t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < MH; ++ps) {
+            const int m = (tid >> 3) + 32 * ps, k = kb * KB + 8 * (tid & 7);
+            const int off = m < M && k < K ? (int)(((int64_t)m * q.wx_row_stride + k) * 2) : kOOB;
+            st.wa[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wa_rs, off, 0, 0));
+            st.wb[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(wb_rs, off, 0, 0));
+        }
+        const int c = kb_t * KB + t_ch;
+        const bool okc = tid < 2 * KB && c < K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {       // taps[i] multiplies x[l - 3 + i] (left-to-right) / x[l + 3 - i] (right-to-left); widths < 4: leading zeros
+            const int wi = i - (4 - p.width);
+            st.tp[i] = tap_val((int)((int64_t)c * cw_c + (int64_t)wi * cw_w), cw_rs, okc && wi >= 0);
+        }
+        st.tp[4] = tap_val(c, cb_rs, okc);
+    };
+    auto w_store = [&](const WStage& st, int tbuf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ps = 0; ps < MH; ++ps) {
+            *reinterpret_cast<lds_s16x8*>(w_a + ((tid >> 3) + 32 * ps) * WP + 8 * (tid & 7)) = st.wa[ps];
+            *reinterpret_cast<lds_s16x8*>(w_b + ((tid >> 3) + 32 * ps) * WP + 8 * (tid & 7)) = st.wb[ps];
+        }
+        if (tid < 2 * KB) {
+            lds_f32* dst = tp + ((tbuf * 2 + t_dir) * KB + t_ch) * TPP;
+            *(lds_f32x4*)dst = f32x4{st.tp[0], st.tp[1], st.tp[2], st.tp[3]};
+            dst[4] = st.tp[4];
+        }
+    };
+    auto up = [](u32 d, int hi) __attribute__((always_inline)) -> float {    // element `hi` of a dword of two T
+        return static_cast<float>(__builtin_bit_cast(T, (unsigned short)(hi ? d >> 16 : d & 0xffffu)));
+    };
+    // the convolutions of step kb's pieces: both conv1d outputs to HBM and to the LDS tiles
+    auto conv_store = [&](const XStage& st, int kb, int tbuf) __attribute__((always_inline)) {
+        const int l = l0 + 8 * ipc;
+#pragma unroll
+        for (int ps = 0; ps < NL; ++ps) {
+            const int r = irow + RPP * ps, k = kb * KB + r;
+            typedef u32 u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ md = __builtin_bit_cast(u32x4_, st.m[ps]);
+            // the previous piece's positions 5, 6, 7 and the next piece's 0, 1, 2 sit in the neighbouring lanes
+            u32 pl2 = (u32)__builtin_amdgcn_update_dpp(0, (int)md[2], DPP_WAVE_SHR1, 0xf, 0xf, false);
+            u32 pl3 = (u32)__builtin_amdgcn_update_dpp(0, (int)md[3], DPP_WAVE_SHR1, 0xf, 0xf, false);
+            u32 pr0 = (u32)__builtin_amdgcn_update_dpp(0, (int)md[0], DPP_WAVE_SHL1, 0xf, 0xf, false);
+            u32 pr1 = (u32)__builtin_amdgcn_update_dpp(0, (int)md[1], DPP_WAVE_SHL1, 0xf, 0xf, false);
+            if (ipc == 0) { pl2 = st.el[ps][0]; pl3 = st.el[ps][1]; }
+            if (ipc == PPR - 1) { pr0 = st.er[ps][0]; pr1 = st.er[ps][1]; }
+            float xv[8 + 6];     // xv[3 + i] = x[l + i]; [0..2] = the 3 positions before, [11..13] = the 3 after
+            xv[0] = up(pl2, 1); xv[1] = up(pl3, 0); xv[2] = up(pl3, 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) xv[3 + i] = up(md[i >> 1], i & 1);
+            xv[11] = up(pr0, 0); xv[12] = up(pr0, 1); xv[13] = up(pr1, 0);
+            const lds_f32* ta_ = tp + ((tbuf * 2 + 0) * KB + r) * TPP;
+            const lds_f32* tb_ = tp + ((tbuf * 2 + 1) * KB + r) * TPP;
+            const f32x4 tav = *(const lds_f32x4*)ta_, tbv = *(const lds_f32x4*)tb_;
+            const float bias_a = ta_[4], bias_b = tb_[4];
+            const float taps_a[4] = {tav.x, tav.y, tav.z, tav.w}, taps_b[4] = {tbv.x, tbv.y, tbv.z, tbv.w};
+            vec_t<T, 8> oa, ob;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float acc = bias_a, acc_b = bias_b;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    acc = fmaf(taps_a[kk], xv[i + kk], acc);
+                    acc_b = fmaf(taps_b[kk], xv[i + 6 - kk], acc_b);
+                }
+                float ra = acc * sigmoidf_(acc), rb = acc_b * sigmoidf_(acc_b);
+                asm volatile("" : "+v"(ra), "+v"(rb));   // as conv_fwd_dual_kernel: narrowed from the rounded fp32 value
+                oa[i] = static_cast<T>(ra);
+                ob[i] = static_cast<T>(rb);
+            }
+            const bool ok = k < K && l < L;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, oa), oa_rs, ok ? (int)(((int64_t)k * p.out_c_stride + l) * 2) : kOOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, ob), ob_rs, ok ? (int)(((int64_t)k * q.c.out_b_c_stride + l) * 2) : kOOB, 0, 0);
+            *reinterpret_cast<lds_s16x8*>(in_a + r * INP + 8 * ipc) = __builtin_bit_cast(s16x8, oa);
+            *reinterpret_cast<lds_s16x8*>(in_b + r * INP + 8 * ipc) = __builtin_bit_cast(s16x8, ob);
+        }
+    };
+
+    f32x4 acc_a[MH][NL], acc_b[MH][NL];
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl) { acc_a[mh][nl] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_b[mh][nl] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int m0w = wm * 16 * MH;
+    const int tb_off = (8 * g16 + (i16 >> 2)) * INP + wl * (TL / 2) + 4 * (i16 & 3);
+    const int ta_off = (m0w + i16) * WP + 8 * g16;
+    auto product = [&](const lds_s16* in_t, const lds_s16* w_t, f32x4 (&acc)[MH][NL]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < KB / 32; ++s) {
+            s16x8 af[MH];
+#pragma unroll
+            for (int mh = 0; mh < MH; ++mh) af[mh] = *reinterpret_cast<const lds_s16x8*>(w_t + ta_off + 16 * mh * WP + 32 * s);
+#pragma unroll
+            for (int nl = 0; nl < NL; ++nl) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(in_t + tb_off + (32 * s) * INP + 16 * nl));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(in_t + tb_off + (32 * s + 4) * INP + 16 * nl));
+                const s16x8 bf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int mh = 0; mh < MH; ++mh) acc[mh][nl] = Mfma16<T>::run(af[mh], bf, acc[mh][nl]);
+            }
+        }
+    };
+
+    const int nkb = (K + KB - 1) / KB;
+    XStage sa, sb;      // x of steps kb and kb + 1 (HBM latency: two steps of requests in flight)
+    WStage sw;          // W_x blocks of step kb, conv taps of step kb + 1 (L2 latency: one step)
+    w_load(sw, 0, 0);
+    x_load(sa, 0);
+    w_store(sw, 0);     // taps of step 0 (the W blocks are stored again below)
+    w_load(sw, 0, 1);
+    x_load(sb, 1);
+    __syncthreads();
+    auto step = [&](XStage& st, int kb) __attribute__((always_inline)) {
+        conv_store(st, kb, kb & 1);
+        w_store(sw, (kb + 1) & 1);      // W blocks of this step, taps of the next
+        // (requests return in issue order: the L2-resident W blocks go out BEFORE the x pieces of two steps ahead, so that waiting for
+        // them at the next step's w_store leaves those x requests in flight)
+        w_load(sw, kb + 1, kb + 2);
+        x_load(st, kb + 2);
+        __syncthreads();                // both conv1d tiles and the W blocks are in LDS
+        product(in_a, w_a, acc_a);
+        product(in_b, w_b, acc_b);
+        __syncthreads();                // every wave has read them
+    };
+    for (int kb = 0; kb < nkb; kb += 2) {
+        step(sa, kb);
+        if (kb + 1 < nkb) step(sb, kb + 1);    // (workgroup-uniform)
+    }
+    T* const xa_b = static_cast<T*>(q.x_dbl) + (int64_t)b * q.xdbl_batch_stride;
+    T* const xb_b = static_cast<T*>(q.x_dbl_b) + (int64_t)b * q.xdbl_batch_stride;
+#pragma unroll
+    for (int mh = 0; mh < MH; ++mh)
+#pragma unroll
+        for (int nl = 0; nl < NL; ++nl)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m = m0w + 16 * mh + 4 * g16 + v, l = l0 + wl * (TL / 2) + 16 * nl + i16;
+                if (m < M && l < L) {
+                    xa_b[(int64_t)m * q.xdbl_row_stride + l] = static_cast<T>(acc_a[mh][nl][v]);
+                    xb_b[(int64_t)m * q.xdbl_row_stride + l] = static_cast<T>(acc_b[mh][nl][v]);
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 
@@ -931,6 +1151,42 @@ static int dispatch_kred(const vms_proj_kred_params& p, hipStream_t stream) {
         default: return VMS_KRED(3);
     }
 #undef VMS_KRED
+}
+
+template <typename T, typename WT_, int MH, int NL>
+static int launch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream) {
+    constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = KB + 8;
+    const dim3 grid((q.c.f.seqlen + TL - 1) / TL, 1, q.c.f.batch), block(kPT);
+    const size_t smem = (size_t)(2 * KB * INP + 2 * MP * WP) * 2 + (size_t)2 * 2 * KB * 8 * sizeof(float);
+    if (smem > 64 * 1024) {
+        static PerDeviceOnce attr_once;
+        const hipError_t arc = attr_once.run([&]() -> hipError_t {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_xproj_dual_kernel<T, WT_, MH, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        });
+        if (arc != hipSuccess) {
+            set_error("hipFuncSetAttribute(conv_xproj_dual, %zu bytes of LDS) failed: %s", smem, hipGetErrorString(arc));
+            return VMS_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((conv_xproj_dual_kernel<T, WT_, MH, NL>), grid, block, smem, stream, q);
+    VMS_LAUNCH_CHECK();
+    set_last_kernel(NL == 4 ? "conv_xproj_dual_128" : "conv_xproj_dual_64");
+    return VMS_OK;
+}
+
+template <typename T, typename WT_>
+static int dispatch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream) {
+    // 64 positions per workgroup: two workgroups per CU; 128 (one per CU, 256 registers) measured 25-45 % slower on every shape
+    // (profiles/r04_conv_xproj.md) and stays a knob
+    const int tile = q.tile == 128 ? 128 : 64;
+    const int mh = ((q.m + 15) / 16 + 1) / 2;
+#define VMS_CXP(MH_) (tile == 128 ? launch_conv_xproj<T, WT_, MH_, 4>(q, stream) : launch_conv_xproj<T, WT_, MH_, 2>(q, stream))
+    switch (mh) {
+        case 1: return VMS_CXP(1);
+        case 2: return VMS_CXP(2);
+        default: return VMS_CXP(3);
+    }
+#undef VMS_CXP
 }
 
 template <typename T, int KS>
@@ -1051,6 +1307,35 @@ extern "C" int vms_proj_kred(const vms_proj_kred_params* pp, void* stream) {
     return p.dtype == VMS_BF16 ? dispatch_kred<bf16_t>(p, s) : dispatch_kred<f16_t>(p, s);
 }
 extern "C" int vms_sizeof_proj_kred_params(void) { return (int)sizeof(vms_proj_kred_params); }
+extern "C" int vms_conv_xproj_dual(const vms_conv_xproj_dual_params* qq, void* stream) {
+    VMS_CHECK(qq != nullptr, "null parameter block");
+    const vms_conv_xproj_dual_params& q = *qq;
+    const vms_conv_fwd_params& p = q.c.f;
+    VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "conv_xproj_dual: 16-bit activations only (bf16 / fp16)");
+    VMS_CHECK(p.wdtype == VMS_F32 || p.wdtype == p.dtype, "conv_xproj_dual: conv weights in fp32 or in the activations' dtype");
+    VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0, "empty problem");
+    VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
+    VMS_CHECK(p.silu_activation && !p.reverse && !p.reverse_from && !p.conv_state, "conv_xproj_dual: SiLU on, seqlen-contiguous layout, no reverse / reverse_from / conv_state");
+    VMS_CHECK(p.x && p.weight && p.out && q.c.weight_b && q.c.out_b && q.w_x && q.w_x_b && q.x_dbl && q.x_dbl_b, "x, weight, out, weight_b, out_b, w_x, w_x_b, x_dbl, x_dbl_b are required");
+    VMS_CHECK((p.bias == nullptr) == (q.c.bias_b == nullptr), "bias and bias_b come together");
+    VMS_CHECK(q.m >= 1 && q.m <= 96, "conv_xproj_dual: 1 <= m <= 96");
+    VMS_CHECK(p.x_l_stride == 1 && p.out_l_stride == 1, "conv_xproj_dual: unit seqlen strides");
+    VMS_CHECK(p.seqlen % 8 == 0 && p.dim % 8 == 0 && p.x_batch_stride % 8 == 0 && p.x_c_stride % 8 == 0 && p.out_batch_stride % 8 == 0 && p.out_c_stride % 8 == 0 &&
+                  q.c.out_b_batch_stride % 8 == 0 && q.c.out_b_c_stride % 8 == 0 && q.wx_row_stride % 8 == 0 && aligned16(p.x) && aligned16(p.out) &&
+                  aligned16(q.c.out_b) && aligned16(q.w_x) && aligned16(q.w_x_b),
+              "conv_xproj_dual: seqlen, dim and the strides (elements) must be multiples of 8, bases 16-byte aligned");
+    {
+        const int64_t lim = (int64_t)1 << 31;
+        VMS_CHECK(((int64_t)(p.dim - 1) * p.x_c_stride + p.seqlen) * 2 < lim && ((int64_t)(p.dim - 1) * p.out_c_stride + p.seqlen) * 2 < lim &&
+                      ((int64_t)(p.dim - 1) * q.c.out_b_c_stride + p.seqlen) * 2 < lim && p.x_c_stride >= p.seqlen && p.out_c_stride >= p.seqlen &&
+                      q.c.out_b_c_stride >= p.seqlen && ((int64_t)(q.m - 1) * q.wx_row_stride + p.dim) * 2 < lim && q.wx_row_stride >= p.dim,
+                  "conv_xproj_dual: a batch entry of x / out / out_b and w_x must each span < 2 GiB, rows must not overlap");
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (p.dtype == VMS_BF16) return p.wdtype == VMS_F32 ? dispatch_conv_xproj<bf16_t, float>(q, s) : dispatch_conv_xproj<bf16_t, bf16_t>(q, s);
+    return p.wdtype == VMS_F32 ? dispatch_conv_xproj<f16_t, float>(q, s) : dispatch_conv_xproj<f16_t, f16_t>(q, s);
+}
+extern "C" int vms_sizeof_conv_xproj_dual_params(void) { return (int)sizeof(vms_conv_xproj_dual_params); }
 extern "C" int vms_sizeof_proj_apply_params(void) { return (int)sizeof(vms_proj_apply_params); }
 extern "C" int vms_sizeof_proj_wgrad_params(void) { return (int)sizeof(vms_proj_wgrad_params); }
 

@@ -424,6 +424,40 @@ std::vector<Tensor> conv_fwd_dual(const Tensor& x, const Tensor& weight, const O
     return {out, out_b};
 }
 
+// The head of a bidirectional block's forward in one pass over x (vms_hip.h vms_conv_xproj_dual):
+// -> {conv1d_out, conv1d_out_b, x_dbl, x_dbl_b}, or an empty vector when the kernel does not take the problem (the caller then runs
+// conv_fwd_dual + x_proj_dual)
+std::vector<Tensor> conv_xproj_dual(const Tensor& x, const Tensor& weight, const OptT& bias_, const Tensor& weight_b, const OptT& bias_b_,
+                                    const Tensor& w_x, const Tensor& w_x_b) {
+    const auto t16 = [](const Tensor& t) { return t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kHalf; };
+    if (!(x.is_cuda() && x.dim() == 3 && x.stride(2) == 1 && t16(x) && w_x.scalar_type() == x.scalar_type() && w_x_b.scalar_type() == x.scalar_type() &&
+          (weight.scalar_type() == at::kFloat || weight.scalar_type() == x.scalar_type()) && weight_b.scalar_type() == weight.scalar_type() &&
+          weight.dim() == 2 && weight.sizes() == weight_b.sizes() && weight.size(1) >= 2 && weight.size(1) <= 4 && bias_.has_value() == bias_b_.has_value()))
+        return {};
+    if (bias_.has_value() && (bias_->scalar_type() != weight.scalar_type() || bias_b_->scalar_type() != weight.scalar_type())) return {};
+    const int64_t b = x.size(0), d = x.size(1), L = x.size(2), m = w_x.size(0);
+    if (!(w_x.dim() == 2 && w_x.size(1) == d && w_x.sizes() == w_x_b.sizes() && w_x.strides() == w_x_b.strides() && m >= 1 && m <= 96 &&
+          w_x.stride(1) == 1 && w_x.stride(0) % 8 == 0 && weight.size(0) == d))
+        return {};
+    const auto al16 = [](const Tensor& t) { return (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0; };
+    if (L % 8 || d % 8 || x.stride(0) % 8 || x.stride(1) % 8 || x.stride(1) < L || !al16(x) || !al16(w_x) || !al16(w_x_b)) return {};
+    if (((d - 1) * x.stride(1) + L) * 2 >= ((int64_t)1 << 31) || d * L * 2 >= ((int64_t)1 << 31)) return {};
+    c10::DeviceGuard guard(x.device());
+    Tensor out = at::empty(x.sizes(), x.options()), out_b = at::empty(x.sizes(), x.options());
+    Tensor xa = at::empty({b, m, L}, x.options()), xb = at::empty({b, m, L}, x.options());
+    vms_conv_xproj_dual_params Q{};
+    fill_conv(Q.c.f, x, weight, bias_, out, true, false, 0);
+    Q.c.weight_b = weight_b.data_ptr(); Q.c.bias_b = cptr(bias_b_); Q.c.out_b = out_b.data_ptr();
+    Q.c.weight_b_c_stride = weight_b.stride(0); Q.c.weight_b_width_stride = weight_b.stride(1);
+    Q.c.out_b_batch_stride = out_b.stride(0); Q.c.out_b_c_stride = out_b.stride(1);
+    Q.w_x = w_x.data_ptr(); Q.w_x_b = w_x_b.data_ptr(); Q.x_dbl = xa.data_ptr(); Q.x_dbl_b = xb.data_ptr();
+    Q.m = (int)m; Q.tile = 0;
+    Q.wx_row_stride = w_x.stride(0);
+    Q.xdbl_batch_stride = xa.stride(0); Q.xdbl_row_stride = xa.stride(1);
+    call("vms_conv_xproj_dual", vms_conv_xproj_dual, Q, x);
+    return {out, out_b, xa, xb};
+}
+
 std::vector<OptT> conv_bwd(const Tensor& x, const Tensor& weight, const OptT& bias_, Tensor dout, const OptT& dx_, bool silu,
                            bool reverse, const OptT& zeroed, bool accumulate_dx, int64_t reverse_from = 0) {   // causal_conv1d.cpp:191-268
     TORCH_CHECK(x.dim() == 3, "x must be (batch, dim, seqlen)");
@@ -887,6 +921,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("reverse"), py::arg("zeroed"), py::arg("accumulate_dx"), py::arg("reverse_from") = 0);
     m.def("conv_update", &conv_update);
     m.def("conv_fwd_dual", &conv_fwd_dual);
+    m.def("conv_xproj_dual", &conv_xproj_dual);
     m.def("inner_fwd", &inner_fwd, py::arg("xz"), py::arg("conv_w"), py::arg("conv_b"), py::arg("x_proj_w"), py::arg("dt_proj_w"), py::arg("A"),
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
           py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());

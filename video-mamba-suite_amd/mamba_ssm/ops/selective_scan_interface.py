@@ -594,6 +594,24 @@ def _dual_conv(xz, conv_w, conv_b, conv_w_b, conv_b_b):
     return o, ob
 
 
+_CONV_XPROJ = os.environ.get("VMS_NO_CONV_XPROJ", "0") != "1"   # =1: conv1d and x_proj of a bidirectional block as separate launches (A/B, tests)
+
+
+def _conv_xproj_dual(xz, conv_w, conv_b, conv_w_b, conv_b_b, x_proj_w, x_proj_w_b):
+    """Both directions' conv1d + SiLU AND both x_proj products from ONE pass over x (vms_conv_xproj_dual: conv1d_out is written but never
+    read back) -> [conv_out, conv_out_b, x_dbl, x_dbl_b], or None when the kernel does not apply (then _dual_conv + x_proj_dual)."""
+    if not (_CONV_XPROJ and _DUAL_CONV and _PROJ_KRED and xz.is_cuda):
+        return None
+    ext = _vms.ext()
+    if ext is None or not hasattr(ext, "conv_xproj_dual"):
+        return None
+    d_inner = conv_w.shape[0]
+    cb = conv_b.contiguous() if conv_b is not None else None
+    cbb = conv_b_b.contiguous() if conv_b_b is not None else None
+    r = ext.conv_xproj_dual(xz[:, :d_inner], conv_w.squeeze(1), cb, conv_w_b.squeeze(1), cbb, x_proj_w, x_proj_w_b)
+    return r if len(r) == 4 else None
+
+
 class _SubCtx:
     """What _inner_forward / _inner_backward need from an autograd ctx, for nodes that run them more than once."""
 
@@ -637,12 +655,15 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         subs, out = [], None
         # conv1d of both directions from ONE pass over x (vms_causal_conv1d_fwd_dual): the second direction's filter runs
         # anti-causally over the same rows
-        conv_outs = _dual_conv(xz, params[0], params[1], params[n], params[n + 1])
+        fused = _conv_xproj_dual(xz, params[0], params[1], params[n], params[n + 1], params[2], params[n + 2])
+        conv_outs = fused[:2] if fused is not None else _dual_conv(xz, params[0], params[1], params[n], params[n + 1])
         # x_proj of both directions right behind it, while both outputs are (partly) in the 256 MB Infinity Cache: the second
         # direction's x_proj otherwise reads its operand from HBM after the first direction's scan (40 instead of 30 us)
         # (both as ONE launch of vms_proj_kred when the compiled binding is loaded)
         ext = _vms.ext() if conv_outs[0] is not None else None
-        if ext is not None and hasattr(ext, "x_proj_dual"):
+        if fused is not None:
+            x_dbls = fused[2:]
+        elif ext is not None and hasattr(ext, "x_proj_dual"):
             x_dbls = ext.x_proj_dual(params[2], conv_outs[0], params[n + 2], conv_outs[1], _PROJ_KRED)
         else:
             x_dbls = [torch.matmul(params[i * n + 2], conv_outs[i]) if conv_outs[i] is not None else None for i in range(2)]

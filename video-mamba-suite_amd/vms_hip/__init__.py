@@ -77,6 +77,11 @@ class ConvFwdDualParams(ctypes.Structure):
                 + [(n, _i64) for n in ("weight_b_c_stride", "weight_b_width_stride", "out_b_batch_stride", "out_b_c_stride")])
 
 
+class ConvXprojDualParams(ctypes.Structure):
+    _fields_ = ([("c", ConvFwdDualParams)] + [(n, _vp) for n in ("w_x", "w_x_b", "x_dbl", "x_dbl_b")]
+                + [(n, _i32) for n in ("m", "tile")] + [(n, _i64) for n in ("wx_row_stride", "xdbl_batch_stride", "xdbl_row_stride")])
+
+
 class NormParams(ctypes.Structure):
     _fields_ = (
         [(n, _i32) for n in ("rows", "cols", "x_dtype", "res_dtype", "is_rms")] + [("eps", ctypes.c_float)]
@@ -175,6 +180,7 @@ EXPORTS = (
     "vms_causal_conv1d_fwd_dual", "vms_sizeof_conv_fwd_dual_params",
     "vms_selective_scan_bwd_dual", "vms_scan_bwd_dual_fused",
     "vms_proj_kred", "vms_sizeof_proj_kred_params",
+    "vms_conv_xproj_dual", "vms_sizeof_conv_xproj_dual_params",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -290,7 +296,7 @@ def lib():
                          ("norm", NormParams), ("norm_bwd", NormBwdParams), ("state_update", StateUpdateParams),
                          ("proj_apply", ProjApplyParams), ("proj_wgrad", ProjWgradParams),
                          ("proj_conv_bwd", ProjConvBwdParams), ("prep", PrepParams), ("conv_fwd_dual", ConvFwdDualParams),
-                         ("proj_kred", ProjKredParams)):
+                         ("proj_kred", ProjKredParams), ("conv_xproj_dual", ConvXprojDualParams)):
             n = getattr(L, f"vms_sizeof_{name}_params")()
             if n != ctypes.sizeof(st):
                 raise ImportError(f"ABI mismatch: {name} params are {n} bytes in the library, "
@@ -641,6 +647,47 @@ def conv_fwd_dual(x, weight, bias, out, weight_b, bias_b, out_b, silu):
         raise RuntimeError("conv_fwd_dual: out_b must be (batch, dim, seqlen) with a unit seqlen stride")
     Q.out_b_batch_stride, Q.out_b_c_stride = out_b.stride(0), out_b.stride(1)
     _call("vms_causal_conv1d_fwd_dual", Q, x)
+
+
+def conv_xproj_dual_eligible(x, weight, bias, weight_b, bias_b, w_x, w_x_b):
+    """Does vms_conv_xproj_dual take the head of a bidirectional block's forward?  (16-bit x of one dtype with the x_proj weights, conv
+    weights in fp32 or that dtype, unit seqlen stride, seqlen / dim / strides multiples of 8, 16-byte aligned, m <= 96)"""
+    if not (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.dim() == 3 and x.stride(2) == 1 and w_x.dtype == x.dtype
+            and w_x_b.dtype == x.dtype and weight.dtype in (torch.float32, x.dtype) and weight_b.dtype == weight.dtype
+            and weight.shape == weight_b.shape and weight.dim() == 2 and 2 <= weight.shape[1] <= 4 and (bias is None) == (bias_b is None)):
+        return False
+    if (bias is not None and (bias.dtype != weight.dtype or bias_b.dtype != weight.dtype)) or w_x.shape != w_x_b.shape or w_x.stride() != w_x_b.stride():
+        return False
+    b, d, L = x.shape
+    m = w_x.shape[0]
+    if not (w_x.dim() == 2 and w_x.shape[1] == d and 1 <= m <= 96 and w_x.stride(1) == 1 and w_x.stride(0) % 8 == 0 and weight.shape[0] == d):
+        return False
+    if L % 8 or d % 8 or x.stride(0) % 8 or x.stride(1) % 8 or x.stride(1) < L or x.data_ptr() % 16 or w_x.data_ptr() % 16 or w_x_b.data_ptr() % 16:
+        return False
+    return ((d - 1) * x.stride(1) + L) * 2 < 2 ** 31 and ((d - 1) * L + L) * 2 < 2 ** 31
+
+
+def conv_xproj_dual(x, weight, bias, out, weight_b, bias_b, out_b, w_x, w_x_b, x_dbl, x_dbl_b, tile=0):
+    """out / out_b = both directions' causal_conv1d (+ SiLU) of x, x_dbl / x_dbl_b = w_x @ out / w_x_b @ out_b, one pass over x
+    (vms_hip.h vms_conv_xproj_dual)."""
+    if not conv_xproj_dual_eligible(x, weight, bias, weight_b, bias_b, w_x, w_x_b):
+        raise RuntimeError("conv_xproj_dual: not a problem this entry point takes (vms_hip.conv_xproj_dual_eligible)")
+    Q = ConvXprojDualParams()
+    fill_conv_fwd(Q.c.f, x, weight, bias, out, True)
+    Q.c.weight_b, Q.c.bias_b, Q.c.out_b = _ptr(weight_b), _ptr(bias_b), _ptr(out_b)
+    Q.c.weight_b_c_stride, Q.c.weight_b_width_stride = weight_b.stride()
+    if out.stride(2) != 1 or out_b.stride(2) != 1 or out.shape != x.shape or out_b.shape != x.shape or out.dtype != x.dtype or out_b.dtype != x.dtype:
+        raise RuntimeError("conv_xproj_dual: out / out_b must be (batch, dim, seqlen) in x's dtype with a unit seqlen stride")
+    Q.c.out_b_batch_stride, Q.c.out_b_c_stride = out_b.stride(0), out_b.stride(1)
+    m = w_x.shape[0]
+    for t in (x_dbl, x_dbl_b):
+        if tuple(t.shape) != (x.shape[0], m, x.shape[2]) or t.dtype != x.dtype or t.stride(2) != 1 or t.stride() != x_dbl.stride():
+            raise RuntimeError("conv_xproj_dual: x_dbl / x_dbl_b must be (batch, m, seqlen) in x's dtype with equal strides, unit seqlen stride")
+    Q.w_x, Q.w_x_b, Q.x_dbl, Q.x_dbl_b = _ptr(w_x), _ptr(w_x_b), _ptr(x_dbl), _ptr(x_dbl_b)
+    Q.m, Q.tile = m, int(tile)
+    Q.wx_row_stride = w_x.stride(0)
+    Q.xdbl_batch_stride, Q.xdbl_row_stride = x_dbl.stride(0), x_dbl.stride(1)
+    _call("vms_conv_xproj_dual", Q, x)
 
 
 def conv_bwd(x, weight, bias, dout, dx, dweight, dbias, silu, reverse=False, dx_accumulate=False, reverse_from=0):
