@@ -313,6 +313,10 @@ typedef struct {
 int vms_layer_norm_fwd(const vms_norm_params *p, void *stream);
 int vms_layer_norm_bwd(const vms_norm_bwd_params *p, void *stream);
 int vms_layer_norm_bwd_partials(const vms_norm_params *p);
+/* ABI v10: dw[c] = sum over the n_partials rows of dw_partial (and db from db_partial, both or neither), rounded to out_dtype
+ * (vms_dtype: the weight's) -- the sum the caller of vms_layer_norm_bwd owes, as one launch for both arrays.  cols % 4 == 0. */
+int vms_layer_norm_bwd_finish(const float *dw_partial, const float *db_partial, int n_partials, int cols, void *dw, void *db,
+                              int out_dtype, void *stream);
 
 /* ---- single-token SSM step ------------------------------------------------------------------
  * replaces the Triton kernel behind selective_state_update
@@ -483,6 +487,11 @@ typedef struct {
     vms_prep_job job[VMS_PREP_MAX_JOBS];
 } vms_prep_params;
 int vms_param_prep(const vms_prep_params *p, void *stream);
+/* ABI v10: dst[i] = sum_{s < n_slices} src[s * slice_stride + i], i < n -- the sum over the K slices of a weight-gradient GEMM that
+ * ran as a batched GEMM (this build's formulation of mamba_simple.py's in_proj / out_proj weight gradients: one workgroup per CU
+ * instead of 32 output tiles); 16-bit slices (src_dtype), fp32 accumulation, dst in dst_dtype (the parameter's).  n, slice_stride
+ * multiples of 8 elements. */
+int vms_sum_slices(const void *src, int src_dtype, int n_slices, int64_t n, int64_t slice_stride, void *dst, int dst_dtype, void *stream);
 int vms_sizeof_prep_params(void);
 
 int vms_abi_version(void);

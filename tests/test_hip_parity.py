@@ -1852,6 +1852,26 @@ def test_norm_any_residual_dtype(oracle, pair, N, is_rms, prenorm):
     check(b.grad, ob["db"], tol * 5, "dbias")
 
 
+@pytest.mark.parametrize("shape", [(2048, 768), (2048, 1024), (37, 384), (1, 8), (500, 2052)])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("has_db", [True, False])
+def test_norm_bwd_finish(shape, odt, has_db):
+    """vms_layer_norm_bwd_finish: the sum over the backward's partial rows, both arrays in one launch, vs a float64 sum"""
+    import vms_hip
+    torch.manual_seed(shape[0])
+    dwp = torch.randn(*shape, device=DEV)
+    dbp = torch.randn(*shape, device=DEV) if has_db else None
+    dw = torch.full((shape[1],), float("nan"), device=DEV, dtype=odt)
+    db = torch.full((shape[1],), float("nan"), device=DEV, dtype=odt) if has_db else None
+    vms_hip.norm_bwd_finish(dwp, dbp, dw, db)
+    for got, src in ((dw, dwp), (db, dbp)):
+        if got is None:
+            continue
+        want = src.double().sum(0)
+        tol = (2.0 ** -8 if odt == torch.bfloat16 else 1e-5) * max(want.abs().max().item(), 1.0) + 1e-6 * shape[0]
+        assert (got.double() - want).abs().max().item() <= tol
+
+
 def test_norm_extension_errors():
     import layer_norm_cuda
     x = torch.randn(4, 64, device=DEV)

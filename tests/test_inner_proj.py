@@ -271,6 +271,23 @@ def test_bidirectional_node_fused_head_vs_separate(monkeypatch):
         assert err <= 1e-3, f"tensor {i}: rel err {err:.3e}"     # identical forward values; atomics' order in the batch sums
 
 
+@pytest.mark.parametrize("shape", [(8, 2048, 1024), (14, 1536, 768), (16, 768, 768), (2, 96, 8), (1, 64, 64), (3, 5, 7)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("odt", [torch.float32, torch.bfloat16])
+def test_sum_slices(shape, dtype, odt):
+    """vms_sum_slices (the sum over the K slices of the large weight-gradient GEMMs) vs a float64 sum; shapes it declines go to torch"""
+    vms = _vms()
+    torch.manual_seed(shape[0])
+    t = torch.randn(*shape, device=DEV).to(dtype)
+    got = vms.sum_slices(t, odt)
+    assert got.dtype == odt and tuple(got.shape) == shape[1:]
+    want = t.double().sum(0)
+    tol = (2.0 ** -8 if odt == torch.bfloat16 else 2e-6) * max(want.abs().max().item(), 1.0) * (1 if odt == torch.bfloat16 else shape[0])
+    assert (got.double() - want).abs().max().item() <= tol
+    if (shape[1] * shape[2]) % 8 == 0 and shape[0] > 0:
+        assert vms.lib().vms_last_kernel().decode() == "sum_slices"
+
+
 def test_proj_kred_checks():
     vms = _vms()
     w = torch.randn(48, 128, device=DEV).bfloat16()

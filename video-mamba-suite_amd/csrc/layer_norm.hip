@@ -412,5 +412,53 @@ extern "C" int vms_layer_norm_bwd(const vms_norm_bwd_params* qq, void* stream) {
     VMS_NORM_DISPATCH(norm_bwd_launch, q_.f, vec, s);
 }
 
+// ---- sum of the backward's partial rows ---------------------------------------------------------------------
+// dw[c] = sum_p dw_partial[p][c] (and db): a workgroup owns 16 columns; thread = (row lane tid / 4, 4 columns tid % 4), 64 row
+// lanes walk the partial rows 64 apart with 16-byte loads (all of a thread's loads independent), their sums meet in LDS.
+// (torch's sum over the same (2048, 768) array: 14 us + a 5 us fill of its multi-block semaphores; this: one 5 us launch for both)
+namespace vms {
+template <typename TO>
+__global__ __launch_bounds__(256) void norm_bwd_finish_kernel(const float* __restrict__ dw_p, const float* __restrict__ db_p, const int n_part,
+                                                              const int cols, TO* __restrict__ dw, TO* __restrict__ db) {
+    __shared__ float red[64][17];
+    const float* const src = blockIdx.y ? db_p : dw_p;
+    TO* const dst = blockIdx.y ? db : dw;
+    const int rl = threadIdx.x >> 2, cg = threadIdx.x & 3;
+    const int c0 = blockIdx.x * 16 + 4 * cg;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c0 < cols) {      // cols % 4 == 0 (host)
+#pragma unroll 8
+        for (int r = rl; r < n_part; r += 64) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * cols + c0);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+    }
+    red[rl][4 * cg + 0] = a0; red[rl][4 * cg + 1] = a1; red[rl][4 * cg + 2] = a2; red[rl][4 * cg + 3] = a3;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float t = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) t += red[r][threadIdx.x];
+        const int c = blockIdx.x * 16 + threadIdx.x;
+        if (c < cols) dst[c] = static_cast<TO>(t);
+    }
+}
+}  // namespace vms
+
+extern "C" int vms_layer_norm_bwd_finish(const float* dw_partial, const float* db_partial, int n_partials, int cols, void* dw, void* db,
+                                         int out_dtype, void* stream) {
+    VMS_CHECK(dw_partial && dw && n_partials > 0 && cols > 0, "dw_partial, dw, n_partials, cols are required");
+    VMS_CHECK((db_partial == nullptr) == (db == nullptr), "db comes with db_partial");
+    VMS_CHECK(cols % 4 == 0 && aligned16(dw_partial) && (!db_partial || aligned16(db_partial)), "cols % 4 == 0 and 16-byte aligned partial rows");
+    VMS_CHECK(out_dtype == VMS_F32 || out_dtype == VMS_F16 || out_dtype == VMS_BF16, "out dtype must be fp32/fp16/bf16");
+    const dim3 grid((cols + 15) / 16, db_partial ? 2 : 1), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (out_dtype == VMS_F32) hipLaunchKernelGGL((vms::norm_bwd_finish_kernel<float>), grid, block, 0, s, dw_partial, db_partial, n_partials, cols, static_cast<float*>(dw), static_cast<float*>(db));
+    else if (out_dtype == VMS_F16) hipLaunchKernelGGL((vms::norm_bwd_finish_kernel<vms::f16_t>), grid, block, 0, s, dw_partial, db_partial, n_partials, cols, static_cast<vms::f16_t*>(dw), static_cast<vms::f16_t*>(db));
+    else hipLaunchKernelGGL((vms::norm_bwd_finish_kernel<vms::bf16_t>), grid, block, 0, s, dw_partial, db_partial, n_partials, cols, static_cast<vms::bf16_t*>(dw), static_cast<vms::bf16_t*>(db));
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+
 extern "C" int vms_sizeof_norm_params(void) { return (int)sizeof(vms_norm_params); }
 extern "C" int vms_sizeof_norm_bwd_params(void) { return (int)sizeof(vms_norm_bwd_params); }

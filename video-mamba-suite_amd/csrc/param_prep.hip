@@ -144,3 +144,49 @@ extern "C" int vms_param_prep(const vms_prep_params* pp, void* stream) {
     return VMS_OK;
 }
 extern "C" int vms_sizeof_prep_params(void) { return (int)sizeof(vms_prep_params); }
+
+// ---- sum of the K slices of a weight-gradient GEMM ---------------------------------------------------------
+// The block's large weight gradients run as a batched GEMM over K slices (one workgroup per CU) whose results are then summed
+// (mamba_ssm/ops/projections.py): dst[i] = sum_s src[s * slice_stride + i], 16-bit slices, fp32 accumulation, dst in the
+// parameter's dtype.  A thread owns 8 consecutive elements (one 16-byte load per slice, all independent).
+namespace vms {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void sum_slices_kernel(const TI* __restrict__ src, const int n_slices, const int64_t n, const int64_t slice_stride,
+                                                         TO* __restrict__ dst) {
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i0 >= n) return;      // n % 8 == 0 (host)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < n_slices; ++s) {
+        const vec_t<TI, 8> v = *reinterpret_cast<const vec_t<TI, 8>*>(src + (int64_t)s * slice_stride + i0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += static_cast<float>(v[e]);
+    }
+    vec_t<TO, 8> o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = static_cast<TO>(acc[e]);
+    *reinterpret_cast<vec_t<TO, 8>*>(dst + i0) = o;
+}
+template <typename TI>
+static int launch_sum_slices(const void* src, int n_slices, int64_t n, int64_t slice_stride, void* dst, int dst_dtype, hipStream_t s) {
+    const dim3 grid((unsigned)((n / 8 + 255) / 256)), block(256);
+    const TI* sp = static_cast<const TI*>(src);
+    if (dst_dtype == VMS_F32) hipLaunchKernelGGL((sum_slices_kernel<TI, float>), grid, block, 0, s, sp, n_slices, n, slice_stride, static_cast<float*>(dst));
+    else if (dst_dtype == VMS_F16) hipLaunchKernelGGL((sum_slices_kernel<TI, f16_t>), grid, block, 0, s, sp, n_slices, n, slice_stride, static_cast<f16_t*>(dst));
+    else hipLaunchKernelGGL((sum_slices_kernel<TI, bf16_t>), grid, block, 0, s, sp, n_slices, n, slice_stride, static_cast<bf16_t*>(dst));
+    VMS_LAUNCH_CHECK();
+    return VMS_OK;
+}
+}  // namespace vms
+
+extern "C" int vms_sum_slices(const void* src, int src_dtype, int n_slices, int64_t n, int64_t slice_stride, void* dst, int dst_dtype, void* stream) {
+    VMS_CHECK(src && dst && n_slices > 0 && n > 0, "src, dst, n_slices, n are required");
+    VMS_CHECK(src_dtype == VMS_BF16 || src_dtype == VMS_F16, "sum_slices: 16-bit slices (bf16 / fp16)");
+    VMS_CHECK(dst_dtype == VMS_F32 || dst_dtype == VMS_F16 || dst_dtype == VMS_BF16, "dst dtype must be fp32/fp16/bf16");
+    VMS_CHECK(n % 8 == 0 && slice_stride % 8 == 0 && slice_stride >= n && aligned16(src) && aligned16(dst) && n / 8 < ((int64_t)1 << 38),
+              "sum_slices: n and slice_stride multiples of 8 elements, 16-byte aligned src / dst");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    set_last_kernel("sum_slices");
+    return src_dtype == VMS_BF16 ? launch_sum_slices<bf16_t>(src, n_slices, n, slice_stride, dst, dst_dtype, s)
+                                 : launch_sum_slices<f16_t>(src, n_slices, n, slice_stride, dst, dst_dtype, s);
+}

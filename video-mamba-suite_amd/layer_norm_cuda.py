@@ -55,8 +55,13 @@ def bwd(dy, x, weight, bias, eps, mean, rstd, dresidual=None, has_residual=False
     dw_p = torch.empty((n_part, N), dtype=torch.float32, device=x.device)
     db_p = torch.empty((n_part, N), dtype=torch.float32, device=x.device) if bias is not None else None
     _k.norm_bwd(x, dy, weight.float(), mean, rstd, dresidual, dx, dresidual_in, dw_p, db_p, is_rms_norm)
-    dw = dw_p.sum(0).to(weight.dtype)
-    db = db_p.sum(0).to(bias.dtype) if bias is not None else None
+    if N % 4 == 0 and (bias is None or bias.dtype == weight.dtype):   # one launch sums both arrays (vms_layer_norm_bwd_finish)
+        dw = torch.empty(N, dtype=weight.dtype, device=x.device)
+        db = torch.empty(N, dtype=bias.dtype, device=x.device) if bias is not None else None
+        _k.norm_bwd_finish(dw_p, db_p, dw, db)
+    else:
+        dw = dw_p.sum(0).to(weight.dtype)
+        db = db_p.sum(0).to(bias.dtype) if bias is not None else None
     if has_residual and dx.dtype == x.dtype:  # no separate tensor needed in this case (layernorm.py:373-375)
         dresidual_in = dx
     return dx, dw, db, dresidual_in

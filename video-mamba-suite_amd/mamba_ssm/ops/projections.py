@@ -27,6 +27,15 @@ def _autocast_dtype():
     return torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
 
 
+def _sum_slices(t, w_dtype):
+    """sum over the K slices of a batched weight-gradient GEMM, in the parameter's dtype (vms_sum_slices on the GPU: one streaming
+    launch instead of torch's multi-block reduction + its semaphore fill)"""
+    if t.is_cuda and t.shape[0] > 1:
+        import vms_hip
+        return vms_hip.sum_slices(t, w_dtype)
+    return t.sum(0, dtype=w_dtype)
+
+
 def _k_splits(k_total, rows_out=2048, cols_out=1024, most=32):
     """Number of K slices for a weight-gradient GEMM (K = batch * seqlen, output rows_out x cols_out): the library tiles the
     small output 256 x 256, so slices x tiles should come to about one workgroup per CU -- 8 slices for in_proj at d_model 1024
@@ -149,7 +158,7 @@ def _in_proj_param_grads(g2, x2, channels, d_model, w_dtype, stack_halves, want_
         s = _k_splits(rows, channels, d_model)
         if x2.dtype != g2.dtype:
             x2 = x2.to(g2.dtype)
-        dweight = unstack(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)).sum(0, dtype=w_dtype))
+        dweight = unstack(_sum_slices(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)), w_dtype))
     if want_b:
         dbias = unstack(g2.sum(dim=1))
     return dweight, dbias
@@ -241,10 +250,10 @@ class OutProjFn(torch.autograd.Function):
                     # fill the chip (batch 1 at 65,536 positions was ONE 768 x 768 GEMM with K = 65,536: 196 -> 94 us)
                     rows = b_ * l_
                     ks = _k_splits(rows, dout.shape[2], c_)
-                    dweight = torch.bmm(dout.reshape(ks, rows // ks, -1).transpose(1, 2),
-                                        y.permute(1, 0, 2).reshape(c_, ks, rows // ks).permute(1, 2, 0)).sum(0, dtype=ctx.w_dtype)
+                    dweight = _sum_slices(torch.bmm(dout.reshape(ks, rows // ks, -1).transpose(1, 2),
+                                                    y.permute(1, 0, 2).reshape(c_, ks, rows // ks).permute(1, 2, 0)), ctx.w_dtype)
                 else:
-                    dweight = torch.bmm(dout.transpose(1, 2), y.transpose(1, 2)).sum(0, dtype=ctx.w_dtype)
+                    dweight = _sum_slices(torch.bmm(dout.transpose(1, 2), y.transpose(1, 2)), ctx.w_dtype)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 dbias = dout.sum(dim=(0, 1))
             return dy, dweight, dbias, None, None
@@ -257,7 +266,7 @@ class OutProjFn(torch.autograd.Function):
             dy2 = torch.matmul(wp.t(), dout.reshape(batch * seqlen, d_model).t())        # (C, B L), rows [c][half]
             dy = dy2.view(half_c, 2 * batch, seqlen).permute(1, 0, 2)                      # (2 B, C / 2, L), the scan's layout
         if ctx.needs_input_grad[1]:
-            dwp = torch.bmm(dout.transpose(1, 2), y2.view(2 * half_c, batch, seqlen).permute(1, 2, 0)).sum(0, dtype=ctx.w_dtype)   # (d_model, C) permuted
+            dwp = _sum_slices(torch.bmm(dout.transpose(1, 2), y2.view(2 * half_c, batch, seqlen).permute(1, 2, 0)), ctx.w_dtype)   # (d_model, C) permuted
             dweight = dwp.view(d_model, half_c, 2).transpose(1, 2).reshape(d_model, 2 * half_c)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dout.sum(dim=(0, 1))

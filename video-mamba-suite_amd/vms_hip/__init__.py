@@ -180,7 +180,7 @@ EXPORTS = (
     "vms_causal_conv1d_fwd_dual", "vms_sizeof_conv_fwd_dual_params",
     "vms_selective_scan_bwd_dual", "vms_scan_bwd_dual_fused",
     "vms_proj_kred", "vms_sizeof_proj_kred_params",
-    "vms_conv_xproj_dual", "vms_sizeof_conv_xproj_dual_params",
+    "vms_conv_xproj_dual", "vms_sizeof_conv_xproj_dual_params", "vms_layer_norm_bwd_finish", "vms_sum_slices",
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
@@ -739,6 +739,41 @@ def norm_bwd_partials(rows, cols):
     P = NormParams()
     P.rows, P.cols = rows, cols
     return lib().vms_layer_norm_bwd_partials(ctypes.byref(P))
+
+
+def sum_slices(t, out_dtype):
+    """t (n_slices, ...) contiguous, 16-bit -> t.sum(0, dtype=out_dtype) with fp32 accumulation as one streaming launch (vms_hip.h
+    vms_sum_slices); anything else (CPU, fp32 slices, odd sizes) goes to torch."""
+    n = t[0].numel() if t.dim() > 0 and t.shape[0] > 0 else 0
+    if not (t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.is_contiguous() and n > 0 and n % 8 == 0
+            and out_dtype in (torch.float32, torch.bfloat16, torch.float16) and t.data_ptr() % 16 == 0):
+        return t.sum(0, dtype=out_dtype)
+    out = torch.empty(t.shape[1:], dtype=out_dtype, device=t.device)
+    L = lib()
+    with torch.cuda.device(t.device):
+        rc = L.vms_sum_slices(ctypes.c_void_p(t.data_ptr()), dtype_code(t), int(t.shape[0]), ctypes.c_int64(n), ctypes.c_int64(n),
+                              ctypes.c_void_p(out.data_ptr()), _DTYPE[out_dtype], ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"vms_sum_slices failed ({rc}): {L.vms_last_error().decode()}")
+    return out
+
+
+def norm_bwd_finish(dw_partial, db_partial, dw, db):
+    """dw = dw_partial.sum(0) (and db), rounded to dw's dtype: one launch for both arrays (vms_hip.h vms_layer_norm_bwd_finish)"""
+    L = lib()
+    if not dw_partial.is_cuda:
+        raise RuntimeError("vms_layer_norm_bwd_finish: tensors must be on a GPU (no CPU path in this library)")
+    n_part, cols = dw_partial.shape
+    if (dw_partial.dtype != torch.float32 or not dw_partial.is_contiguous() or (db_partial is not None and (
+            db_partial.dtype != torch.float32 or not db_partial.is_contiguous() or db_partial.shape != dw_partial.shape))
+            or tuple(dw.shape) != (cols,) or not dw.is_contiguous() or (db is not None and (tuple(db.shape) != (cols,) or db.dtype != dw.dtype))):
+        raise RuntimeError("norm_bwd_finish: contiguous fp32 (n_partials, cols) partials and (cols,) outputs of one dtype expected")
+    with torch.cuda.device(dw_partial.device):
+        rc = L.vms_layer_norm_bwd_finish(ctypes.c_void_p(_ptr(dw_partial)), ctypes.c_void_p(_ptr(db_partial)), int(n_part), int(cols),
+                                         ctypes.c_void_p(_ptr(dw)), ctypes.c_void_p(_ptr(db)), dtype_code(dw),
+                                         ctypes.c_void_p(torch.cuda.current_stream(dw_partial.device).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"vms_layer_norm_bwd_finish failed ({rc}): {L.vms_last_error().decode()}")
 
 
 def norm_bwd(s, dy, weight, mean, rstd, dres_out, dx, dres_in, dw_partial, db_partial, is_rms):
