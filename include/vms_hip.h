@@ -374,6 +374,8 @@ typedef struct {
     int32_t batch, m, n, seqlen;
     int32_t dtype;
     int32_t tiles_per_wg;     /* 64-position tiles per workgroup (each workgroup ends with m x 128 atomics); 0 = automatic */
+    int32_t dw_transposed;    /* ABI v10: != 0: dw is stored (n, m) -- dw[n * dw_row_stride + m] -- e.g. ddt_proj.weight in the parameter's own layout */
+    int32_t reserved;
     const void *p, *q;
     float *dw;
     int64_t p_batch_stride, p_row_stride, q_batch_stride, q_row_stride;   /* elements; multiples of 8 */

@@ -84,6 +84,23 @@ def test_proj_wgrad_vs_matmul(shape, dtype):
     assert (dw.double() - 2 * want).abs().max().item() <= 2e-5 * scale + 1e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 48, 768, 3136), (8, 64, 1024, 1024), (1, 24, 384, 3152), (3, 17, 200, 72), (2, 128, 130, 136)])
+def test_proj_wgrad_transposed(shape):
+    """dw stored (n, m) -- ddt_proj.weight in the parameter's own (d_inner, dt_rank) layout -- == the (m, n) call, transposed"""
+    vms = _vms()
+    b, m, n, L = shape
+    torch.manual_seed(m * n)
+    p = torch.randn(b, m, L, device=DEV).bfloat16()
+    q = torch.randn(b, n, L, device=DEV).bfloat16()
+    dw, dwt = torch.zeros(m, n, device=DEV), torch.zeros(n, m, device=DEV)
+    vms.proj_wgrad(p, q, dw)
+    vms.proj_wgrad(p, q, dwt, transposed=True)
+    want = torch.einsum("bml,bnl->mn", p.double(), q.double())
+    scale = want.abs().max().item()
+    assert (dwt.t().double() - want).abs().max().item() <= 1e-4 * scale + 1e-5
+    assert (dwt.t() - dw).abs().max().item() <= 1e-4 * scale + 1e-5     # (the atomics' order differs)
+
+
 def test_proj_wgrad_strided_rows():
     vms = _vms()
     torch.manual_seed(1)

@@ -250,15 +250,34 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
         }
         __syncthreads();          // every wave has read tile t
     }
-    const int n = n0 + c32;
-    if (n < p.n) {
+    if (!p.dw_transposed) {
+        const int n = n0 + c32;
+        if (n < p.n) {
 #pragma unroll
-        for (int mb = 0; mb < MB; ++mb)
+            for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = 32 * mb + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m < p.m) atomicAdd(p.dw + (int64_t)m * p.dw_row_stride + n, acc[mb][v]);
-            }
+                for (int v = 0; v < 16; ++v) {
+                    const int m = 32 * mb + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (m < p.m) atomicAdd(p.dw + (int64_t)m * p.dw_row_stride + n, acc[mb][v]);
+                }
+        }
+        return;
+    }
+    // dw stored (n, m) -- dt_proj.weight's own (d_inner, dt_rank) layout, so that autograd keeps the gradient instead of copying a
+    // transposed view: 32 rows m at a time through an LDS tile [n][m], atomics with the lanes along m (128 contiguous bytes per half wave)
+    lds_f32* const tt = (lds_f32*)reinterpret_cast<float*>(smem);   // [128][33] floats: the staging tiles are free (last barrier of the loop)
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) tt[(wave * 32 + c32) * 33 + (v & 3) + 8 * (v >> 2) + 4 * h] = acc[mb][v];
+        __syncthreads();
+        const int ml = tid & 31, m = 32 * mb + ml;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int nl = (tid >> 5) + 8 * i, n = blockIdx.y * 128 + nl;
+            if (m < p.m && n < p.n) atomicAdd(p.dw + (int64_t)n * p.dw_row_stride + m, tt[nl * 33 + ml]);
+        }
+        __syncthreads();
     }
 }
 

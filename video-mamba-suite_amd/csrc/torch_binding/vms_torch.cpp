@@ -572,12 +572,14 @@ bool proj_wgrad_eligible(const Tensor& p, const Tensor& q) {
            p.size(1) <= 128;
 }
 // dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw: fp32 (m, n), unit column stride, zero-filled by the caller
-void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw) {
-    TORCH_CHECK(dw.scalar_type() == at::kFloat && dw.dim() == 2 && dw.stride(1) == 1 && dw.size(0) == p.size(1) && dw.size(1) == q.size(1),
-                "proj_wgrad: dw must be a float32 (m, n) matrix with unit column stride");
+// transposed: dw is the (n, m) matrix (a parameter stored that way receives a gradient in its own layout)
+void proj_wgrad(const Tensor& p, const Tensor& q, const Tensor& dw, bool transposed = false) {
+    TORCH_CHECK(dw.scalar_type() == at::kFloat && dw.dim() == 2 && dw.stride(1) == 1 && dw.size(transposed ? 1 : 0) == p.size(1) &&
+                    dw.size(transposed ? 0 : 1) == q.size(1),
+                "proj_wgrad: dw must be a float32 (m, n) matrix -- (n, m) when transposed -- with unit column stride");
     vms_proj_wgrad_params P{};
     P.batch = (int)p.size(0); P.m = (int)p.size(1); P.n = (int)q.size(1); P.seqlen = (int)p.size(2);
-    P.dtype = dtype_code(p);
+    P.dtype = dtype_code(p); P.dw_transposed = transposed;
     P.p = p.data_ptr(); P.q = q.data_ptr(); P.dw = dw.data_ptr<float>();
     P.p_batch_stride = p.stride(0); P.p_row_stride = p.stride(1);
     P.q_batch_stride = q.stride(0); P.q_row_stride = q.stride(1);
@@ -782,9 +784,9 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
     if (!kred_dt) dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)}).copy_(dbc.permute({1, 0, 2, 3}));
     Tensor ddt_proj_w, dx_proj_w;
     if (I.mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
-        Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({R, d});                  // (R, d) = ddt_proj_w^T
-        proj_wgrad(dt_in, ddelta, dw1);
-        ddt_proj_w = dw1.t().to(wdt);                                                       // (d, R)
+        Tensor dw1 = zeros.narrow(0, n_scan + n_conv, R * d).view({d, R});                  // (d, R): the parameter's own layout
+        proj_wgrad(dt_in, ddelta, dw1, /*transposed=*/true);
+        ddt_proj_w = dw1.to(wdt);
     } else {
         // (d, R) = sum over batch AND positions of ddelta dt_in^T.  With a small batch the library runs ONE skinny GEMM per entry
         // with K = seqlen (batch 1, 65,536 positions: 24 workgroups, 105 us): cut K into slices -- more, shorter GEMMs -- and

@@ -123,7 +123,7 @@ class ProjApplyParams(ctypes.Structure):
 
 class ProjWgradParams(ctypes.Structure):
     _fields_ = (
-        [(n, _i32) for n in ("batch", "m", "n", "seqlen", "dtype", "tiles_per_wg")]
+        [(n, _i32) for n in ("batch", "m", "n", "seqlen", "dtype", "tiles_per_wg", "dw_transposed", "reserved")]
         + [(n, _vp) for n in ("p", "q", "dw")]
         + [(n, _i64) for n in ("p_batch_stride", "p_row_stride", "q_batch_stride", "q_row_stride", "dw_row_stride")]
     )
@@ -811,16 +811,18 @@ def proj_apply(w, inp, out, accumulate=False, tiles_per_wg=0):
     _call("vms_proj_apply", P, inp)
 
 
-def proj_wgrad(p, q, dw, tiles_per_wg=0):
-    """dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw fp32 (m, n), added to with atomics (vms_hip.h vms_proj_wgrad)."""
+def proj_wgrad(p, q, dw, tiles_per_wg=0, transposed=False):
+    """dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw fp32 (m, n), added to with atomics (vms_hip.h vms_proj_wgrad).
+    transposed: dw is the (n, m) matrix instead (dw[n, m] += ...)."""
     P = ProjWgradParams()
     P.batch, P.m, P.seqlen = p.shape
     P.n = q.shape[1]
-    P.dtype, P.tiles_per_wg = dtype_code(p), int(tiles_per_wg)
+    P.dtype, P.tiles_per_wg, P.dw_transposed = dtype_code(p), int(tiles_per_wg), int(bool(transposed))
     if q.dtype != p.dtype or dw.dtype != torch.float32 or p.stride(2) != 1 or q.stride(2) != 1 or dw.stride(1) != 1:
         raise RuntimeError("proj_wgrad: p and q must share one 16-bit dtype with unit seqlen strides; dw fp32, unit column stride")
-    if tuple(dw.shape) != (p.shape[1], q.shape[1]) or q.shape[0] != p.shape[0] or q.shape[2] != p.shape[2]:
-        raise RuntimeError("proj_wgrad: p (batch, m, seqlen), q (batch, n, seqlen), dw (m, n) expected")
+    want = (q.shape[1], p.shape[1]) if transposed else (p.shape[1], q.shape[1])
+    if tuple(dw.shape) != want or q.shape[0] != p.shape[0] or q.shape[2] != p.shape[2]:
+        raise RuntimeError("proj_wgrad: p (batch, m, seqlen), q (batch, n, seqlen), dw (m, n) -- or (n, m) with transposed -- expected")
     P.p, P.q, P.dw = _ptr(p), _ptr(q), _ptr(dw)
     P.p_batch_stride, P.p_row_stride = p.stride(0), p.stride(1)
     P.q_batch_stride, P.q_row_stride = q.stride(0), q.stride(1)
