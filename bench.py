@@ -327,8 +327,9 @@ def projection_mfma(block, hidden, iters=20):
             "in_proj": (lambda x: in_proj_fn(x, block.in_proj.weight, block.in_proj.bias),
                         hidden.detach().clone().requires_grad_(), block.in_proj.weight),
             "out_proj": (lambda y: out_proj_fn(y, block.out_proj.weight, block.out_proj.bias),
-                         torch.randn(hidden.shape[0], block.out_proj.weight.shape[1], hidden.shape[1],
-                                     device=hidden.device, dtype=torch.bfloat16, requires_grad=True),
+                         # y in the layout the scans leave it in (channel-slowest, strides (L, B L, 1)): the path of the step
+                         torch.randn(block.out_proj.weight.shape[1], hidden.shape[0], hidden.shape[1], device=hidden.device,
+                                     dtype=torch.bfloat16).permute(1, 0, 2).requires_grad_(),
                          block.out_proj.weight),
         }
         for name, (fn, x, w) in cases.items():

@@ -27,10 +27,13 @@ def _autocast_dtype():
     return torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
 
 
+_SUM_SLICES = __import__("os").environ.get("VMS_NO_SUM_SLICES", "0") != "1"   # =1: torch's reduction (A/B)
+
+
 def _sum_slices(t, w_dtype):
     """sum over the K slices of a batched weight-gradient GEMM, in the parameter's dtype (vms_sum_slices on the GPU: one streaming
     launch instead of torch's multi-block reduction + its semaphore fill)"""
-    if t.is_cuda and t.shape[0] > 1:
+    if t.is_cuda and t.shape[0] > 1 and _SUM_SLICES:
         import vms_hip
         return vms_hip.sum_slices(t, w_dtype)
     return t.sum(0, dtype=w_dtype)

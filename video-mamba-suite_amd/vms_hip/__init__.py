@@ -345,6 +345,19 @@ def _call(fn_name, params, ref_tensor, params2=None):
         raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
 
 
+def _call_plain(fn_name, ref_tensor, *args):
+    """the entry points with a plain argument list (no parameter block): args, then the stream of ref_tensor's device"""
+    L = lib()
+    idx = ref_tensor.device.index
+    if idx == torch.cuda.current_device():
+        rc = getattr(L, fn_name)(*args, ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(idx)))
+    else:
+        with torch.cuda.device(ref_tensor.device):
+            rc = getattr(L, fn_name)(*args, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"{fn_name} failed (status {rc}): {L.vms_last_error().decode()}")
+
+
 def _call2(fn_name, pa, pb, ref_tensor):
     L = lib()
     if not ref_tensor.is_cuda:
@@ -749,18 +762,13 @@ def sum_slices(t, out_dtype):
             and out_dtype in (torch.float32, torch.bfloat16, torch.float16) and t.data_ptr() % 16 == 0):
         return t.sum(0, dtype=out_dtype)
     out = torch.empty(t.shape[1:], dtype=out_dtype, device=t.device)
-    L = lib()
-    with torch.cuda.device(t.device):
-        rc = L.vms_sum_slices(ctypes.c_void_p(t.data_ptr()), dtype_code(t), int(t.shape[0]), ctypes.c_int64(n), ctypes.c_int64(n),
-                              ctypes.c_void_p(out.data_ptr()), _DTYPE[out_dtype], ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream))
-    if rc != 0:
-        raise RuntimeError(f"vms_sum_slices failed ({rc}): {L.vms_last_error().decode()}")
+    _call_plain("vms_sum_slices", t, ctypes.c_void_p(t.data_ptr()), dtype_code(t), int(t.shape[0]), ctypes.c_int64(n), ctypes.c_int64(n),
+                ctypes.c_void_p(out.data_ptr()), _DTYPE[out_dtype])
     return out
 
 
 def norm_bwd_finish(dw_partial, db_partial, dw, db):
     """dw = dw_partial.sum(0) (and db), rounded to dw's dtype: one launch for both arrays (vms_hip.h vms_layer_norm_bwd_finish)"""
-    L = lib()
     if not dw_partial.is_cuda:
         raise RuntimeError("vms_layer_norm_bwd_finish: tensors must be on a GPU (no CPU path in this library)")
     n_part, cols = dw_partial.shape
@@ -768,12 +776,8 @@ def norm_bwd_finish(dw_partial, db_partial, dw, db):
             db_partial.dtype != torch.float32 or not db_partial.is_contiguous() or db_partial.shape != dw_partial.shape))
             or tuple(dw.shape) != (cols,) or not dw.is_contiguous() or (db is not None and (tuple(db.shape) != (cols,) or db.dtype != dw.dtype))):
         raise RuntimeError("norm_bwd_finish: contiguous fp32 (n_partials, cols) partials and (cols,) outputs of one dtype expected")
-    with torch.cuda.device(dw_partial.device):
-        rc = L.vms_layer_norm_bwd_finish(ctypes.c_void_p(_ptr(dw_partial)), ctypes.c_void_p(_ptr(db_partial)), int(n_part), int(cols),
-                                         ctypes.c_void_p(_ptr(dw)), ctypes.c_void_p(_ptr(db)), dtype_code(dw),
-                                         ctypes.c_void_p(torch.cuda.current_stream(dw_partial.device).cuda_stream))
-    if rc != 0:
-        raise RuntimeError(f"vms_layer_norm_bwd_finish failed ({rc}): {L.vms_last_error().decode()}")
+    _call_plain("vms_layer_norm_bwd_finish", dw_partial, ctypes.c_void_p(_ptr(dw_partial)), ctypes.c_void_p(_ptr(db_partial)), int(n_part), int(cols),
+                ctypes.c_void_p(_ptr(dw)), ctypes.c_void_p(_ptr(db)), dtype_code(dw))
 
 
 def norm_bwd(s, dy, weight, mean, rstd, dres_out, dx, dres_in, dw_partial, db_partial, is_rms):
