@@ -473,7 +473,7 @@ int vms_proj_conv_bwd(const vms_proj_conv_bwd_params *p, void *stream);
  *   VMS_PREP_CAST     dst (rows, cols) = src converted to dst_dtype
  *   VMS_PREP_CAST_T   dst (cols, rows) = src^T converted to dst_dtype
  *   VMS_PREP_NEG_EXP  dst (rows, cols) = -exp(src) (fp32 arithmetic)
- * Row strides in elements; src and dst of different jobs may not overlap a job's dst. */
+ * Row strides in elements; src and dst of different jobs may not overlap a job's dst (interleaved halves are disjoint elements). */
 enum { VMS_PREP_CAST = 0, VMS_PREP_CAST_T = 1, VMS_PREP_NEG_EXP = 2 };
 #define VMS_PREP_MAX_JOBS 8
 typedef struct {
@@ -482,7 +482,9 @@ typedef struct {
     int32_t rows, cols;
     int64_t src_row_stride, dst_row_stride;
     int32_t src_dtype, dst_dtype;   /* vms_dtype */
-    int32_t op, reserved;
+    int32_t op;
+    int32_t dst_col_stride;         /* ABI v10: elements between consecutive destination columns; 0 = 1.  2 = one half of an
+                                     * interleaved matrix (the DBM block's stacked projections, projections.py InProjFn / OutProjFn) */
 } vms_prep_job;
 typedef struct {
     int32_t n_jobs, reserved;

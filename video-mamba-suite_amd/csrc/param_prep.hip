@@ -40,9 +40,10 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p
     const vms_prep_job& q = p.job[j];
     const int tc = (q.cols + kTile - 1) / kTile;
     const int r0 = (t / tc) * kTile, c0 = (t % tc) * kTile;
+    const int64_t dcs = q.dst_col_stride > 0 ? q.dst_col_stride : 1;   // destination columns `dcs` elements apart (interleaved halves)
     // whole tiles of an fp32 matrix going to a 16-bit one (every job of a ViM block but the two A): 16 consecutive values
     // per thread, 16-byte accesses on both sides
-    if (q.op != VMS_PREP_NEG_EXP && q.src_dtype == VMS_F32 && q.dst_dtype != VMS_F32 && r0 + kTile <= q.rows && c0 + kTile <= q.cols &&
+    if (q.op != VMS_PREP_NEG_EXP && dcs == 1 && q.src_dtype == VMS_F32 && q.dst_dtype != VMS_F32 && r0 + kTile <= q.rows && c0 + kTile <= q.cols &&
         (q.src_row_stride & 3) == 0 && (q.dst_row_stride & 7) == 0 && ((uintptr_t)q.src & 15) == 0 && ((uintptr_t)q.dst & 15) == 0) {
         const int row = threadIdx.x >> 2, seg = (threadIdx.x & 3) * 16;
         const float4* sp = reinterpret_cast<const float4*>(static_cast<const float*>(q.src) + (int64_t)(r0 + row) * q.src_row_stride + c0 + seg);
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p
         for (int k = 0; k < kTile / 4; ++k) {
             const int r = r0 + ty + 4 * k, c = c0 + tx;
             if (r < q.rows && c < q.cols)
-                st_f(q.dst, (int64_t)r * q.dst_row_stride + c, q.dst_dtype, q.op == VMS_PREP_NEG_EXP ? -expf(v[k]) : v[k]);
+                st_f(q.dst, (int64_t)r * q.dst_row_stride + c * dcs, q.dst_dtype, q.op == VMS_PREP_NEG_EXP ? -expf(v[k]) : v[k]);
         }
         return;
     }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void param_prep_kernel(const vms_prep_params p
 #pragma unroll 4
     for (int k = 0; k < kTile / 4; ++k) {
         const int c = c0 + ty + 4 * k, r = r0 + tx;   // dst row c, dst column r
-        if (r < q.rows && c < q.cols) st_f(q.dst, (int64_t)c * q.dst_row_stride + r, q.dst_dtype, tile[tx][ty + 4 * k]);
+        if (r < q.rows && c < q.cols) st_f(q.dst, (int64_t)c * q.dst_row_stride + r * dcs, q.dst_dtype, tile[tx][ty + 4 * k]);
     }
 }
 
@@ -133,7 +134,9 @@ extern "C" int vms_param_prep(const vms_prep_params* pp, void* stream) {
         VMS_CHECK(q.src && q.dst && q.rows > 0 && q.cols > 0, "job: src, dst and a non-empty shape are required");
         VMS_CHECK(q.op >= VMS_PREP_CAST && q.op <= VMS_PREP_NEG_EXP, "job: unknown op");
         VMS_CHECK(q.src_dtype >= VMS_F32 && q.src_dtype <= VMS_BF16 && q.dst_dtype >= VMS_F32 && q.dst_dtype <= VMS_BF16, "job: dtype");
-        VMS_CHECK(q.src_row_stride >= q.cols && q.dst_row_stride >= (q.op == VMS_PREP_CAST_T ? q.rows : q.cols), "job: row strides");
+        VMS_CHECK(q.dst_col_stride >= 0 && q.src_row_stride >= q.cols &&
+                      q.dst_row_stride >= (int64_t)(q.op == VMS_PREP_CAST_T ? q.rows : q.cols) * (q.dst_col_stride > 0 ? q.dst_col_stride : 1),
+                  "job: row strides");
         tiles += (int64_t)((q.rows + kTile - 1) / kTile) * ((q.cols + kTile - 1) / kTile);
     }
     if (tiles == 0) return VMS_OK;

@@ -159,6 +159,40 @@ class MambaCore(nn.Module):
         vms_hip.param_prep(jobs)
         return dict(wt_in=lows[0], small=tuple(lows[1:5]), w_out=lows[5], A=A2[0], A_b=A2[1])
 
+    def _prepare_params_dbm(self, hidden_states):
+        """The DBM block's per-step parameter preparation as ONE launch: in_proj's weight as the K-contiguous (d_model, channels)
+        matrix whose columns are ordered [c][half] (what InProjFn's stack_halves wants: two transposing jobs, one per half, into
+        interleaved columns), x_proj / dt_proj weights in the compute dtype, out_proj's weight with its columns ordered [c][half]
+        (OutProjFn's stacked_halves), A = -exp(A_log) -- five small kernels per step otherwise.  None = the nodes prepare their own."""
+        if not (_PARAM_PREP and hidden_states.is_cuda and torch.is_autocast_enabled()):
+            return None
+        dt = torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
+        ws = (self.in_proj.weight, self.x_proj.weight, self.dt_proj.weight, self.out_proj.weight)
+        if dt not in (torch.bfloat16, torch.float16) or any(w.dtype != torch.float32 or not w.is_contiguous() for w in ws) \
+                or self.A_log.dtype != torch.float32 or self.in_proj.weight.shape[0] % 2 or self.out_proj.weight.shape[1] % 2:
+            return None
+        import vms_hip
+        dev = hidden_states.device
+        sizes = [(w.numel() + 127) // 128 * 128 for w in ws]
+        flat = torch.empty(sum(sizes), dtype=dt, device=dev)
+        o, lows = 0, []
+        for w, n in zip(ws, sizes):
+            lows.append(flat[o:o + w.numel()])
+            o += n
+        w_in, w_out = self.in_proj.weight.detach(), self.out_proj.weight.detach()
+        ch, dm = w_in.shape                                      # channels = 2 halves x (2 d_inner), d_model
+        wt_in = lows[0].view(dm, ch)                             # column 2 c + half <- row half * ch/2 + c of the weight
+        w_x, w_dt = lows[1].view(self.x_proj.weight.shape), lows[2].view(self.dt_proj.weight.shape)
+        C = w_out.shape[1]
+        wp_out = lows[3].view(w_out.shape[0], C)                 # column 2 c + half <- column half * C/2 + c of the weight
+        A = torch.empty_like(self.A_log)
+        jobs = [(w_in[h * (ch // 2):(h + 1) * (ch // 2)], wt_in[:, h::2], vms_hip.PREP_CAST_T) for h in range(2)]
+        jobs += [(self.x_proj.weight.detach(), w_x, vms_hip.PREP_CAST), (self.dt_proj.weight.detach(), w_dt, vms_hip.PREP_CAST)]
+        jobs += [(w_out[:, h * (C // 2):(h + 1) * (C // 2)], wp_out[:, h::2], vms_hip.PREP_CAST) for h in range(2)]
+        jobs += [(self.A_log.detach(), A, vms_hip.PREP_NEG_EXP)]
+        vms_hip.param_prep(jobs)
+        return dict(wt_in=wt_in, small=(w_x, w_dt), w_out=wp_out, A=A)
+
     def python_mamba_inner_fn_no_out_proj(self, xz, A, conv_state, ssm_state, seqlen, conv1d, x_proj, dt_proj, D,
                                           use_pytorch_conv=False):
         """Unfused path (use_fast_path=False): separate conv, projections and scan ops."""
@@ -275,13 +309,22 @@ class MambaCore(nn.Module):
             # both halves as one node: the projection emits them stacked on the batch axis, entries >= B run right-to-left
             # (the reference stacks a flipped copy of the second half, mamba_new.py:192-213, and flips its output back)
             batch = hidden_states.shape[0]
-            xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True)    # (2 B, 2 d, L)
-            A = NegExpFn.apply(self.A_log)
+            prep = self._prepare_params_dbm(hidden_states)
+            if prep is None:
+                xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True)    # (2 B, 2 d, L)
+                A = NegExpFn.apply(self.A_log)
+                out = mamba_inner_fn_no_out_proj(
+                    xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
+                    self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,
+                    checkpoint_lvl=_CHECKPOINT_LVL)                                                            # (2 B, d, L)
+                return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True)
+            xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True, wt_prepared=prep["wt_in"])
+            A = NegExpFn.apply(self.A_log, prep["A"])
             out = mamba_inner_fn_no_out_proj(
                 xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
                 self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,
-                checkpoint_lvl=_CHECKPOINT_LVL)                                                            # (2 B, d, L)
-            return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True)
+                checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"])
+            return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True, w_prepared=prep["w_out"])
         xz = self._in_projection(hidden_states)
         xz_f, xz_b = torch.chunk(xz, 2, dim=1)
         if _USE_REVERSE_KERNELS:

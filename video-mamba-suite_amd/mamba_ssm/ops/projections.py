@@ -28,6 +28,23 @@ def _autocast_dtype():
 
 
 _SUM_SLICES = __import__("os").environ.get("VMS_NO_SUM_SLICES", "0") != "1"   # =1: torch's reduction (A/B)
+_mm_out_dtype_ok = [None]   # does torch.mm(a, b, out_dtype=torch.float32) work for 16-bit operands on this build / device?
+
+
+def _mm_wgrad(a, b, w_dtype):
+    """a (m, k) @ b (k, n) -> (m, n) in the parameter's dtype: an unsliced weight gradient.  With 16-bit operands and an fp32
+    parameter the GEMM writes fp32 itself (out_dtype: no cast kernel behind it, no rounding to 16 bits in between) where the
+    library offers that; otherwise the product in the operands' dtype, then the cast."""
+    if a.is_cuda and w_dtype == torch.float32 and a.dtype in (torch.bfloat16, torch.float16) and _mm_out_dtype_ok[0] is not False:
+        try:
+            r = torch.mm(a, b, out_dtype=torch.float32)
+            _mm_out_dtype_ok[0] = True
+            return r
+        except (RuntimeError, TypeError):
+            if _mm_out_dtype_ok[0]:
+                raise
+            _mm_out_dtype_ok[0] = False
+    return torch.mm(a, b).to(w_dtype)
 
 
 def _sum_slices(t, w_dtype):
@@ -93,7 +110,8 @@ class InProjFn(torch.autograd.Function):
         transposed = hidden.is_cuda and (wt_prepared is not None or dt != weight.dtype)
         if transposed:
             if wt_prepared is not None:
-                assert not stack_halves and wt_prepared.dtype == dt and tuple(wt_prepared.shape) == (d_model, channels)
+                # (with stack_halves: the prepared copy already has its columns in the order [c][half])
+                assert wt_prepared.dtype == dt and tuple(wt_prepared.shape) == (d_model, channels)
                 wt = wt_prepared
             else:
                 # W^T as its own (d_model, channels) matrix in the compute dtype: cast and transpose in one copy kernel
@@ -161,7 +179,15 @@ def _in_proj_param_grads(g2, x2, channels, d_model, w_dtype, stack_halves, want_
         s = _k_splits(rows, channels, d_model)
         if x2.dtype != g2.dtype:
             x2 = x2.to(g2.dtype)
-        dweight = unstack(_sum_slices(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)), w_dtype))
+        if s == 1 and stack_halves and g2.is_cuda and w_dtype == torch.float32 and _mm_out_dtype_ok[0]:
+            # the rows of g2 are ordered [c][half]: as the strided (half, c, rows) view the two halves are two batched GEMMs whose
+            # (2, C / 2, d_model) result IS the parameter's row order -- no un-stacking copy behind the GEMM
+            g3 = g2.view(channels // 2, 2, rows).permute(1, 0, 2)
+            dweight = torch.bmm(g3, x2.unsqueeze(0).expand(2, -1, -1), out_dtype=torch.float32).view(channels, d_model)
+        elif s == 1:
+            dweight = unstack(_mm_wgrad(g2, x2, w_dtype))
+        else:
+            dweight = unstack(_sum_slices(torch.bmm(g2.view(channels, s, rows // s).permute(1, 0, 2), x2.view(s, rows // s, d_model)), w_dtype))
     if want_b:
         dbias = unstack(g2.sum(dim=1))
     return dweight, dbias
@@ -215,8 +241,12 @@ class OutProjFn(torch.autograd.Function):
         b2, half_c, seqlen = y.shape
         batch, d_model = b2 // 2, weight.shape[0]
         dt = (_autocast_dtype() or weight.dtype) if y.is_cuda else weight.dtype
-        wp = torch.empty(d_model, 2 * half_c, dtype=dt, device=weight.device)     # column c * 2 + half <- column half * C/2 + c
-        wp.view(d_model, half_c, 2).copy_(weight.view(d_model, 2, half_c).transpose(1, 2))
+        if w_prepared is not None:     # the block's one-launch preparation made the permuted copy
+            assert w_prepared.dtype == dt and tuple(w_prepared.shape) == (d_model, 2 * half_c)
+            wp = w_prepared
+        else:
+            wp = torch.empty(d_model, 2 * half_c, dtype=dt, device=weight.device)     # column c * 2 + half <- column half * C/2 + c
+            wp.view(d_model, half_c, 2).copy_(weight.view(d_model, 2, half_c).transpose(1, 2))
         y2 = y.permute(1, 0, 2).reshape(2 * half_c, batch * seqlen)                 # a view in the scan's layout
         if y2.dtype != dt:
             y2 = y2.to(dt)
@@ -269,7 +299,8 @@ class OutProjFn(torch.autograd.Function):
             dy2 = torch.matmul(wp.t(), dout.reshape(batch * seqlen, d_model).t())        # (C, B L), rows [c][half]
             dy = dy2.view(half_c, 2 * batch, seqlen).permute(1, 0, 2)                      # (2 B, C / 2, L), the scan's layout
         if ctx.needs_input_grad[1]:
-            dwp = _sum_slices(torch.bmm(dout.transpose(1, 2), y2.view(2 * half_c, batch, seqlen).permute(1, 2, 0)), ctx.w_dtype)   # (d_model, C) permuted
+            # (d_model, C) permuted: ONE GEMM over the flattened rows (y2 is the (C, B L) matrix), fp32 out of the GEMM where offered
+            dwp = _mm_wgrad(dout.reshape(batch * seqlen, d_model).t(), y2.t(), ctx.w_dtype)
             dweight = dwp.view(d_model, half_c, 2).transpose(1, 2).reshape(d_model, 2 * half_c)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = dout.sum(dim=(0, 1))

@@ -512,8 +512,14 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
     @custom_fwd
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                 A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False, reverse_from=0):
-        """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)"""
+                C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False, reverse_from=0,
+                x_proj_prepared=None, delta_proj_prepared=None):
+        """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)
+        x_proj_prepared / delta_proj_prepared (extension): the two projection weights already in the autocast dtype (the block's
+        one-launch parameter preparation); used instead of casting here, no gradient (it goes to the parameters)."""
+        if x_proj_prepared is not None:
+            ctx.w_dtype_override = x_proj_weight.dtype      # the PARAMETERS' dtype, not that of the prepared copies
+            x_proj_weight, delta_proj_weight = x_proj_prepared, delta_proj_prepared
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               None, A, None, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
                               delta_softplus, checkpoint_lvl, reverse, reverse_from=reverse_from)
@@ -524,7 +530,7 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
         g = _inner_backward(ctx, dout)
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
                 g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
-                None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class NegExpPairFn(torch.autograd.Function):
@@ -556,7 +562,11 @@ class NegExpFn(torch.autograd.Function):
     `-torch.exp(x.float())` costs 2 + 2 small kernels: the DBM block's step is ~30 kernels of a few microseconds each."""
 
     @staticmethod
-    def forward(ctx, a_log):
+    def forward(ctx, a_log, prepared=None):
+        """prepared: -exp(a_log) already computed (the block's one-launch parameter preparation); this node then only routes the gradient"""
+        if prepared is not None:
+            ctx.save_for_backward(prepared)
+            return prepared.view_as(prepared)
         if a_log.is_cuda and a_log.dtype == torch.float32 and a_log.is_contiguous() and a_log.dim() == 2:
             out = torch.empty_like(a_log)
             _vms.param_prep([(a_log.detach(), out, _vms.PREP_NEG_EXP)])
@@ -568,7 +578,7 @@ class NegExpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (a,) = ctx.saved_tensors
-        return g * a   # d(-exp(x)) = -exp(x) dx
+        return g * a, None   # d(-exp(x)) = -exp(x) dx
 
 
 _DUAL_CONV = os.environ.get("VMS_NO_DUAL_CONV", "0") != "1"   # =1: one conv1d launch per direction (A/B, tests)
@@ -786,9 +796,10 @@ def bimamba_inner_fn(
 def mamba_inner_fn_no_out_proj(
     xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1, reverse_from=0
+    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1, reverse_from=0, prepared=None
 ):
-    """reverse (extension, default off): the node runs right-to-left over xz -- the value of
+    """prepared (extension): None or (x_proj_weight, delta_proj_weight) already in the autocast dtype.
+    reverse (extension, default off): the node runs right-to-left over xz -- the value of
     flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for.
     reverse_from (extension): batch entries >= reverse_from run right-to-left, the others left-to-right -- the DBM block's
     two halves (shared weights) as ONE node on a batch of 2 B (mamba_new.py:192-213 stacks a flipped copy instead).
@@ -802,7 +813,7 @@ def mamba_inner_fn_no_out_proj(
         return selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                        A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                                       checkpoint_lvl, reverse, reverse_from)
+                                       checkpoint_lvl, reverse, reverse_from, *(prepared or ()))
 
 
 # ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------

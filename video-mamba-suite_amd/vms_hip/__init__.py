@@ -155,7 +155,7 @@ class ProjConvBwdParams(ctypes.Structure):
 
 class PrepJob(ctypes.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("rows", _i32), ("cols", _i32), ("src_row_stride", _i64), ("dst_row_stride", _i64),
-                ("src_dtype", _i32), ("dst_dtype", _i32), ("op", _i32), ("reserved", _i32)]
+                ("src_dtype", _i32), ("dst_dtype", _i32), ("op", _i32), ("dst_col_stride", _i32)]
 
 
 PREP_MAX_JOBS = 8
@@ -939,7 +939,8 @@ def state_update(state, x, dt, A, B, C, D, z, dt_bias, out, dt_softplus):
 
 
 def param_prep(jobs):
-    """jobs: up to PREP_MAX_JOBS triples (src, dst, op) of 2-D tensors with unit column stride (1-D ones count as one row):
+    """jobs: up to PREP_MAX_JOBS triples (src, dst, op) of 2-D tensors (1-D ones count as one row), src with a unit column stride, dst
+    with any column stride (2 = one half of an interleaved matrix):
     PREP_CAST dst = src in dst's dtype, PREP_CAST_T dst = src^T, PREP_NEG_EXP dst = -exp(src); one launch (vms_hip.h)."""
     P = PrepParams()
     assert 0 < len(jobs) <= PREP_MAX_JOBS
@@ -947,9 +948,10 @@ def param_prep(jobs):
     for j, (src, dst, op) in zip(P.job, jobs):
         s2 = src if src.dim() == 2 else src.reshape(1, -1)
         d2 = dst if dst.dim() == 2 else dst.reshape(1, -1)
-        if s2.stride(1) != 1 or d2.stride(1) != 1 or tuple(d2.shape) != (tuple(s2.shape) if op != PREP_CAST_T else tuple(s2.shape[::-1])):
-            raise RuntimeError("param_prep: jobs are (rows, cols) matrices with unit column stride and matching shapes")
+        if s2.stride(1) != 1 or d2.stride(1) < 1 or tuple(d2.shape) != (tuple(s2.shape) if op != PREP_CAST_T else tuple(s2.shape[::-1])):
+            raise RuntimeError("param_prep: jobs are (rows, cols) matrices, src with a unit column stride, and matching shapes")
         j.src, j.dst, j.rows, j.cols = _ptr(s2), _ptr(d2), s2.shape[0], s2.shape[1]
+        j.dst_col_stride = d2.stride(1) if d2.shape[1] > 1 else 1
         j.src_row_stride, j.dst_row_stride = s2.stride(0) if s2.shape[0] > 1 else s2.shape[1], d2.stride(0) if d2.shape[0] > 1 else d2.shape[1]
         j.src_dtype, j.dst_dtype, j.op = dtype_code(s2), dtype_code(d2), op
     _call("vms_param_prep", P, jobs[0][0])
