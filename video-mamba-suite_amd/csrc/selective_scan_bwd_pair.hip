@@ -932,13 +932,15 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
             // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
-            asm volatile("s_nop 1\n\t"
-                         "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
-                         "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
-                         "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
-                         "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
-                         : "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]), "+v"(vb[4]), "+v"(vb[5]), "+v"(vb[6]), "+v"(vb[7]),
-                           "+v"(vc[0]), "+v"(vc[1]), "+v"(vc[2]), "+v"(vc[3]), "+v"(vc[4]), "+v"(vc[5]), "+v"(vc[6]), "+v"(vc[7]));
+            // one asm statement per pair: with all 16 values tied to ONE statement the register allocator gathered them with ~9
+            // v_mov per state (167 -> 59 per chunk, 2,511 -> 2,403 VALU instructions; the compiler's own permlane*_swap builtins
+            // mis-assign the second result inside this loop -- tools/microbench/swap_probe.hip shows them correct in isolation).
+            // The products are final before the first swap (no instruction moves across the scheduling barrier): its s_nop
+            // covers the VALU-write -> swap-read wait states for all eight.
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vb[0]), "+v"(vc[0]));
+#pragma unroll
+            for (int i = 1; i < K; ++i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(vb[i]), "+v"(vc[i]));
             f2 t2[K / 2];
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) t2[k] = f2{vb[2 * k], vb[2 * k + 1]} + f2{vc[2 * k], vc[2 * k + 1]};
@@ -946,10 +948,10 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             float t[K];
 #pragma unroll
             for (int i = 0; i < K; ++i) t[i] = VMS_EL(t2, i);
-            asm volatile("s_nop 1\n\t"
-                         "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\t"
-                         "v_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7"
-                         : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t[0]), "+v"(t[4]));
+#pragma unroll
+            for (int i = 1; i < K / 2; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(t[i + 4]));
             const f2 o0 = f2{t[0], t[1]} + f2{t[4], t[5]}, o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
             slab4[(buf * kB4Pair + st * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
                 __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
