@@ -887,7 +887,8 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
     const __amdgpu_buffer_rsrc_t wa_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w_x), 0, w_bytes, kPBufFlags);
     const __amdgpu_buffer_rsrc_t wb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(q.w_x_b), 0, w_bytes, kPBufFlags);
     // conv taps / biases: thread t < 128 owns (direction t >> 6, channel t & 63) of the block; a missing bias is a resource of size 0
-    const int t_dir = (tid >> 6) & 1, t_ch = tid & 63;
+    const int t_dir = wave & 1, t_ch = tid & 63;     // (from the wave index, a scalar: the two resources below stay in SGPRs -- built from a
+                                                     // per-thread value they are "divergent" and every load through them becomes a waterfall loop)
     const int64_t cw_c = t_dir ? q.c.weight_b_c_stride : p.weight_c_stride, cw_w = t_dir ? q.c.weight_b_width_stride : p.weight_width_stride;
     const __amdgpu_buffer_rsrc_t cw_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(t_dir ? q.c.weight_b : p.weight), 0, (int)(((int64_t)(K - 1) * cw_c + (int64_t)(p.width - 1) * cw_w + 1) * sizeof(WT_)), kPBufFlags);
