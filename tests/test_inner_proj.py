@@ -305,6 +305,40 @@ def test_sum_slices(shape, dtype, odt):
         assert vms.lib().vms_last_kernel().decode() == "sum_slices"
 
 
+def test_proj_kred_and_fused_head_random_shapes():
+    """Random small problems (every tile tail, channel-block tail and row-count class): vms_proj_kred vs float64 products, the fused head
+    vs the two launches it replaces, bit for bit."""
+    import random
+    vms = _vms()
+    rnd = random.Random(20250930)
+    for it in range(24):
+        b, d, L = rnd.randint(1, 3), 8 * rnd.randint(1, 40), 8 * rnd.randint(1, 60)
+        m, width = rnd.randint(1, 96), rnd.randint(2, 4)
+        torch.manual_seed(it)
+        x = torch.randn(b, d, L, device=DEV).bfloat16()
+        w = (torch.randn(m, d, device=DEV) * d ** -0.5).bfloat16()
+        out = torch.full((b, m, L), float("nan"), device=DEV, dtype=torch.bfloat16)
+        tile = rnd.choice([0, 64, 128, 256])
+        vms.proj_kred(w, x, out, tile=tile)
+        want = w.double() @ x.double()
+        assert (out.double() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item() * 1.01 + 1e-6, (b, d, L, m, tile)
+        if m % 8 == 0:      # the transposed weight form needs whole 16-byte pieces along m
+            wt = w.t().contiguous()                                        # (d, m): read as its transpose
+            out2 = torch.full_like(out, float("nan"))
+            vms.proj_kred(wt.t(), x, out2, tile=tile)
+            assert torch.equal(out2, out), (b, d, L, m, tile, "transposed weight")
+        cw, cwb = torch.randn(d, width, device=DEV) * 0.4, torch.randn(d, width, device=DEV) * 0.4
+        cb, cbb = (torch.randn(d, device=DEV) * 0.2, torch.randn(d, device=DEV) * 0.2) if it % 2 else (None, None)
+        wb = (torch.randn(m, d, device=DEV) * d ** -0.5).bfloat16()
+        ro, rob = torch.empty_like(x), torch.empty_like(x)
+        vms.conv_fwd_dual(x, cw, cb, ro, cwb, cbb, rob, True)
+        rx, rxb = torch.empty_like(out), torch.empty_like(out)
+        vms.proj_kred(w, ro, rx, wb, rob, rxb)
+        o, ob, xd, xdb = torch.empty_like(x), torch.empty_like(x), torch.empty_like(out), torch.empty_like(out)
+        vms.conv_xproj_dual(x, cw, cb, o, cwb, cbb, ob, w, wb, xd, xdb, tile=rnd.choice([0, 64, 128]))
+        assert torch.equal(o, ro) and torch.equal(ob, rob) and torch.equal(xd, rx) and torch.equal(xdb, rxb), (b, d, L, m, width)
+
+
 def test_proj_kred_checks():
     vms = _vms()
     w = torch.randn(48, 128, device=DEV).bfloat16()
