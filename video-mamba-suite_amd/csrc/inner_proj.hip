@@ -77,7 +77,23 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
 
     // W fragments: A[i = c32][k = 16 s + 8 h + e] = W[d0 + c32][k], zero beyond the matrix
     s16x8 wf[KS];
-    {
+    // (dword-aligned rows: the range check of a buffer load works on dwords -- a row ending inside one would lose its last element)
+    if (p.w_k_stride == 1 && R % 2 == 0 && p.w_row_stride % 2 == 0 && (reinterpret_cast<uintptr_t>(p.w) & 3) == 0 &&
+        (int64_t)p.rows * p.w_row_stride * 2 < ((int64_t)1 << 31)) {
+        // k contiguous (dt_proj.weight): a fragment row piece is ONE 16-byte buffer load (any 2-byte alignment), all KS of them in
+        // flight together -- gathered element by element the 8 KS loads of a lane came out as KS x 4 dependent round trips at
+        // the start of every workgroup (a quarter of its life at 5 tiles per workgroup)
+        const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(p.w), 0, (int)(((int64_t)(p.rows - 1) * p.w_row_stride + R) * 2), 0x00020000);
+        const int d = d0 + c32;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 16 * s + 8 * h;
+            const s16x8 v = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(w_rs, d < p.rows && k < R ? (int)(((int64_t)d * p.w_row_stride + k) * 2) : -1, 0, 0));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) wf[s][e] = k + e < R ? v[e] : (short)0;     // (what follows the row's end is the next row)
+        }
+    } else {
         const int d = d0 + c32;
         const T* wrow = static_cast<const T*>(p.w) + (int64_t)(d < p.rows ? d : 0) * p.w_row_stride;
 #pragma unroll
