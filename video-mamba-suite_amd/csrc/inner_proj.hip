@@ -46,6 +46,7 @@ template <> struct Mfma32<f16_t> {
     }
 };
 
+constexpr int kPBufFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format (as causal_conv1d.hip)
 constexpr int kPT = 256;           // threads per workgroup (4 waves)
 constexpr int kTL = 64;            // positions per tile
 constexpr int kRowE = kTL + 8;     // LDS row pitch of a 16-bit tile, elements (144 B: 16 consecutive rows = 16 distinct 16-byte slots)
@@ -198,7 +199,7 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
 // proj_wgrad
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int MB>
-__global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p, const int tiles_per_wg) {
+__global__ __launch_bounds__(kPT, (MB <= 2 ? 4 : 2)) void proj_wgrad_kernel(const vms_proj_wgrad_params p, const int tiles_per_wg) {
     constexpr int MR = MB * 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) short lds_s16;
@@ -216,31 +217,34 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
     const int t_hi = t_lo + tiles_per_wg < n_tiles ? t_lo + tiles_per_wg : n_tiles;
     if (t_lo >= t_hi) return;
 
-    s16x8 stp[MB], stq[4];
-    auto stage_load = [&](int t) __attribute__((always_inline)) {
+    // Every load of the loop goes through a buffer resource (out-of-range offset = zeros, no memory access) instead of a select:
+    // the compiler counts the requests, so the tiles of TWO steps ahead stay in flight across the barriers (the grid is 1-2 waves per
+    // SIMD on the d = 768 shapes: with one tile of requests per wave the kernel ran at 2.3 TB/s)
+    const __amdgpu_buffer_rsrc_t p_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(P_b), 0, (int)(((int64_t)(p.m - 1) * p.p_row_stride + L) * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(Q_b), 0, (int)(((int64_t)(p.n - 1) * p.q_row_stride + L) * 2), kPBufFlags);
+    struct Stage { s16x8 p[MB], q[4]; };
+    auto stage_load = [&](Stage& st, int t) __attribute__((always_inline)) {
         const int lp = t * kTL + 8 * (tid & 7), lq = t * kTL + 8 * (lane & 7);
 #pragma unroll
         for (int ps = 0; ps < MB; ++ps) {
             const int r = (tid >> 3) + 32 * ps;
             const bool ok = r < p.m && lp < L && t < t_hi;
-            const s16x8 v = *reinterpret_cast<const s16x8*>(P_b + (int64_t)(ok ? r : 0) * p.p_row_stride + (ok ? lp : 0));
-            stp[ps] = ok ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            st.p[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(p_rs, ok ? (int)(((int64_t)r * p.p_row_stride + lp) * 2) : -1, 0, 0));
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int n = n0 + (lane >> 3) + 8 * ps;
             const bool ok = n < p.n && lq < L && t < t_hi;
-            const s16x8 v = *reinterpret_cast<const s16x8*>(Q_b + (int64_t)(ok ? n : 0) * p.q_row_stride + (ok ? lq : 0));
-            stq[ps] = ok ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            st.q[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(q_rs, ok ? (int)(((int64_t)n * p.q_row_stride + lq) * 2) : -1, 0, 0));
         }
     };
-    auto stage_store = [&]() __attribute__((always_inline)) {
+    auto stage_store = [&](const Stage& st) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < MB; ++ps)
-            *reinterpret_cast<lds_s16x8*>(p_lds + ((tid >> 3) + 32 * ps) * kRowE + 8 * (tid & 7)) = stp[ps];
+            *reinterpret_cast<lds_s16x8*>(p_lds + ((tid >> 3) + 32 * ps) * kRowE + 8 * (tid & 7)) = st.p[ps];
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
-            *reinterpret_cast<lds_s16x8*>(q_lds + ((lane >> 3) + 8 * ps) * kRowE + 8 * (lane & 7)) = stq[ps];
+            *reinterpret_cast<lds_s16x8*>(q_lds + ((lane >> 3) + 8 * ps) * kRowE + 8 * (lane & 7)) = st.q[ps];
     };
     f32x16 acc[MB];
 #pragma unroll
@@ -250,11 +254,7 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
 
     const lds_s16* const pa = p_lds + c32 * kRowE + 8 * h;
     const lds_s16* const qa = q_lds + c32 * kRowE + 8 * h;
-    stage_load(t_lo);
-    for (int t = t_lo; t < t_hi; ++t) {
-        stage_store();
-        __syncthreads();          // tile t is in LDS
-        stage_load(t + 1);        // travels during the matrix work
+    auto product = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < kTL / 16; ++s) {
             const s16x8 bq = *reinterpret_cast<const lds_s16x8*>(qa + 16 * s);
@@ -264,7 +264,25 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
                 acc[mb] = Mfma32<T>::run(ap, bq, acc[mb]);
             }
         }
+    };
+    Stage sa, sb;
+    stage_load(sa, t_lo);
+    stage_load(sb, t_lo + 1);
+    for (int t = t_lo; t < t_hi; t += 2) {
+        stage_store(sa);
+        __syncthreads();          // tile t is in LDS
+        stage_load(sa, t + 2);
+        product();
         __syncthreads();          // every wave has read tile t
+        if (t + 1 < t_hi) {       // (workgroup-uniform; no load under it)
+            stage_store(sb);
+            __syncthreads();
+        }
+        stage_load(sb, t + 3);
+        if (t + 1 < t_hi) {
+            product();
+            __syncthreads();
+        }
     }
     if (!p.dw_transposed) {
         const int n = n0 + c32;
@@ -323,7 +341,6 @@ __global__ VMS_PROJ_BOUNDS void proj_wgrad_kernel(const vms_proj_wgrad_params p,
 // conv backward: 34), HBM traffic 1.20x the algorithmic bytes: bound by vector issue, 114-119 us at (8, 1024, 8192) where its
 // three passes would take 75 at the chip's streaming rate.  A 3-waves-per-SIMD build spills and is slower.
 typedef unsigned int pu32x4 __attribute__((ext_vector_type(4)));
-constexpr int kPBufFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format (as causal_conv1d.hip)
 constexpr int kCD = 64;             // channels per workgroup of proj_conv_bwd (16 per wave)
 constexpr int kWRowE = kCD + 8;     // LDS row pitch of the W_x tile (k rows x 64 channels), elements
 constexpr int kEpT = kTL + 4;       // LDS row pitch of the fp32 tile of the first product (16 channels x 64 positions), floats
@@ -1312,6 +1329,9 @@ extern "C" int vms_proj_wgrad(const vms_proj_wgrad_params* pp, void* stream) {
     VMS_CHECK(p.seqlen % 8 == 0 && p.p_batch_stride % 8 == 0 && p.p_row_stride % 8 == 0 && p.q_batch_stride % 8 == 0 &&
                   p.q_row_stride % 8 == 0 && aligned16(p.p) && aligned16(p.q),
               "proj_wgrad: seqlen, strides (elements) must be multiples of 8 and p / q 16-byte aligned");
+    VMS_CHECK(p.p_row_stride >= 0 && p.q_row_stride >= 0 && ((int64_t)(p.m - 1) * p.p_row_stride + p.seqlen) * 2 < ((int64_t)1 << 31) &&
+                  ((int64_t)(p.n - 1) * p.q_row_stride + p.seqlen) * 2 < ((int64_t)1 << 31),
+              "proj_wgrad: a batch entry of p and q must each span < 2 GiB (one buffer resource each)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == VMS_BF16 ? dispatch_wgrad<bf16_t>(p, s) : dispatch_wgrad<f16_t>(p, s);
 }

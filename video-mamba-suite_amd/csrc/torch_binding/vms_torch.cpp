@@ -568,8 +568,9 @@ void proj_apply(const Tensor& w, const Tensor& in, const Tensor& out, bool accum
     call("vms_proj_apply", vms_proj_apply, P, in);
 }
 bool proj_wgrad_eligible(const Tensor& p, const Tensor& q) {
+    const auto fits = [](const Tensor& t) { return ((t.size(1) - 1) * t.stride(1) + t.size(2)) * 2 < ((int64_t)1 << 31); };   // one buffer resource per batch entry
     return proj_ok16(p) && proj_ok16(q) && p.scalar_type() == q.scalar_type() && p.size(0) == q.size(0) && p.size(2) == q.size(2) &&
-           p.size(1) <= 128;
+           p.size(1) <= 128 && fits(p) && fits(q);
 }
 // dw[m, n] += sum_{b, l} p[b, m, l] q[b, n, l];  dw: fp32 (m, n), unit column stride, zero-filled by the caller
 // transposed: dw is the (n, m) matrix (a parameter stored that way receives a gradient in its own layout)
