@@ -111,23 +111,29 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
     const int t_hi = t_lo + tiles_per_wg < n_tiles ? t_lo + tiles_per_wg : n_tiles;
     if (t_lo >= t_hi) return;
 
-    // staging of the `in` tile: thread -> row (tid >> 3) + 32 pass, piece tid & 7
-    s16x8 stg[NPASS];
-    auto stage_load = [&](int t) __attribute__((always_inline)) {
+    // staging of the `in` tile: thread -> row (tid >> 3) + 32 pass, piece tid & 7.  Every access of the loop goes through a buffer
+    // resource per tensor and batch entry (out-of-range offset: loads return zeros, stores are dropped) instead of a select or a
+    // branch: the compiler then counts what is in flight -- with plain loads carried over the loop's back edge it drained everything,
+    // the tile's STORES included, at every iteration (vmcnt(0): 66 % of the wave cycles waiting) -- and the `in` tiles of two steps
+    // ahead travel while a tile computes.
+    const __amdgpu_buffer_rsrc_t in_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(in_b), 0, (int)(((int64_t)(R - 1) * p.in_k_stride + L) * 2), kPBufFlags);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(out_b, 0, (int)(((int64_t)(p.rows - 1) * p.out_row_stride + L) * 2), kPBufFlags);
+    typedef unsigned int au32x4 __attribute__((ext_vector_type(4)));
+    struct Stage { s16x8 v[NPASS]; };
+    auto stage_load = [&](Stage& st, int t) __attribute__((always_inline)) {
         const int l = t * kTL + 8 * (tid & 7);
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = (tid >> 3) + 32 * ps;
             const bool ok = r < R && l < L && t < t_hi;
-            const s16x8 v = *reinterpret_cast<const s16x8*>(in_b + (int64_t)(ok ? r : 0) * p.in_k_stride + (ok ? l : 0));
-            stg[ps] = ok ? v : s16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            st.v[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(in_rs, ok ? (int)(((int64_t)r * p.in_k_stride + l) * 2) : -1, 0, 0));
         }
     };
-    auto stage_store = [&]() __attribute__((always_inline)) {
+    auto stage_store = [&](const Stage& st) __attribute__((always_inline)) {
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int r = (tid >> 3) + 32 * ps;
-            if (NPASS * 32 == KR || r < KR) *reinterpret_cast<lds_s16x8*>(in_lds + r * kRowE + 8 * (tid & 7)) = stg[ps];
+            if (NPASS * 32 == KR || r < KR) *reinterpret_cast<lds_s16x8*>(in_lds + r * kRowE + 8 * (tid & 7)) = st.v[ps];
         }
     };
     // transposing read: lane i of a 16-lane group supplies the address of row i / 4, columns 4 (i % 4) .. + 3 of a [4][16] block
@@ -137,12 +143,11 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
     // epilogue pieces of a 32 x 32 half tile: lane -> row (lane >> 2) + 16 pp, columns 8 (lane & 3) .. + 7
     const int er = lane >> 2, ec = 8 * (lane & 3);
 
-    stage_load(t_lo);
-    for (int t = t_lo; t < t_hi; ++t) {
+    auto step = [&](Stage& st, int t) __attribute__((always_inline)) {
         const int l0 = t * kTL;
-        stage_store();
+        stage_store(st);
         __syncthreads();          // tile t is in LDS
-        stage_load(t + 1);        // travels during the rest of the iteration
+        stage_load(st, t + 2);    // travels during this tile and the next
         vec_t<T, 8> prev[2][2];
         if (ACC) {
 #pragma unroll
@@ -150,8 +155,8 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
 #pragma unroll
                 for (int pp = 0; pp < 2; ++pp) {
                     const int d = d0 + er + 16 * pp, l = l0 + 32 * j + ec;
-                    const bool ok = d < p.rows && l < L;
-                    prev[j][pp] = *reinterpret_cast<const vec_t<T, 8>*>(out_b + (int64_t)(ok ? d : 0) * p.out_row_stride + (ok ? l : 0));
+                    prev[j][pp] = __builtin_bit_cast(vec_t<T, 8>, __builtin_amdgcn_raw_buffer_load_b128(
+                        out_rs, d < p.rows && l < L ? (int)(((int64_t)d * p.out_row_stride + l) * 2) : -1, 0, 0));
                 }
         }
         f32x16 acc[2];
@@ -189,9 +194,17 @@ __global__ VMS_PROJ_BOUNDS void proj_apply_kernel(const vms_proj_apply_params p,
                     if (ACC) f[e] += static_cast<float>(prev[j][pp][e]);
                     o[e] = static_cast<T>(f[e]);
                 }
-                if (d < p.rows && l < L) *reinterpret_cast<vec_t<T, 8>*>(out_b + (int64_t)d * p.out_row_stride + l) = o;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(au32x4, o), out_rs,
+                                                       d < p.rows && l < L ? (int)(((int64_t)d * p.out_row_stride + l) * 2) : -1, 0, 0);
             }
         }
+    };
+    Stage sa, sb;
+    stage_load(sa, t_lo);
+    stage_load(sb, t_lo + 1);
+    for (int t = t_lo; t < t_hi; t += 2) {
+        step(sa, t);
+        if (t + 1 < t_hi) step(sb, t + 1);     // (workgroup-uniform)
     }
 }
 
@@ -1315,6 +1328,9 @@ extern "C" int vms_proj_apply(const vms_proj_apply_params* pp, void* stream) {
     VMS_CHECK(p.seqlen % 8 == 0 && p.in_batch_stride % 8 == 0 && p.in_k_stride % 8 == 0 && p.out_batch_stride % 8 == 0 &&
                   p.out_row_stride % 8 == 0 && aligned16(p.in) && aligned16(p.out),
               "proj_apply: seqlen, strides (elements) must be multiples of 8 and in / out 16-byte aligned");
+    VMS_CHECK(p.in_k_stride >= 0 && p.out_row_stride >= 0 && ((int64_t)(p.k - 1) * p.in_k_stride + p.seqlen) * 2 < ((int64_t)1 << 31) &&
+                  ((int64_t)(p.rows - 1) * p.out_row_stride + p.seqlen) * 2 < ((int64_t)1 << 31),
+              "proj_apply: a batch entry of in and out must each span < 2 GiB (one buffer resource each)");
     hipStream_t s = static_cast<hipStream_t>(stream);
     return p.dtype == VMS_BF16 ? dispatch_apply<bf16_t>(p, s) : dispatch_apply<f16_t>(p, s);
 }

@@ -552,9 +552,10 @@ bool proj_ok16(const Tensor& t) {
            t.size(2) % 8 == 0 && t.stride(0) % 8 == 0 && t.stride(1) % 8 == 0 && (reinterpret_cast<uintptr_t>(t.data_ptr()) & 15) == 0;
 }
 bool proj_apply_eligible(const Tensor& w, const Tensor& in, const Tensor& out) {
+    const auto fits = [](const Tensor& t) { return ((t.size(1) - 1) * t.stride(1) + t.size(2)) * 2 < ((int64_t)1 << 31); };   // one buffer resource per batch entry
     return proj_ok16(in) && proj_ok16(out) && w.is_cuda() && w.dim() == 2 && w.scalar_type() == in.scalar_type() &&
            out.scalar_type() == in.scalar_type() && w.size(1) == in.size(1) && w.size(1) <= 96 && out.size(1) == w.size(0) &&
-           out.size(0) == in.size(0) && out.size(2) == in.size(2);
+           out.size(0) == in.size(0) && out.size(2) == in.size(2) && fits(in) && fits(out);
 }
 // out[b, d, l] (+)= sum_r w[d, r] in[b, r, l]
 void proj_apply(const Tensor& w, const Tensor& in, const Tensor& out, bool accumulate) {
