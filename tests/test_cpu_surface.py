@@ -7,6 +7,7 @@ import ctypes
 import importlib
 import os
 import re
+import sys
 import types
 
 import numpy as np
@@ -433,3 +434,31 @@ def test_in_proj_weight_gradient_is_ready_before_the_input_gradient():
     # an input that needs no gradient: one node, as before
     x2 = torch.randn(2, 12, 8)
     in_proj_fn(x2, w, b).sum().backward()
+
+
+def test_isa_hazard_scanner_finds_trans_then_asm_fma(tmp_path):
+    """tools/isa_hazards.py: a v_pk_fma_f32 directly behind the v_exp_f32 that writes one of its sources is reported, one with an
+    instruction in between (or reading other registers) is not"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("isa_hazards", os.path.join(ROOT, "tools", "isa_hazards.py"))
+    hz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hz)
+    bad = tmp_path / "bad.s"
+    bad.write_text("\tv_exp_f32_e32 v18, v18\n\tv_exp_f32_e32 v19, v19\n\tv_pk_fma_f32 v[18:19], v[18:19], v[4:5], v[62:63]\n")
+    ok = tmp_path / "ok.s"
+    ok.write_text("\tv_exp_f32_e32 v19, v19\n\ts_nop 0\n\tv_pk_fma_f32 v[18:19], v[18:19], v[4:5], v[62:63]\n"
+                  "\tv_rcp_f32_e32 v7, v7\n\tv_pk_fma_f32 v[18:19], v[18:19], v[4:5], v[62:63]\n"
+                  "\tv_exp_f32_e32 v18, v18\n\tv_pk_fma_f32 v[18:19], v[20:21], v[4:5], v[62:63]\n")
+    assert len(hz.scan(str(bad))) == 1
+    assert hz.scan(str(ok)) == []
+
+
+def test_no_trans_forwarding_hazard_in_the_pair_kernels():
+    """the gfx950 ISA of the two sources with inline-asm VALU statements holds no transcendental -> asm-fma pair without a wait
+    state (the compiler does not guard asm statements; tools/isa_hazards.py)"""
+    import shutil
+    import subprocess
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -157,6 +157,15 @@ __device__ __forceinline__ f2 pk_fma_b(f2 a, f2 b, f2 c) {
     return r;
 }
 
+// the same where an operand comes straight from v_exp_f32: gfx950 wants one wait state between a transcendental's write and a
+// non-transcendental VALU read of it, and the hazard recognizer does not look inside an asm statement (without the s_nop the
+// carry pass read stale exponentials wherever the scheduler put the fma directly behind the exp)
+__device__ __forceinline__ f2 pk_fma_after_trans_b(f2 a, f2 b, f2 c) {
+    f2 r;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // workgroup barrier that orders LDS traffic only (no vmcnt drain)
 __device__ __forceinline__ void lds_barrier_b() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1123,88 +1132,102 @@ __device__ __forceinline__ void scan_bwd_carry_body(const vms_scan_bwd_params& q
     const int cs = (cps + sub_m - 1) / sub_m;                                         // chunks per sub-range
     const int c_lo = r_lo + sub_k * cs < r_hi ? r_lo + sub_k * cs : r_hi;
     const int c_hi = c_lo + cs < r_hi ? c_lo + cs : r_hi;                            // empty (c_lo == c_hi): the identity map
-    float gcar = 0.f, pacc = 1.f, anx = 1.f;   // lane j <-> state j
-    if (c_hi < n_c) {
-        const int lr = c_hi * CH;
-        float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
-        if (p.delta_softplus) t = softplusf_(t);
-        anx = fast_exp2(t * A_mine);
-    }
+    // The adjoint recurrence g_i = a_{i+1} g_{i+1} + c_i (a_k = exp2(A' delta_k), c_i = C_i dy_i) over the sub-range [lo, hi) is the affine
+    // map  g_lo = P g_hi + q  with  P = exp2(A' sum_{k = lo+1 .. hi} delta_k)  and  q = sum_i exp2(A' T_i) c_i,  T_i = sum_{k = lo+1 .. i}
+    // delta_k: only the AGGREGATE is wanted here, so nothing has to run sequentially -- T is a prefix sum of delta (one scan per chunk,
+    // shared by the 16 states) and q a dot product: per (element, state) half a packed multiply for A' T, one exp2, half a packed
+    // multiply for C dy and half a packed fma into the state's accumulator.  (Until round 4 this pass ran the recurrence itself --
+    // the a_i chain, its 8 fma per state and a 4-step row scan per state and chunk: 68 instead of 28 vector instructions per state,
+    // 260 us of the 920 us a long-video backward scan took.)  Exponents are <= 0 (A < 0, T >= 0): far terms underflow to 0.
+    float gcar = 0.f, pacc = 1.f;              // lane j <-> state j
     const bool is_last = j == 15;
-    RawB<T, REV> rcA, rcB, rdt, rdo, rz;
-    for (int c = c_hi - 1; c >= c_lo; --c) {
-        const int l0 = c * CH + j * K;
-        const bool ok = l0 < L && row_ok;              // seqlen % K == 0 (host): all or nothing
-        const uint32_t pl0 = REV ? L - l0 - K : l0;
-        const uint32_t pl0n = REV ? L - (l0 - CH) - K : l0 - CH;   // the same lane in the next chunk (c - 1)
-        if (c == c_hi - 1) {
-            rcA.load(Cv, pl0, l0 < L);
-            rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
-            rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
-            if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
-        }
-        f2 dl2[K / 2], dy2[K / 2];
-        float sdl = 0.f, dl_first = 0.f;
+    (void)is_last;
+    if (c_lo < c_hi) {
+        RawB<T, REV> rcA, rcB, rdt, rdo, rz;
+        f2 qacc[N];
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            float t = rdt.at(i) + bias;
-            if (p.delta_softplus) t = softplusf_(t);
-            t = ok ? t : 0.f;
-            float dyv = ok ? rdo.at(i) : 0.f;
-            if (HZ) {
-                const float zv = rz.at(i);
-                dyv *= zv * sigmoidf_(zv);
+        for (int n = 0; n < N; ++n) qacc[n] = f2{0.f, 0.f};
+        float off = 0.f, dl_lo = 0.f;            // sum of delta over the chunks already walked; delta of the sub-range's first element
+        for (int c = c_lo; c < c_hi; ++c) {
+            const int l0 = c * CH + j * K;
+            const bool ok = l0 < L && row_ok;              // seqlen % K == 0 (host): all or nothing
+            const uint32_t pl0 = REV ? L - l0 - K : l0;
+            const uint32_t pl0n = REV ? L - (l0 + CH) - K : l0 + CH;   // the same lane in the next chunk (c + 1)
+            const bool okn = c + 1 < c_hi && l0 + CH < L && row_ok;
+            if (c == c_lo) {
+                rcA.load(Cv, pl0, l0 < L);
+                rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0, ok);
+                rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0, ok);
+                if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0, ok);
             }
-            dl2[i / 2][i % 2] = t;
-            dy2[i / 2][i % 2] = dyv;
-            sdl += t;
-            if (i == 0) dl_first = t;
-        }
-        {   // the next chunk's row data travels while this chunk's 16 states compute
-            const bool okn = c > c_lo && row_ok;
-            rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0n, okn);
-            rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0n, okn);
-            if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0n, okn);
-        }
-#define VMS_EL(arr, i) arr[(i) / 2][(i) % 2]
+            f2 T2[K / 2], dy2[K / 2];
+            {
+                float run = 0.f, pf[K];
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    float t = rdt.at(i) + bias;
+                    if (p.delta_softplus) t = softplusf_(t);
+                    t = ok ? t : 0.f;
+                    float dyv = ok ? rdo.at(i) : 0.f;
+                    if (HZ) {
+                        const float zv = rz.at(i);
+                        dyv *= zv * sigmoidf_(zv);
+                    }
+                    run += t;
+                    pf[i] = run;                               // inclusive prefix inside the lane
+                    dy2[i / 2][i % 2] = dyv;
+                    if (i == 0 && c == c_lo) dl_lo = row_newbcast<0>(t);     // (uniform branch; lane 0's first element)
+                }
+                // exclusive scan of the lane totals over the row's 16 lanes
+                float inc = run;
+                inc += bdpp<DPP_ROW_SHR1>(0.f, inc);
+                inc += bdpp<DPP_ROW_SHR2>(0.f, inc);
+                inc += bdpp<DPP_ROW_SHR4>(0.f, inc);
+                inc += bdpp<DPP_ROW_SHR8>(0.f, inc);
+                const float base = off + (inc - run) - dl_lo;  // T of the element before this lane's first
+                off += row_newbcast<15>(inc);
+#pragma unroll
+                for (int i = 0; i < K; ++i) T2[i / 2][i % 2] = base + pf[i];
+            }
+            {   // the next chunk's row data travels while this chunk's 16 states compute
+                rdt.load(dt_b, VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + pl0n, okn);
+                rdo.load(dout_b, VMS_OFF(q.dout_batch_stride, q.dout_d_stride) + pl0n, okn);
+                if (HZ) rz.load(z_b, VMS_OFF(p.z_batch_stride, p.z_d_stride) + pl0n, okn);
+            }
 #define VMS_CARRY_STATE(n, rc, rn)                                                                                  \
-        {                                                                                                           \
-            /* C of the next state -- after the last one: state 0 of the next chunk (to the left) -- while this one computes */ \
-            rn.load(Cv + (int64_t)(((n) + 1) & (N - 1)) * p.C_dstate_stride, (n) == N - 1 ? pl0n : pl0,             \
-                    (n) == N - 1 ? c > c_lo : l0 < L);                                                              \
-            const float An = row_newbcast<n>(A_mine), anx_n = row_newbcast<n>(anx), gin = row_newbcast<n>(gcar);    \
-            const f2 An2 = f2{An, An};                                                                              \
-            f2 a2[K / 2], c2[K / 2];                                                                                \
-            _Pragma("unroll") for (int k = 0; k < K / 2; ++k) {                                                     \
-                const f2 t = dl2[k] * An2;                                                                          \
-                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};                                                         \
-                c2[k] = f2{rc.at(2 * k), rc.at(2 * k + 1)} * dy2[k];                                                \
-            }                                                                                                       \
-            const float a_right = bdpp<DPP_ROW_SHL1>(anx_n, a2[0].x);                                               \
-            float rg = 0.f;                                                                                         \
-            _Pragma("unroll") for (int i = K - 1; i >= 0; --i)                                                      \
-                rg = fmaf(i == K - 1 ? a_right : VMS_EL(a2, i + 1), rg, VMS_EL(c2, i));                             \
-            float ra = fast_exp2((sdl - dl_first) * An) * a_right;                                                  \
-            rg = fmaf(ra, is_last ? gin : 0.f, rg);                                                                 \
-            asm volatile("s_nop 1\n\t"                                                                              \
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"                       \
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"                       \
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"                       \
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
-                         "v_fmac_f32_dpp %0, %0, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"                       \
-                         "s_nop 0\n\tv_mul_f32_dpp %1, %1, %1 row_shl:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1"      \
-                         : "+v"(rg), "+v"(ra));                                                                     \
-            const float g0 = row_newbcast<0>(rg), p0 = row_newbcast<0>(ra), a0 = row_newbcast<0>(a2[0].x);          \
-            if (j == (n)) { gcar = g0; pacc *= p0; anx = a0; }                                                      \
-        }
-        VMS_CARRY_STATE(0, rcA, rcB) VMS_CARRY_STATE(1, rcB, rcA) VMS_CARRY_STATE(2, rcA, rcB) VMS_CARRY_STATE(3, rcB, rcA)
-        VMS_CARRY_STATE(4, rcA, rcB) VMS_CARRY_STATE(5, rcB, rcA) VMS_CARRY_STATE(6, rcA, rcB) VMS_CARRY_STATE(7, rcB, rcA)
-        VMS_CARRY_STATE(8, rcA, rcB) VMS_CARRY_STATE(9, rcB, rcA) VMS_CARRY_STATE(10, rcA, rcB) VMS_CARRY_STATE(11, rcB, rcA)
-        VMS_CARRY_STATE(12, rcA, rcB) VMS_CARRY_STATE(13, rcB, rcA) VMS_CARRY_STATE(14, rcA, rcB) VMS_CARRY_STATE(15, rcB, rcA)
+            {                                                                                                       \
+                /* C of the next state -- after the last one: state 0 of the next chunk -- while this one computes */  \
+                rn.load(Cv + (int64_t)(((n) + 1) & (N - 1)) * p.C_dstate_stride, (n) == N - 1 ? pl0n : pl0,         \
+                        (n) == N - 1 ? (c + 1 < c_hi && l0 + CH < L) : l0 < L);                                      \
+                const float An = row_newbcast<n>(A_mine);                                                           \
+                const f2 An2 = f2{An, An};                                                                          \
+                _Pragma("unroll") for (int k = 0; k < K / 2; ++k) {                                                 \
+                    const f2 t = T2[k] * An2;                                                                       \
+                    const f2 e2 = f2{fast_exp2(t.x), fast_exp2(t.y)};                                               \
+                    const f2 c2 = f2{rc.at(2 * k), rc.at(2 * k + 1)} * dy2[k];                                      \
+                    qacc[n] = pk_fma_after_trans_b(e2, c2, qacc[n]);                                                         \
+                }                                                                                                   \
+            }
+            VMS_CARRY_STATE(0, rcA, rcB) VMS_CARRY_STATE(1, rcB, rcA) VMS_CARRY_STATE(2, rcA, rcB) VMS_CARRY_STATE(3, rcB, rcA)
+            VMS_CARRY_STATE(4, rcA, rcB) VMS_CARRY_STATE(5, rcB, rcA) VMS_CARRY_STATE(6, rcA, rcB) VMS_CARRY_STATE(7, rcB, rcA)
+            VMS_CARRY_STATE(8, rcA, rcB) VMS_CARRY_STATE(9, rcB, rcA) VMS_CARRY_STATE(10, rcA, rcB) VMS_CARRY_STATE(11, rcB, rcA)
+            VMS_CARRY_STATE(12, rcA, rcB) VMS_CARRY_STATE(13, rcB, rcA) VMS_CARRY_STATE(14, rcA, rcB) VMS_CARRY_STATE(15, rcB, rcA)
 #undef VMS_CARRY_STATE
-#undef VMS_EL
+        }
+        // delta of the first element to the right of the sub-range (a_hi multiplies the entering adjoint); 0 at the sequence's end
+        float dl_hi = 0.f;
+        if (c_hi < n_c) {
+            const int lr = c_hi * CH;
+            float t = static_cast<float>(dt_b[VMS_OFF(p.delta_batch_stride, p.delta_d_stride) + (REV ? L - 1 - lr : lr)]) + bias;
+            if (p.delta_softplus) t = softplusf_(t);
+            dl_hi = t;
+        }
+        pacc = fast_exp2(A_mine * (off - dl_lo + dl_hi));
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float tot = row_allsum_b(qacc[n].x + qacc[n].y);
+            if (j == n) gcar = tot;
+        }
     }
     if (row_ok) seg_carry[(((int64_t)b * p.dim + d) * (n_seg * sub_m) + sub) * N + j] = float2{pacc, gcar};
 #undef VMS_OFF
