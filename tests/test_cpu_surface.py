@@ -462,3 +462,15 @@ def test_no_trans_forwarding_hazard_in_the_pair_kernels():
         pytest.skip("hipcc not on PATH")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazards.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_padded_len_rule():
+    """modules/_core.py _padded_len: multiples of 16, extended to whole 256-token GEMM tiles when <= 2 % more positions buy it"""
+    from mamba_ssm.modules import _core
+    for batch, seqlen, want in ((8, 3137, 3168), (8, 1569, 1600), (16, 1569, 1584), (2, 1569, 1584), (1, 3137, 3152), (2, 197, 208),
+                                (64, 197, 208), (8, 35, 48), (32, 785, 800), (8, 3136, 3136), (3, 1, 16)):
+        got = _core._padded_len(batch, seqlen, 16)
+        assert got == want, (batch, seqlen, got, want)
+        assert got % 16 == 0 and got >= seqlen and got - seqlen <= 15 + seqlen // 50
+    m = _core.MambaCore(32, bimamba_type="v2")
+    assert m._seq_padding(torch.zeros(2, 197, 32)) == 0      # CPU tensors are never padded

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <atomic>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -686,8 +687,9 @@ void proj_conv_bwd(const Tensor& x, const Tensor& du, const Tensor& dx_dbl, cons
 std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
                               const Tensor& A, const OptT& D_, const OptT& delta_bias_, bool delta_softplus, bool reverse,
                               const OptT& out_z_into, int64_t impl, int64_t segments, int64_t reverse_from, int64_t proj_flags,
-                              const OptT& conv_out_given, const OptT& x_dbl_given) {
+                              const OptT& conv_out_given, const OptT& x_dbl_given, int64_t seq_valid) {
     TORCH_CHECK(xz.is_cuda() && xz.dim() == 3 && xz.stride(2) == 1, "xz must be a (batch, 2 * dim, seqlen) GPU tensor with unit seqlen stride");
+    TORCH_CHECK(seq_valid >= 0 && seq_valid <= xz.size(2) && (seq_valid == 0 || delta_softplus), "inner_fwd: 0 <= seq_valid <= seqlen, and only with delta_softplus");
     c10::DeviceGuard guard(xz.device());
     const int64_t d = conv_w.size(0), R = dt_proj_w.size(1), N = A.size(1);
     TORCH_CHECK(xz.size(1) == 2 * d && x_proj_w.size(0) == R + 2 * N && x_proj_w.size(1) == d && dt_proj_w.size(0) == d,
@@ -710,6 +712,10 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
         delta = at::empty({x_dbl.size(0), d, x_dbl.size(2)}, x_dbl.options());
         if ((proj_flags & 1) && proj_apply_eligible(dt_proj_w, dt_in, delta)) proj_apply(dt_proj_w, dt_in, delta, false);
         else at::matmul_out(delta, dt_proj_w, dt_in);
+        // seq_valid: the positions behind it are the mixer's zero padding to whole vectors (modules/_core.py): softplus(-inf) = 0 makes
+        // them identity steps of the recurrence (a = 1, b = 0) in either direction, and every gradient through them exactly 0
+        if (seq_valid > 0 && seq_valid < delta.size(2))
+            delta.narrow(2, seq_valid, delta.size(2) - seq_valid).fill_(-std::numeric_limits<float>::infinity());
     }
     const PaddedBC bc = pad_bc(x_dbl.narrow(1, R, N).unsqueeze(1), x_dbl.narrow(1, R + N, N).unsqueeze(1), reverse, reverse_from > 0);
     // proj_flags bit 4: nothing will run this node's backward (small checkpoint layout); bit 8: keep the 128-element checkpoints
@@ -928,7 +934,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("conv_xproj_dual", &conv_xproj_dual);
     m.def("inner_fwd", &inner_fwd, py::arg("xz"), py::arg("conv_w"), py::arg("conv_b"), py::arg("x_proj_w"), py::arg("dt_proj_w"), py::arg("A"),
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
-          py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none());
+          py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none(), py::arg("seq_valid") = 0);
     m.def("proj_kred", &proj_kred, py::arg("w"), py::arg("inp"), py::arg("out"), py::arg("w2") = py::none(), py::arg("inp2") = py::none(),
           py::arg("out2") = py::none(), py::arg("tile") = 0, py::arg("cast_src") = py::none());
     m.def("x_proj_dual", &x_proj_dual);

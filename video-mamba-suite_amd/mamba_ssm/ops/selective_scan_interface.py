@@ -37,7 +37,11 @@ except ImportError:  # pragma: no cover
 
 
 def _last_dim_contiguous(t):
-    return t if t is None or t.stride(-1) == 1 else t.contiguous()
+    if t is None or t.stride(-1) == 1:
+        return t
+    if t.shape[-1] == 1:   # a size-1 axis may carry any stride (and .contiguous() keeps it): restate it as 1
+        return t.as_strided(t.shape, t.stride()[:-1] + (1,), t.storage_offset())
+    return t.contiguous()
 
 
 # =================================================================================================
@@ -274,10 +278,23 @@ def _bc_from_x_dblT(x_dblT, lo, hi, bias):
     return M.unsqueeze(1)                                # (b, 1, n, l), unit seqlen stride
 
 
+def _mask_padding(delta, seq_valid, delta_softplus=True):
+    """delta (pre-softplus) with -inf behind seq_valid: softplus gives exactly 0 there, so a = exp(0 A) = 1 and b = 0 u B = 0 (the
+    recurrence passes its state through unchanged, in either direction), and d softplus = 0 (no gradient reaches the padding's
+    delta; du, dB, dC, dA carry the factor delta = 0).  In place: delta is this node's own product."""
+    if seq_valid and seq_valid < delta.shape[-1]:
+        assert delta_softplus, "sequence padding needs delta_softplus (softplus(-inf) = 0)"
+        delta[..., seq_valid:].fill_(float("-inf"))
+    return delta
+
+
 def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                    out_proj, A, A_b, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                   checkpoint_lvl, reverse=False, out_z_into=None, reverse_from=0, conv_out=None, x_dbl=None):
+                   checkpoint_lvl, reverse=False, out_z_into=None, reverse_from=0, conv_out=None, x_dbl=None, seq_valid=0):
     """out_proj: None (no projection) or (weight, bias).  A_b: None or the reverse-direction A.
+    seq_valid > 0 (extension; the mixer's padding of ragged sequences to whole vectors, modules/_core.py): positions >= seq_valid
+    of xz are zero padding; the pre-softplus delta is set to -inf there, which makes them identity steps of both directions'
+    recurrences and every gradient through them exactly zero (_mask_padding).
     reverse: the whole node runs right-to-left (== flip o node o flip, without the copies).
     reverse_from > 0: the batch entries >= reverse_from run right-to-left, the others left-to-right (vms_hip.h ABI v5).
     conv_out: this direction's conv1d + SiLU output when the caller already has it (both directions of a block from one pass
@@ -313,8 +330,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         out_z, conv_out, x_dbl, delta, ckpt, out = ext.inner_fwd(
             xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, bool(delta_softplus), bool(reverse),
             out_z_into, _vms.scan_impl_from_env(), _vms.segments_from_env("VMS_FWD_SEGMENTS"), int(reverse_from), _mfma_proj(d_inner, R) | _x_flags(ctx, xz, d_state),
-            conv_out, x_dbl)
+            conv_out, x_dbl, int(seq_valid))
         ctx.reverse_from = int(reverse_from)
+        ctx.seq_valid = int(seq_valid)
         ctx.delta_softplus, ctx.checkpoint_lvl = delta_softplus, checkpoint_lvl
         ctx.has_D, ctx.has_delta_bias = D is not None, delta_bias is not None
         ctx.has_out_proj = ctx.has_out_proj_bias = ctx.bidirectional = False
@@ -325,6 +343,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
                               D, delta_bias, ckpt, out, None, None, None)
         return out_z
     ctx.reverse_from = int(reverse_from)
+    ctx.seq_valid = int(seq_valid)
     rf = {"reverse_from": int(reverse_from)} if reverse_from else {}
     if conv_out is None:
         conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :d_inner], conv_w, conv_b, True, reverse, **rf)
@@ -332,6 +351,7 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
     else:
         delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
+    delta = _mask_padding(delta, seq_valid, delta_softplus)
 
     if B is None:
         B = _bc_from_x_dblT(x_dbl, R, R + d_state, B_proj_bias)
@@ -389,7 +409,8 @@ def _inner_backward(ctx, dout, dxz_into=None):
     rf = {"reverse_from": ctx.reverse_from} if getattr(ctx, "reverse_from", 0) else {}
     if ctx.checkpoint_lvl == 1:
         conv_out = causal_conv1d_cuda.causal_conv1d_fwd(x, conv_w, conv_b, True, ctx.reverse, **rf)
-        delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
+        delta = _mask_padding(_last_dim_contiguous(torch.matmul(delta_proj_weight, x_dbl[:, :R])), getattr(ctx, "seq_valid", 0),
+                              ctx.delta_softplus)
     if getattr(ctx, "fast", False):
         dxz, dconv_w, dconv_b, dx_proj_weight, ddelta_proj_weight, dA, dD, ddelta_bias = _inner_ext_module().inner_bwd(
             dout, xz, conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out,
@@ -484,6 +505,7 @@ def _inner_backward_dual(first, second, dout):
     ext = _inner_ext_module()
     if ext is None or not hasattr(ext, "inner_bwd_dual") or first.reverse or not second.reverse:
         return None, None
+    dout = _last_dim_contiguous(dout)
     packs = []
     for sub in (first, second):
         (xz, conv_w, conv_b, x_dbl, x_proj_weight, delta_proj_weight, _, conv_out, delta, A, _, _, D, delta_bias, ckpt, out,
@@ -491,7 +513,8 @@ def _inner_backward_dual(first, second, dout):
         if sub.checkpoint_lvl == 1:
             R = delta_proj_weight.shape[1]
             conv_out = causal_conv1d_cuda.causal_conv1d_fwd(xz[:, :conv_w.shape[0]], conv_w, conv_b, True, sub.reverse)
-            delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
+            delta = _mask_padding(_last_dim_contiguous(torch.matmul(delta_proj_weight, x_dbl[:, :R])), getattr(sub, "seq_valid", 0),
+                                  sub.delta_softplus)
         packs.append([conv_w, conv_b, x_proj_weight, delta_proj_weight, A, D, delta_bias, conv_out, x_dbl, delta, ckpt, out])
     r = ext.inner_bwd_dual(dout, xz, packs[0], packs[1], bool(first.delta_softplus), _vms.scan_impl_from_env(),
                            _vms.segments_from_env("VMS_BWD_SEGMENTS"), first.w_dtype == torch.float32,
@@ -639,10 +662,10 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
 
     @staticmethod
     @custom_fwd
-    def forward(ctx, xz, delta_softplus, checkpoint_lvl, *params):
+    def forward(ctx, xz, delta_softplus, checkpoint_lvl, seq_valid, *params):
         """params: the 2 x 7 parameters, optionally followed by the four small projection weights (x_proj, dt_proj of both
         directions) already in the autocast dtype -- the block's one-launch parameter preparation -- which are used instead of
-        casting here and receive no gradient."""
+        casting here and receive no gradient.  seq_valid: 0, or the number of real positions of a zero-padded xz (_inner_forward)."""
         n = BiMambaInnerFnNoOutProj.N_PER_DIR
         assert len(params) in (2 * n, 2 * n + 4)
         low_given = params[2 * n:]
@@ -684,7 +707,8 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
             sub.for_backward = any(ctx.needs_input_grad)
             # the second direction's scan adds its gated output to the first's
             out = _inner_forward(sub, xz, cw, cb, xw, dw, None, A, None, None, None, D, dbias, None, None,
-                                 delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out, conv_out=conv_outs[i], x_dbl=x_dbls[i])
+                                 delta_softplus, checkpoint_lvl, reverse=(i == 1), out_z_into=out, conv_out=conv_outs[i], x_dbl=x_dbls[i],
+                                 seq_valid=seq_valid)
             subs.append(sub)
         ctx.counts = [len(sub.saved_tensors) for sub in subs]
         ctx.save_for_backward(*subs[0].saved_tensors, *subs[1].saved_tensors)
@@ -706,14 +730,15 @@ class BiMambaInnerFnNoOutProj(torch.autograd.Function):
         first.saved_tensors = second.saved_tensors = None
         per_dir = lambda g: (g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"], g["dA"], g["dD"],
                              g["ddelta_bias"])
-        return (g1["dxz"], None, None) + per_dir(g1) + per_dir(g2) + (None,) * ctx.n_extra
+        return (g1["dxz"], None, None, None) + per_dir(g1) + per_dir(g2) + (None,) * ctx.n_extra
 
 
-def bimamba_inner_fn_no_out_proj(xz, params, params_b, delta_softplus=True, checkpoint_lvl=1, prepared=None):
+def bimamba_inner_fn_no_out_proj(xz, params, params_b, delta_softplus=True, checkpoint_lvl=1, prepared=None, seq_valid=0):
     """params / params_b: (conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, A, D, delta_bias) of the
     left-to-right and of the right-to-left direction -> out_z_fwd + out_z_bwd, (batch, dim, seqlen).
-    prepared: None, or (x_proj_weight, delta_proj_weight, x_proj_weight_b, delta_proj_weight_b) already in the autocast dtype."""
-    return BiMambaInnerFnNoOutProj.apply(xz, delta_softplus, checkpoint_lvl, *params, *params_b, *(prepared or ()))
+    prepared: None, or (x_proj_weight, delta_proj_weight, x_proj_weight_b, delta_proj_weight_b) already in the autocast dtype.
+    seq_valid: 0, or the number of real positions when xz[..., seq_valid:] is the caller's zero padding (_inner_forward)."""
+    return BiMambaInnerFnNoOutProj.apply(xz, delta_softplus, checkpoint_lvl, int(seq_valid), *params, *params_b, *(prepared or ()))
 
 
 class MambaInnerFn(torch.autograd.Function):
