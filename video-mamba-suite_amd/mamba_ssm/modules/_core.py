@@ -50,7 +50,8 @@ _PARAM_PREP = os.environ.get("VMS_NO_PARAM_PREP", "0") != "1"
 # mixer: zero rows behind the real ones, delta = -inf there (selective_scan_interface._mask_padding), the result sliced back.
 # Every kernel of the block then runs its whole-vector form -- the one-grid backward of both directions, the LDS forward with lane
 # checkpoints, the fused conv1d + x_proj head -- instead of the element-wise ragged ones: a 2-layer (8, 3137, 768) stack 4.62 ->
-# 3.2 ms per step, the aligned (8, 3136, 768) one 3.04.  VMS_NO_SEQ_PAD=1: ragged rows as they come.
+# 3.3 ms per step, the aligned (8, 3136, 768) one 3.04; also on the host the padded step is the cheaper one (fewer launches: a
+# 2-layer stack at (1, 65, 768), all host time, 3.1 -> 2.3 ms).  VMS_NO_SEQ_PAD=1: ragged rows as they come.
 _SEQ_PAD = 0 if os.environ.get("VMS_NO_SEQ_PAD", "0") == "1" else 16
 _SEQ_PAD_TILES = os.environ.get("VMS_SEQ_PAD_TILES", "1") != "0"   # extend the padding to a GEMM-friendly token count (_seq_padding)
 _SEQ_PAD_FP32 = False   # tests: pad fp32 activations too (the arithmetic of the padding checked without 16-bit rounding)
@@ -68,40 +69,6 @@ def _padded_len(batch, seqlen, unit=None):
             if (batch * (padded + more)) % 256 == 0:
                 return padded + more
     return padded
-
-
-class _PadSeqFn(torch.autograd.Function):
-    """(B, L, D) -> (B, L + pad, D), zeros behind the sequence: one copy and a fill of the tail only (F.pad fills the whole
-    buffer first); the gradient is the slice"""
-
-    @staticmethod
-    def forward(ctx, x, pad):
-        ctx.seqlen = x.shape[1]
-        out = x.new_empty(x.shape[0], x.shape[1] + pad, x.shape[2])
-        out[:, :x.shape[1]].copy_(x)
-        out[:, x.shape[1]:].zero_()
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        return g[:, :ctx.seqlen], None
-
-
-class _UnpadSeqFn(torch.autograd.Function):
-    """(B, L + pad, D) -> its first L positions, contiguous; the gradient takes zeros behind the sequence (what the padded run must
-    see: no upstream gradient on the padding)"""
-
-    @staticmethod
-    def forward(ctx, x, seqlen):
-        ctx.padded = x.shape[1]
-        return x[:, :seqlen].contiguous()
-
-    @staticmethod
-    def backward(ctx, g):
-        out = g.new_empty(g.shape[0], ctx.padded, g.shape[2])
-        out[:, :g.shape[1]].copy_(g)
-        out[:, g.shape[1]:].zero_()
-        return out, None
 
 
 def _s4d_real_log(d_inner, d_state, device):
@@ -328,7 +295,7 @@ class MambaCore(nn.Module):
             # -- what the right-to-left conv1d must see beyond the sequence's end, and a closed gate (z = 0) on the padding's output
             pad = self._seq_padding(hidden_states)
             if pad:
-                hidden_states = _PadSeqFn.apply(hidden_states, pad)
+                hidden_states = F.pad(hidden_states, (0, 0, 0, pad))   # (its backward: a slice; the slice's below: zeros + a copy)
             valid = seqlen if pad else 0
             prep = self._prepare_params(hidden_states)
             if prep is None:
@@ -337,14 +304,14 @@ class MambaCore(nn.Module):
                 out = self._merge_and_project(
                     bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                                  checkpoint_lvl=_CHECKPOINT_LVL, seq_valid=valid), None)
-                return _UnpadSeqFn.apply(out, seqlen) if pad else out
+                return out[:, :seqlen] if pad else out
             xz = self._in_projection(hidden_states, prep["wt_in"])
             A, A_b = NegExpPairFn.apply(self.A_log, self.A_b_log, prep["A"], prep["A_b"])
             out = self._merge_and_project(
                 bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                              checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"], seq_valid=valid), None,
                 w_prepared=None if self.if_devide_out and self.variant == "vim_norm" else prep["w_out"])
-            return _UnpadSeqFn.apply(out, seqlen) if pad else out
+            return out[:, :seqlen] if pad else out
         xz = self._in_projection(hidden_states)
         if self.bimamba_type == "v2":
             if fast:
