@@ -15,6 +15,7 @@
 // end reads the row start and is neutralised through delta = 0), so that the prefetch of the next state's
 // B / C -- after the last state: of the next chunk's first state -- really stays in flight.
 #include "vms_common.h"
+#include <type_traits>
 
 namespace vms {
 
@@ -84,6 +85,15 @@ __device__ __forceinline__ void wave_scan_fused_p(float& a, float& x) {
     asm volatile("s_nop 1\n\t" VMS_STEP("row_shr:1", "0xf") VMS_STEP("row_shr:2", "0xf") VMS_STEP("row_shr:4", "0xf")
                      VMS_STEP("row_shr:8", "0xf") VMS_STEP("row_bcast:15", "0xa") VMS_STEP("row_bcast:31", "0xc")
                  : "+v"(x), "+v"(a));
+#undef VMS_STEP
+}
+// the same over each 16-lane DPP row separately (4 in-row steps): four independent scans per wave
+__device__ __forceinline__ void row_scan_fused_p(float& a, float& x) {
+#define VMS_STEP(CTRL)                                                            \
+    "v_fmac_f32_dpp %0, %0, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"           \
+    "s_nop 1\n\t"
+    asm volatile("s_nop 1\n\t" VMS_STEP("row_shr:1") VMS_STEP("row_shr:2") VMS_STEP("row_shr:4") VMS_STEP("row_shr:8") : "+v"(x), "+v"(a));
 #undef VMS_STEP
 }
 __device__ __forceinline__ f2 pk_fma_p(f2 a, f2 b, f2 c) {
@@ -465,8 +475,17 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
     stage_issue(gi);
     stage_commit(0);
     __syncthreads();
-    for (int c = c_lo; c < c_hi; ++c) {
-        const int l0 = c * CS + lane * K;
+    // the chunk body twice, as a whole-wave pass (the loop) and as the tail form (once, behind the loop): two separate code
+    // regions, so that the tail form's temporaries do not sit in the loop's register budget (inside the loop, as a branch, they
+    // pushed it into scratch: 2.5x slower)
+    auto run_chunk = [&](const int c, auto tail_tag) __attribute__((always_inline)) {
+        // A row's last chunk of <= 256 elements (L = 3136: 64, L = 2304: 256) would cost a whole 1024-element pass with 4 - 16 of
+        // the 64 lanes at work.  It runs FOUR STATES AT A TIME instead: DPP row g (16 lanes x 16 elements = the 256 positions)
+        // carries state 4 sg + g, the lane aggregates are scanned per row, the four rows' y are summed at the end (do_quad):
+        // a quarter of a pass.  (8, 768, 3136): 4 -> 3.25 passes per row.
+        constexpr bool tail = decltype(tail_tag)::value;
+        const int li = tail ? (lane & 15) : lane;           // the lane's slot of 16 elements inside the chunk
+        const int l0 = c * CS + li * K;
         const bool ok = l0 < L && row_ok;
         const uint32_t pl0 = REV ? L - l0 - K : l0;
         f2 dl2[K / 2], du2[K / 2], y2[K / 2];
@@ -476,7 +495,8 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             t0.load(u_b, o_u + pl0, ok);
             t1.load(dt_b, o_dt + pl0, ok);
             // per element-PAIR (round 3): packed adds / multiplies around the transcendentals
-            const f2 bias2 = f2{bias, bias}, Dd2 = f2{Dd, Dd};
+            const float Dq = tail && lane >= 16 ? 0.f : Dd;   // tail: the four rows' y are summed, D u counts once
+            const f2 bias2 = f2{bias, bias}, Dd2 = f2{Dq, Dq};
             f2 sd2 = f2{0.f, 0.f};
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
@@ -539,22 +559,88 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
                 y2[k] = pk_fma_p((k & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y}, bx2[k], y2[k]);
             }
         };
+        // the four states of a staged group at once, one per DPP row (tail chunks, see above): do_state with per-row A / state
+        auto do_quad = [&](const int sg, const int buf) __attribute__((always_inline)) {
+            const int g4 = lane >> 4;
+            const lds_f4p* bsrc = (const lds_f4p*)(smem + buf * kLGroupFloats + g4 * (kWave * K)) + li;
+            const lds_f4p* csrc = bsrc + kLG * (kWave * K) / 4;
+            const f4 b0 = bsrc[0], b1 = bsrc[kWave], b2 = bsrc[2 * kWave], b3 = bsrc[3 * kWave];
+            const int n0 = 4 * sg;
+            const float A0 = readlane_f(A_mine, n0), A1 = readlane_f(A_mine, n0 + 1), A2 = readlane_f(A_mine, n0 + 2), A3 = readlane_f(A_mine, n0 + 3);
+            const float H0 = readlane_f(hreg, n0), H1 = readlane_f(hreg, n0 + 1), H2 = readlane_f(hreg, n0 + 2), H3 = readlane_f(hreg, n0 + 3);
+            const float An = g4 == 0 ? A0 : g4 == 1 ? A1 : g4 == 2 ? A2 : A3;
+            const float hin = g4 == 0 ? H0 : g4 == 1 ? H1 : g4 == 2 ? H2 : H3;
+            const f2 An2 = f2{An, An};
+            f2 a2[K / 2], bx2[K / 2];
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f4 bq = k < 2 ? b0 : k < 4 ? b1 : k < 6 ? b2 : b3;
+                const f2 t = dl2[k] * An2;
+                a2[k] = f2{fast_exp2(t.x), fast_exp2(t.y)};
+                bx2[k] = du2[k] * ((k & 1) ? f2{bq.z, bq.w} : f2{bq.x, bq.y});
+            }
+            float px = 0.f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) px = fmaf(VMS_ELP(a2, i), px, VMS_ELP(bx2, i));
+            float pa = fast_exp2(sdl * An);
+            row_scan_fused_p(pa, px);
+            const f4 c0 = csrc[0], c1 = csrc[kWave], c2 = csrc[2 * kWave], c3 = csrc[3 * kWave];
+            const float ea = dpp_mov<DPP_ROW_SHR1, 0xf>(1.f, pa);   // (the row's first lane keeps the identity)
+            const float ex = dpp_mov<DPP_ROW_SHR1, 0xf>(0.f, px);
+            float xs = fmaf(ea, hin, ex);
+            const float hend = fmaf(pa, hin, px);
+            if (!XC && p.x_has_sub == 1 && ((li + 1) * K) % 128 == 0 && row_ok) {
+                const int i128 = (c * CS + (li + 1) * K) / 128 - 1;
+                xck[(int64_t)(i128 >> 4) * xpitch + 2 * N + (i128 & 15) * N + n0 + g4] = hend;
+            }
+            // lanes past the row's end are identity steps: the last lane of DPP row g holds state n0 + g after the chunk
+            const float E0 = readlane_f(hend, 15), E1 = readlane_f(hend, 31), E2 = readlane_f(hend, 47), E3 = readlane_f(hend, 63);
+            hreg = lane == n0 ? E0 : lane == n0 + 1 ? E1 : lane == n0 + 2 ? E2 : lane == n0 + 3 ? E3 : hreg;
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                xs = fmaf(VMS_ELP(a2, i), xs, VMS_ELP(bx2, i));
+                VMS_ELP(bx2, i) = xs;
+            }
+            if constexpr (XC) {   // the slots do_state's lane li would use for state n0 + g
+                (park - lane + li)[g4 * kWave] = bx2[3].y;
+                (park - lane + li)[(kLG + g4) * kWave] = bx2[7].y;
+            }
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) {
+                const f4 cq = k < 2 ? c0 : k < 4 ? c1 : k < 6 ? c2 : c3;
+                y2[k] = pk_fma_p((k & 1) ? f2{cq.z, cq.w} : f2{cq.x, cq.y}, bx2[k], y2[k]);
+            }
+        };
 #pragma unroll 1
         for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
             const int buf = gi & 1;
             stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
             if constexpr (XC) flush_park(sg > 0 ? c : c - 1, (sg + kLG - 1) & (kLG - 1), sg > 0 || c > c_lo);   // the group before this one
-            do_state(4 * sg, buf);
-            do_state(4 * sg + 1, buf);
-            do_state(4 * sg + 2, buf);
-            do_state(4 * sg + 3, buf);
+            if constexpr (tail) {
+                do_quad(sg, buf);
+            } else {
+                do_state(4 * sg, buf);
+                do_state(4 * sg + 1, buf);
+                do_state(4 * sg + 2, buf);
+                do_state(4 * sg + 3, buf);
+            }
             stage_commit(buf ^ 1);   // every wave left that buffer at the previous barrier
             __syncthreads();
         }
         float y[K];
 #pragma unroll
         for (int i = 0; i < K; ++i) y[i] = VMS_ELP(y2, i);
-        if (ok) store_p<T, REV>(out_b + (o_out + pl0), y);
+        if constexpr (tail) {   // sum of the four DPP rows' partial y (lane li of each row holds the same 16 positions)
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                y[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, y[i])));
+                y[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, y[i])));
+            }
+#pragma unroll
+            for (int k = 0; k < K / 2; ++k) y2[k] = f2{y[2 * k], y[2 * k + 1]};
+        }
+        const bool st_okk = ok && (!tail || lane < 16);     // tail: DPP row 0 writes the positions
+        if (st_okk) store_p<T, REV>(out_b + (o_out + pl0), y);
         if (HZ) {
             RawP<T, REV> tz;
             tz.load(z_b, o_z + pl0, ok);
@@ -570,7 +656,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
 #pragma unroll
                 for (int i = 0; i < K; ++i) y[i] += told.at(i);
             }
-            if (ok) store_p<T, REV>(outz_b + (o_oz + pl0), y);
+            if (st_okk) store_p<T, REV>(outz_b + (o_oz + pl0), y);
         }
         const bool last = c == n_kchunks - 1;
         const int pos = (c + 1) * CS;
@@ -581,7 +667,12 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             if (r <= 1024) xb[2 * lane] = hreg;
             if (r == 2048 || last) xb[2 * lane + 1] = hreg;
         }
-    }
+    };
+    // (workgroup-uniform) the range's last chunk is the row's last and holds <= 256 elements
+    const bool has_tail = c_hi == n_kchunks && c_hi > c_lo && L - (c_hi - 1) * CS <= 16 * K;
+    const int c_main = has_tail ? c_hi - 1 : c_hi;
+    for (int c = c_lo; c < c_main; ++c) run_chunk(c, std::false_type{});
+    if (has_tail) run_chunk(c_hi - 1, std::true_type{});
     if constexpr (XC) flush_park(c_hi - 1, kLG - 1, c_hi > c_lo);   // the last group of the last chunk
 }
 
