@@ -709,7 +709,9 @@ def test_scan_rows_checkpoint_region(oracle, monkeypatch):
 
 
 
-@pytest.mark.parametrize("L", [2512, 2504, 8])
+# 2064 / 2304 / 1280 / 256 / 64: a last chunk of <= 256 elements -- the LDS forward's four-states-at-a-time tail form; 2512 / 1296: a
+# longer one (whole-wave pass)
+@pytest.mark.parametrize("L", [2512, 2504, 8, 2064, 2304, 1280, 1296, 256, 64])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_scan_lane_checkpoints(oracle, L, reverse):
     """ABI v7, x_has_sub == 3: where the whole-vector backward kernel takes the problem, the forward (the LDS kernel at
