@@ -109,3 +109,53 @@ def test_mask_padding_makes_identity_steps():
     assert got.shape[-1] == L + pad
     assert got[..., L:].abs().max().item() == 0.0
     assert _rel(got[..., :L].float(), ref.float()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_padding_inference_no_grad(monkeypatch, dtype):
+    """forward only (torch.no_grad, eval), fp16 and bf16 autocast, an input that needs no gradient: padded == ragged within the
+    dtype's rounding, and the output has the caller's shape"""
+    from mamba_ssm.modules import _core
+    mod = _make("vim", 96).eval()
+    torch.manual_seed(2)
+    hidden = torch.randn(3, 393, 96, device="cuda")
+    outs = []
+    for pad in (0, 16):
+        monkeypatch.setattr(_core, "_SEQ_PAD", pad)
+        with torch.no_grad(), torch.autocast("cuda", dtype=dtype):
+            outs.append(mod(hidden).float())
+    assert outs[0].shape == outs[1].shape == (3, 393, 96)
+    assert torch.isfinite(outs[1]).all()
+    assert _rel(outs[1], outs[0]) < (2e-2 if dtype == torch.bfloat16 else 5e-3)
+
+
+def test_padding_block_stack_matches_ragged(monkeypatch):
+    """two Blocks (fused add + RMSNorm -> ViM mixer) on a ragged length, bf16 autocast, forward + backward: the padded stack tracks
+    the ragged one (the un-padded slices feed the next block's norm)"""
+    from functools import partial
+    from mamba_ssm.modules import _core
+    from mamba_ssm.modules.mamba_simple import Block, Mamba
+    from mamba_ssm.ops.triton.layernorm import RMSNorm
+    torch.manual_seed(0)
+    d = 128
+    blocks = torch.nn.ModuleList([Block(d, partial(Mamba, bimamba_type="v2", layer_idx=i), norm_cls=partial(RMSNorm, eps=1e-5),
+                                        fused_add_norm=True, residual_in_fp32=True) for i in range(2)]).cuda()
+    x = torch.randn(2, 197, d, device="cuda")
+    g = torch.randn(2, 197, d, device="cuda")
+
+    def run():
+        blocks.zero_grad(set_to_none=True)
+        h = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            hid, res = h, None
+            for blk in blocks:
+                hid, res = blk(hid, res)
+        (hid.float() * g).sum().backward()
+        return hid.detach().float(), h.grad.float(), [p.grad.float().clone() for p in blocks.parameters()]
+    monkeypatch.setattr(_core, "_SEQ_PAD", 0)
+    o0, dh0, g0 = run()
+    monkeypatch.setattr(_core, "_SEQ_PAD", 16)
+    o1, dh1, g1 = run()
+    assert _rel(o1, o0) < 2e-2 and _rel(dh1, dh0) < 3e-2
+    for a, b in zip(g1, g0):
+        assert _rel(a, b) < 3e-2
