@@ -360,7 +360,9 @@ struct Raw8 {
 };
 
 // XC: the state after every 8 elements goes to x (vms_hip.h x_has_sub == 3)
-template <typename T, bool HZ, bool REV, bool XC>
+// TQ: the instantiation that also holds the four-states-at-a-time form of a row's last chunk (launched only for rows that have
+// such a chunk: with the form compiled in, the whole-wave loop of (8, 1024, 8192) ran 2 % slower -- one more spilled register)
+template <typename T, bool HZ, bool REV, bool XC, bool TQ>
 __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, const int n_seg, const float2* __restrict__ seg_carry) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int K = kPK, N = kPN, CS = kWave * K;
@@ -669,26 +671,30 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         }
     };
     // (workgroup-uniform) the range's last chunk is the row's last and holds <= 256 elements
-    const bool has_tail = c_hi == n_kchunks && c_hi > c_lo && L - (c_hi - 1) * CS <= 16 * K;
-    const int c_main = has_tail ? c_hi - 1 : c_hi;
-    for (int c = c_lo; c < c_main; ++c) run_chunk(c, std::false_type{});
-    if (has_tail) run_chunk(c_hi - 1, std::true_type{});
+    if constexpr (TQ) {
+        const bool has_tail = c_hi == n_kchunks && c_hi > c_lo && L - (c_hi - 1) * CS <= 16 * K;
+        const int c_main = has_tail ? c_hi - 1 : c_hi;
+        for (int c = c_lo; c < c_main; ++c) run_chunk(c, std::false_type{});
+        if (has_tail) run_chunk(c_hi - 1, std::true_type{});
+    } else {
+        for (int c = c_lo; c < c_hi; ++c) run_chunk(c, std::false_type{});
+    }
     if constexpr (XC) flush_park(c_hi - 1, kLG - 1, c_hi > c_lo);   // the last group of the last chunk
 }
 
 
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from: entries >= p.reverse_from run
 // right-to-left).  A workgroup serves one batch entry, so the direction is workgroup-uniform: one branch, both bodies.
-template <typename T, bool HZ, int RM, bool XC>
+template <typename T, bool HZ, int RM, bool XC, bool TQ = false>
 __global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
                                                                         const float2* __restrict__ seg_carry) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % p.batch;
-        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true, XC>(p, n_seg, seg_carry);
-        else scan_fwd_lds_body<T, HZ, false, XC>(p, n_seg, seg_carry);
+        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true, XC, TQ>(p, n_seg, seg_carry);
+        else scan_fwd_lds_body<T, HZ, false, XC, TQ>(p, n_seg, seg_carry);
     } else {
-        scan_fwd_lds_body<T, HZ, RM == 1, XC>(p, n_seg, seg_carry);
+        scan_fwd_lds_body<T, HZ, RM == 1, XC, TQ>(p, n_seg, seg_carry);
     }
 }
 
@@ -1158,7 +1164,10 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
             hipError_t e = hipSuccess;
 #define VMS_AL(Z_, R_)                                                                                              \
             if (e == hipSuccess)                                                                                    \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true>),        \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, false>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                     \
+            if (e == hipSuccess)                                                                                    \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, true>),  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
             VMS_AL(true, 0); VMS_AL(true, 1); VMS_AL(true, 2); VMS_AL(false, 0); VMS_AL(false, 1); VMS_AL(false, 2);
 #undef VMS_AL
@@ -1170,10 +1179,21 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
         }
     }
     const dim3 grid_l(p.batch * ((p.dim + kLW - 1) / kLW) * n_seg), block_l(kLW * kWave);
+    // a row whose last 1024-element chunk holds <= 256 elements: the instantiation with the four-states-at-a-time tail form
+#ifndef VMS_FWD_TAIL_QUAD
+#define VMS_FWD_TAIL_QUAD 1   /* 0 (A/B builds, tools/variant.sh): every chunk as a whole-wave pass */
+#endif
+    const int tail_len = p.seqlen % (kWave * kPK);
+    const bool tq = VMS_FWD_TAIL_QUAD && tail_len > 0 && tail_len <= 16 * kPK;
 #define VMS_LL(Z_, R_, S_)                                                                                         \
     do {                                                                                                           \
-        if (p.x_has_sub == 3) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true>), grid_l, block_l, smem_l, stream, p, S_, carry);  \
-        else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false>), grid_l, block_l, smem_l, stream, p, S_, carry);                 \
+        if (p.x_has_sub == 3) {                                                                                    \
+            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, true>), grid_l, block_l, smem_l, stream, p, S_, carry);   \
+            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, false>), grid_l, block_l, smem_l, stream, p, S_, carry);      \
+        } else {                                                                                                   \
+            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, true>), grid_l, block_l, smem_l, stream, p, S_, carry);  \
+            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, false>), grid_l, block_l, smem_l, stream, p, S_, carry);     \
+        }                                                                                                          \
     } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
