@@ -14,6 +14,7 @@ which parameters are created (so a seed gives the same initial weights), forward
 """
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -55,6 +56,10 @@ _PARAM_PREP = os.environ.get("VMS_NO_PARAM_PREP", "0") != "1"
 _SEQ_PAD = 0 if os.environ.get("VMS_NO_SEQ_PAD", "0") == "1" else 16
 _SEQ_PAD_TILES = os.environ.get("VMS_SEQ_PAD_TILES", "1") != "0"   # extend the padding to a GEMM-friendly token count (_seq_padding)
 _SEQ_PAD_FP32 = False   # tests: pad fp32 activations too (the arithmetic of the padding checked without 16-bit rounding)
+
+
+# per module: the parameter-preparation launch's descriptors (vms_hip.PrepPlan); outside the module so that it pickles / deep-copies
+_PREP_PLANS = weakref.WeakKeyDictionary()
 
 
 def _padded_len(batch, seqlen, unit=None):
@@ -170,18 +175,29 @@ class MambaCore(nn.Module):
             return None
         import vms_hip
         dev = hidden_states.device
-        # one allocation for the low-precision copies (each starting on a 256-byte boundary: GEMM operands), one for the two A
-        sizes = [(w.numel() + 127) // 128 * 128 for w in ws]
-        flat = torch.empty(sum(sizes), dtype=dt, device=dev)
-        lows, o = [], 0
-        for w, n in zip(ws, sizes):
-            lows.append(flat[o:o + w.numel()].view(w.shape if w is not self.in_proj.weight else (w.shape[1], w.shape[0])))
-            o += n
+        # one allocation for the low-precision copies (each starting on a 256-byte boundary: GEMM operands), one for the two A;
+        # the job descriptors are built once per (dtype, device, parameter storage) and re-aimed at the new buffers every step
+        srcs = ws + (self.A_log, self.A_b_log)
+        plan = _PREP_PLANS.get(self)
+        if plan is None or plan[0] != (dt, dev) or not plan[1].matches(srcs):
+            esz = 2
+            shapes = [tuple(w.shape) if w is not self.in_proj.weight else (w.shape[1], w.shape[0]) for w in ws]
+            offs, o = [], 0
+            for w in ws:
+                offs.append(o)
+                o += (w.numel() + 127) // 128 * 128
+            jobs = [(w.detach(), 0, off * esz, sh, (sh[1], 1), dt, vms_hip.PREP_CAST_T if w is self.in_proj.weight else vms_hip.PREP_CAST)
+                    for w, off, sh in zip(ws, offs, shapes)]
+            an = self.A_log.numel()
+            jobs += [(a.detach(), 1, k * an * 4, tuple(a.shape), (a.shape[1], 1), torch.float32, vms_hip.PREP_NEG_EXP)
+                     for k, a in enumerate((self.A_log, self.A_b_log))]
+            plan = ((dt, dev), vms_hip.PrepPlan(jobs), o, offs, shapes)
+            _PREP_PLANS[self] = plan
+        _, pp, total, offs, shapes = plan
+        flat = torch.empty(total, dtype=dt, device=dev)
         A2 = torch.empty((2,) + tuple(self.A_log.shape), dtype=torch.float32, device=dev)
-        jobs = [(self.in_proj.weight.detach(), lows[0], vms_hip.PREP_CAST_T)]
-        jobs += [(w.detach(), l, vms_hip.PREP_CAST) for w, l in zip(ws[1:], lows[1:])]
-        jobs += [(self.A_log.detach(), A2[0], vms_hip.PREP_NEG_EXP), (self.A_b_log.detach(), A2[1], vms_hip.PREP_NEG_EXP)]
-        vms_hip.param_prep(jobs)
+        pp.run((flat.data_ptr(), A2.data_ptr()), flat)
+        lows = [flat.as_strided(sh, (sh[1], 1), off) for sh, off in zip(shapes, offs)]
         return dict(wt_in=lows[0], small=tuple(lows[1:5]), w_out=lows[5], A=A2[0], A_b=A2[1])
 
     def _prepare_params_dbm(self, hidden_states):

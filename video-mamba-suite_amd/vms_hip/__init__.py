@@ -947,6 +947,41 @@ def state_update(state, x, dt, A, B, C, D, z, dt_bias, out, dt_softplus):
     _call("vms_selective_state_update", P, x)
 
 
+class PrepPlan:
+    """vms_param_prep for a FIXED list of jobs whose destinations move every step (a block's per-step weight preparation): the
+    parameter block is filled once -- sources, shapes, strides, dtypes -- and a launch only rewrites the destination pointers
+    (param_prep builds it from tensors every time: ~45 us of host time per block step).
+    jobs: (src tensor, dst group, dst byte offset, dst shape, dst strides in elements, dst dtype, op); the destinations are
+    regions of `n_groups` buffers whose base pointers the caller passes to run()."""
+
+    def __init__(self, jobs):
+        assert 0 < len(jobs) <= PREP_MAX_JOBS
+        self.P = PrepParams()
+        self.P.n_jobs = len(jobs)
+        self.src_ptrs = tuple(src.data_ptr() for src, *_ in jobs)
+        self.dst = []
+        codes = {torch.float32: VMS_F32, torch.float16: VMS_F16, torch.bfloat16: VMS_BF16}
+        for j, (src, group, off, dshape, dstrides, ddtype, op) in zip(self.P.job, jobs):
+            s2 = src if src.dim() == 2 else src.reshape(1, -1)
+            dshape, dstrides = (tuple(dshape), tuple(dstrides)) if len(dshape) == 2 else ((1, dshape[0]), (dshape[0], dstrides[0]))
+            if s2.stride(1) != 1 or dstrides[1] < 1 or dshape != (tuple(s2.shape) if op != PREP_CAST_T else tuple(s2.shape[::-1])):
+                raise RuntimeError("param_prep: jobs are (rows, cols) matrices, src with a unit column stride, and matching shapes")
+            j.src, j.rows, j.cols = _ptr(s2), s2.shape[0], s2.shape[1]
+            j.dst_col_stride = dstrides[1] if dshape[1] > 1 else 1
+            j.src_row_stride = s2.stride(0) if s2.shape[0] > 1 else s2.shape[1]
+            j.dst_row_stride = dstrides[0] if dshape[0] > 1 else dshape[1]
+            j.src_dtype, j.dst_dtype, j.op = dtype_code(s2), codes[ddtype], op
+            self.dst.append((group, off))
+
+    def matches(self, srcs):
+        return self.src_ptrs == tuple(t.data_ptr() for t in srcs)
+
+    def run(self, bases, ref_tensor):
+        for j, (group, off) in zip(self.P.job, self.dst):
+            j.dst = bases[group] + off
+        _call("vms_param_prep", self.P, ref_tensor)
+
+
 def param_prep(jobs):
     """jobs: up to PREP_MAX_JOBS triples (src, dst, op) of 2-D tensors (1-D ones count as one row), src with a unit column stride, dst
     with any column stride (2 = one half of an interleaved matrix):
