@@ -61,7 +61,7 @@ def main():
 
 def norm_bench():
     import layer_norm_cuda
-    M, N = 8 * 8192, 1024
+    M, N = [int(v) for v in os.environ.get("KB_NORM_SHAPE", "65536,1024").split(",")]   # rows, columns
     x = torch.randn(M, N, device="cuda", dtype=torch.bfloat16); res = torch.randn(M, N, device="cuda", dtype=torch.float32)
     w = torch.ones(N, device="cuda"); dy = torch.randn_like(x); dres = torch.randn_like(res)
     y, mean, rstd, ro = layer_norm_cuda.fwd(x, w, None, 1e-5, res, is_rms_norm=True)
