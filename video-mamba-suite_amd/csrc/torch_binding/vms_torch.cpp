@@ -603,7 +603,7 @@ bool proj_kred_eligible(const Tensor& w, const Tensor& in, const Tensor& out) {
 }
 // cast_src: fp32 (groups, batch, rows, seqlen), rounded into the groups * rows rows that follow out's m rows in its parent tensor
 void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT& w2, const OptT& in2, const OptT& out2, int64_t tile,
-               const OptT& cast_src = OptT()) {
+               const OptT& cast_src = OptT(), const OptT& cast_src2 = OptT()) {
     TORCH_CHECK(proj_kred_eligible(w, in, out), "proj_kred: 16-bit w (m <= 96, k), in (batch, k, seqlen), out (batch, m, seqlen) of one dtype "
                 "expected; unit seqlen strides, seqlen / strides multiples of 8, 16-byte aligned, w contiguous along k or m");
     vms_proj_kred_params P{};
@@ -625,6 +625,11 @@ void proj_kred(const Tensor& w, const Tensor& in, const Tensor& out, const OptT&
                     "proj_kred: cast_src must be fp32 (groups, batch, rows, seqlen) with a unit seqlen stride");
         P.cast_src = c.data_ptr<float>(); P.cast_groups = (int)c.size(0); P.cast_rows = (int)c.size(2);
         P.cast_group_stride = c.stride(0); P.cast_batch_stride = c.stride(1); P.cast_row_stride = c.stride(2);
+        if (cast_src2.has_value()) {
+            TORCH_CHECK(w2.has_value() && cast_src2->scalar_type() == at::kFloat && cast_src2->sizes() == c.sizes() && cast_src2->strides() == c.strides(),
+                        "proj_kred: cast_src2 comes with the second problem and has cast_src's shape and strides");
+            P.cast_src2 = cast_src2->data_ptr<float>();
+        }
     }
     call("vms_proj_kred", vms_proj_kred, P, in);
 }
@@ -733,6 +738,7 @@ struct InnerBwd {
     bool acc, use_mfma_proj, use_kred, mfma_wg, fused_tail, reverse;
     int64_t reverse_from;
     at::ScalarType wdt;
+    Tensor dx_dbl_pre;      // set by inner_bwd_dual: dx_dbl with its d_dt and dB / dC rows already written (one vms_proj_kred for both directions)
 };
 
 InnerBwd inner_bwd_begin(const Tensor& xz, const Tensor& conv_w, const OptT& conv_b, const Tensor& x_proj_w, const Tensor& dt_proj_w,
@@ -783,12 +789,13 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
     Tensor& zeros = I.zeros;
     const auto wdt = I.wdt;
     Tensor dconv_out = *g[0], ddelta = *g[1];
-    Tensor dx_dbl = at::empty_like(x_dbl);                                                  // (b, R + 2N, l)
+    const bool pre = I.dx_dbl_pre.defined();
+    Tensor dx_dbl = pre ? I.dx_dbl_pre : at::empty_like(x_dbl);                             // (b, R + 2N, l)
     // dB and dC sit back to back in the zero-filled buffer (scan_bwd carves dA, dB, dC, ...): rounded into their rows of dx_dbl by the
     // kernel that writes its first R rows (vms_proj_kred's cast rows), or by one cast kernel for both
     const Tensor dbc = zeros.narrow(0, I.A.numel(), 2 * I.Bv.numel()).view({2, b, N, dx_dbl.size(2)});
     Tensor d_dt = dx_dbl.narrow(1, 0, R);                                                   // (b, R, l) = W_dt^T ddelta
-    const bool kred_dt = I.use_kred && proj_kred_eligible(dt_proj_w.t(), ddelta, d_dt) && dx_dbl.size(2) % 4 == 0;
+    const bool kred_dt = pre || (I.use_kred && proj_kred_eligible(dt_proj_w.t(), ddelta, d_dt) && dx_dbl.size(2) % 4 == 0);
     if (!kred_dt) dx_dbl.narrow(1, R, 2 * N).view({b, 2, N, dx_dbl.size(2)}).copy_(dbc.permute({1, 0, 2, 3}));
     Tensor ddt_proj_w, dx_proj_w;
     if (I.mfma_wg && proj_wgrad_eligible(dt_in, ddelta)) {
@@ -811,7 +818,8 @@ std::vector<OptT> inner_bwd_finish(InnerBwd& I, const std::vector<OptT>& g) {
         }
     }
     // written straight into its rows of dx_dbl (a batch-strided output: no copy kernel)
-    if (kred_dt) proj_kred(dt_proj_w.t(), ddelta, d_dt, OptT(), OptT(), OptT(), 0, dbc);
+    if (pre) {}
+    else if (kred_dt) proj_kred(dt_proj_w.t(), ddelta, d_dt, OptT(), OptT(), OptT(), 0, dbc);
     else at::bmm_out(d_dt, dt_proj_w.t().unsqueeze(0).expand({b, -1, -1}), ddelta);
     if (I.fused_tail) {
         // SSI:278-283 in one pass over the activations (vms_proj_conv_bwd): dconv1d_out = du + W_x^T dx_dbl stays on chip
@@ -873,6 +881,25 @@ std::vector<OptT> inner_bwd_dual(const Tensor& dout_, const Tensor& xz, const st
         Ia.conv_out, T(a[9]), Ia.A, Ia.bc.B, Ia.bc.C, Ia.D_, Ia.delta_bias_, a[10], T(a[11]), Ia.zeros.narrow(0, 0, Ia.n_scan), Ia.Bv, Ia.Cv,
         Ib.conv_out, T(b[9]), Ib.A, Ib.bc.B, Ib.bc.C, Ib.D_, Ib.delta_bias_, b[10], T(b[11]), Ib.zeros.narrow(0, 0, Ib.n_scan), Ib.Bv, Ib.Cv,
         Ia.z, dout, Ia.dz, delta_softplus, /*keep_fp32=*/true, /*accumulate_dz=*/false, Ia.bc.pad, Ib.bc.pad, impl, segments);
+    // d_dt = W_dt^T ddelta of both directions (and the rounding of their dB / dC into dx_dbl) as ONE vms_proj_kred launch: two grids of
+    // ~1.5 workgroups per CU each otherwise ((8, 768, 3136): 2 x 11.8 us)
+    {
+        const Tensor &dda = *g[0][1], &ddb = *g[1][1];
+        const int64_t L = Ia.x_dbl.size(2);
+        if (Ia.use_kred && Ib.use_kred && L % 4 == 0 && Ia.R == Ib.R && Ia.N == Ib.N && Ia.x_dbl.sizes() == Ib.x_dbl.sizes() &&
+            Ia.x_dbl.strides() == Ib.x_dbl.strides() && dda.sizes() == ddb.sizes() && dda.strides() == ddb.strides() &&
+            Ia.dt_proj_w.strides() == Ib.dt_proj_w.strides()) {
+            Tensor xa = at::empty_like(Ia.x_dbl), xb = at::empty_like(Ib.x_dbl);
+            Tensor da = xa.narrow(1, 0, Ia.R), db = xb.narrow(1, 0, Ib.R);
+            if (xa.strides() == xb.strides() && proj_kred_eligible(Ia.dt_proj_w.t(), dda, da) && proj_kred_eligible(Ib.dt_proj_w.t(), ddb, db)) {
+                const Tensor dbca = Ia.zeros.narrow(0, Ia.A.numel(), 2 * Ia.Bv.numel()).view({2, Ia.b, Ia.N, L});
+                const Tensor dbcb = Ib.zeros.narrow(0, Ib.A.numel(), 2 * Ib.Bv.numel()).view({2, Ib.b, Ib.N, L});
+                proj_kred(Ia.dt_proj_w.t(), dda, da, Ib.dt_proj_w.t(), ddb, db, 0, dbca, dbcb);
+                Ia.dx_dbl_pre = xa;
+                Ib.dx_dbl_pre = xb;
+            }
+        }
+    }
     std::vector<OptT> ra = inner_bwd_finish(Ia, g[0]);
     std::vector<OptT> rb = inner_bwd_finish(Ib, g[1]);
     std::vector<OptT> res{ra[0]};
@@ -936,7 +963,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
           py::arg("D"), py::arg("delta_bias"), py::arg("delta_softplus"), py::arg("reverse"), py::arg("out_z_into"), py::arg("impl"),
           py::arg("segments"), py::arg("reverse_from"), py::arg("proj_flags"), py::arg("conv_out_given") = py::none(), py::arg("x_dbl_given") = py::none(), py::arg("seq_valid") = 0);
     m.def("proj_kred", &proj_kred, py::arg("w"), py::arg("inp"), py::arg("out"), py::arg("w2") = py::none(), py::arg("inp2") = py::none(),
-          py::arg("out2") = py::none(), py::arg("tile") = 0, py::arg("cast_src") = py::none());
+          py::arg("out2") = py::none(), py::arg("tile") = 0, py::arg("cast_src") = py::none(), py::arg("cast_src2") = py::none());
     m.def("x_proj_dual", &x_proj_dual);
     m.def("inner_bwd", &inner_bwd);
     m.def("inner_bwd_dual", &inner_bwd_dual);
