@@ -511,7 +511,9 @@ def test_conv_reverse_equals_flipped(seqlen, width, itype):
 @pytest.mark.parametrize("has_z", [True, False])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("shape,segments", [((2, 8, 4096, 1), "2"), ((1, 4, 5136, 1), "6"), ((1, 16, 65536, 1), None),
-                                            ((2, 4, 3072, 1), "16")])
+                                            ((2, 4, 3072, 1), "16"),
+                                            # the LDS kernel's four-state tail form in the last range (5184 = 5 x 1024 + 64, 2304 = 2 x 1024 + 256)
+                                            ((1, 8, 5184, 1), "3"), ((2, 16, 2304, 1), "3")])
 def test_scan_fwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, reverse, monkeypatch):
     """Few rows, long sequences: the forward runs as n ranges of 1024-element chunks per row, each started from the
     state the (P, q) pairs of scan_fwd_carry_kernel give (VMS_FWD_SEGMENTS forces a count; None = the kernel's own
