@@ -69,7 +69,6 @@ def test_padding_bf16_autocast_close_to_ragged_and_fp32(monkeypatch, batch, seql
     rag = _run(mod, hidden, gout, True)
     monkeypatch.setattr(_core, "_SEQ_PAD", 16)
     pad = _run(mod, hidden, gout, True)
-    import vms_hip
     for name, r, a, b in (("out", ref[0], rag[0], pad[0]), ("dhidden", ref[1], rag[1], pad[1])) + tuple(
             (n, ref[2][n], rag[2][n], pad[2][n]) for n in ref[2]):
         e_rag, e_pad = _rel(a, r), _rel(b, r)
