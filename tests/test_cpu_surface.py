@@ -468,9 +468,34 @@ def test_padded_len_rule():
     """modules/_core.py _padded_len: multiples of 16, extended to whole 256-token GEMM tiles when <= 2 % more positions buy it"""
     from mamba_ssm.modules import _core
     for batch, seqlen, want in ((8, 3137, 3168), (8, 1569, 1600), (16, 1569, 1584), (2, 1569, 1584), (1, 3137, 3152), (2, 197, 208),
-                                (64, 197, 208), (8, 35, 48), (32, 785, 800), (8, 3136, 3136), (3, 1, 16)):
+                                (64, 197, 208), (8, 35, 48), (32, 785, 800), (8, 3136, 3136), (3, 17, 32)):
         got = _core._padded_len(batch, seqlen, 16)
         assert got == want, (batch, seqlen, got, want)
         assert got % 16 == 0 and got >= seqlen and got - seqlen <= 15 + seqlen // 50
     m = _core.MambaCore(32, bimamba_type="v2")
     assert m._seq_padding(torch.zeros(2, 197, 32)) == 0      # CPU tensors are never padded
+
+
+def test_x_pitch_short_rows_keep_the_reference_shape():
+    """vms_scan_x_pitch (no GPU needed): problems the lane-per-row kernels take (selective_scan_short.hip: seqlen <= 16, thousands of
+    rows) get the reference's x and nothing behind it -- the 8-element checkpoint layout would cost 16.5 KB per row whatever its
+    length (20 GB per scan at TimeMamba's (1568, 8, 768)); long rows keep their checkpoints"""
+    import vms_hip
+    L = vms_hip.lib()
+
+    def pitch(batch, dim, seqlen, mode=-1, **kw):
+        P = vms_hip.ScanFwdParams()
+        P.batch, P.dim, P.seqlen, P.dstate, P.n_groups, P.n_chunks = batch, dim, seqlen, 16, 1, (seqlen + 2047) // 2048
+        P.dtype, P.is_variable_B, P.is_variable_C, P.delta_softplus = vms_hip.VMS_BF16, 1, 1, 1
+        for k, v in kw.items():
+            setattr(P, k, v)
+        return L.vms_scan_x_pitch(ctypes.byref(P), mode)
+    assert pitch(1568, 768, 8) == 32 and pitch(1568, 768, 16) == 32 and pitch(1568, 768, 8, mode=1) == 32
+    assert pitch(1568, 768, 8, reverse_from=784) == 32                 # both halves of a mixed-direction batch
+    big = (18 * 16, 258 * 16)                                          # room for the long-row kernels' checkpoints
+    assert pitch(1568, 768, 32) in big                                 # longer than the short kernels serve
+    assert pitch(4, 768, 16) in big                                    # too few rows
+    assert pitch(1568, 768, 8, is_variable_B=0) in big                 # constant B
+    assert pitch(1568, 768, 8, impl=vms_hip.IMPL_GENERIC) in big       # the caller forced another kernel generation
+    assert pitch(8, 768, 3136) in big and pitch(8, 768, 3136, mode=1) == 18 * 16
+    assert pitch(1568, 768, 8, mode=0) == 32 and pitch(8, 768, 3136, mode=0) == 32

@@ -1,0 +1,123 @@
+"""Short sequences, many rows (TimeMamba's scans along time: seqlen 4 ... 16, batch x 196 rows per channel): the lane-per-row kernels
+of csrc/selective_scan_short.hip against the f64 oracle and against the long-row kernels (VMS_SCAN_IMPL=generic), every result of
+forward and backward, both directions, mixed directions per batch entry, the accumulate flags, fp32 / bf16 / fp16."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rel(a, ref):
+    a = a.detach().float().cpu().numpy().astype(np.float64)
+    ref = ref.detach().float().cpu().numpy() if torch.is_tensor(ref) else np.asarray(ref)
+    ref = ref.astype(np.float64).reshape(a.shape)
+    return np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-6)
+
+
+def _problem(b, d, L, itype, seed=0):
+    torch.manual_seed(seed)
+    N = 16
+    u = torch.randn(b, d, L, device=DEV).to(itype)
+    z = torch.randn(b, d, L, device=DEV).to(itype)
+    delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
+    A = -0.5 * torch.rand(d, N, device=DEV) - 0.1
+    B = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    C = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    dout = torch.randn(b, d, L, device=DEV).to(itype)
+    return u, delta, A, B, C, D, z, bias, dout
+
+
+NAMES = ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz")
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("has_z", [True, False])
+@pytest.mark.parametrize("b,d,L", [(64, 64, 8), (33, 128, 16), (70, 64, 13), (128, 64, 4), (512, 64, 1)])
+def test_short_rows_vs_oracle(oracle, b, d, L, itype, reverse, has_z):
+    import selective_scan_cuda
+    import vms_hip
+    u, delta, A, B, C, D, z, bias, dout = _problem(b, d, L, itype, seed=L)
+    zz = z if has_z else None
+    res = selective_scan_cuda.fwd(u, delta, A, B, C, D, zz, bias, True, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_fwd_short", vms_hip.last_kernel()
+    out, x = res[0], res[1]
+    assert x.shape == (b, d, 1, 32) and x.stride(2) == 32          # the reference's x, nothing behind it
+    f = lambda t: t.detach().float().cpu().numpy()
+    lf = (lambda t: t.flip(-1)) if reverse else (lambda t: t)
+    o = oracle.scan_fwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)) if has_z else None, f(bias), True, prec="f64")
+    tol = 1e-3 if itype == torch.float32 else 1e-2
+    assert _rel(lf(out), o["out"]) <= tol
+    if has_z:
+        assert _rel(lf(res[2]), o["out_z"]) <= tol
+    assert _rel(x, o["x"]) <= 1e-3
+    g = selective_scan_cuda.bwd(u, delta, A, B, C, D, zz, bias, dout, x, out if has_z else None, None, True, False, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_bwd_short", vms_hip.last_kernel()
+    ob = oracle.scan_bwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)) if has_z else None, f(bias), f(lf(dout)), True,
+                         prec="f64")
+    for name, got in zip(NAMES, g):
+        if name == "dz" and not has_z:
+            continue
+        want = ob[name]
+        gg = lf(got) if got.ndim >= 3 and got.shape[-1] == L else got
+        wide = 5 if name in ("dA", "dD", "ddelta_bias", "dB", "dC") else 2      # sums over the batch / the channels
+        assert _rel(gg, want) <= tol * wide, (name, _rel(gg, want))
+
+
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L", [8, 16, 5])
+def test_short_rows_equal_long_row_kernels(monkeypatch, itype, L):
+    """the same problem through the generic kernels (VMS_SCAN_IMPL=generic): two implementations of one arithmetic"""
+    import selective_scan_cuda
+    import vms_hip
+    b, d = 96, 64
+    u, delta, A, B, C, D, z, bias, dout = _problem(b, d, L, itype, seed=7)
+    res = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
+    assert vms_hip.last_kernel() == "scan_fwd_short"
+    g = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], res[0], None, True, True)
+    assert vms_hip.last_kernel() == "scan_bwd_short"
+    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    ref = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
+    assert vms_hip.last_kernel() == "scan_fwd_generic"
+    gr = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, ref[1], ref[0], None, True, True)
+    tol = 2e-5 if itype == torch.float32 else 1e-2
+    for name, a, r in zip(("out", "x", "out_z"), res, ref):
+        assert _rel(a, r) <= tol, (name, _rel(a, r))
+    for name, a, r in zip(NAMES + ("out_z",), g, gr):
+        assert _rel(a, r) <= tol * (10 if name in ("dA", "dD", "ddelta_bias", "dB", "dC") else 1), (name, _rel(a, r))
+
+
+def test_short_rows_mixed_directions_and_accumulate():
+    """reverse_from (the DBM block's stacked halves): entries >= reverse_from run right-to-left == two calls; out_z_into / dz_
+    accumulate == sums"""
+    import selective_scan_cuda
+    import vms_hip
+    b, d, L = 160, 64, 8
+    u, delta, A, B, C, D, z, bias, dout = _problem(b, d, L, torch.bfloat16, seed=3)
+    rf = 96
+    mixed = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse_from=rf)
+    assert vms_hip.last_kernel() == "scan_fwd_short"
+    lo = selective_scan_cuda.fwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, True)
+    hi = selective_scan_cuda.fwd(u[rf:], delta[rf:], A, B[rf:], C[rf:], D, z[rf:], bias, True, reverse=True)
+    for k in (0, 2):
+        assert torch.equal(mixed[k][:rf], lo[k]) and torch.equal(mixed[k][rf:], hi[k])
+    assert torch.equal(mixed[1][:rf], lo[1]) and torch.equal(mixed[1][rf:], hi[1])
+    gm = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, mixed[1], mixed[0], None, True, False, reverse_from=rf)
+    assert vms_hip.last_kernel() == "scan_bwd_short"
+    gl = selective_scan_cuda.bwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, dout[:rf], lo[1], lo[0], None, True, False)
+    gh = selective_scan_cuda.bwd(u[rf:], delta[rf:], A, B[rf:], C[rf:], D, z[rf:], bias, dout[rf:], hi[1], hi[0], None, True, False,
+                                 reverse=True)
+    for i, name in enumerate(NAMES):
+        if gm[i].shape[0] == b and gm[i].ndim >= 3:
+            assert _rel(gm[i][:rf], gl[i]) <= 1e-6 and _rel(gm[i][rf:], gh[i]) <= 1e-6, name
+        else:
+            assert _rel(gm[i], gl[i].float() + gh[i].float()) <= 2e-2, name
+    # second direction's gated output added to the first's
+    into = lo[2].clone()
+    selective_scan_cuda.fwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, True, reverse=True, out_z_into=into)
+    both = selective_scan_cuda.fwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, True, reverse=True)[2]
+    assert _rel(into, lo[2].float() + both.float()) <= 1e-2

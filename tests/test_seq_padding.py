@@ -46,7 +46,7 @@ def test_padding_fp32_equals_ragged(monkeypatch, batch, seqlen, d_model, variant
     monkeypatch.setattr(_core, "_SEQ_PAD", 0)
     o0, dh0, g0 = _run(mod, hidden, gout, False)
     monkeypatch.setattr(_core, "_SEQ_PAD", 16)
-    assert mod._seq_padding(hidden) == (-seqlen) % 16
+    assert mod._seq_padding(hidden) == ((-seqlen) % 8 if seqlen <= 16 else (-seqlen) % 16)
     o1, dh1, g1 = _run(mod, hidden, gout, False)
     assert o1.shape == o0.shape and dh1.shape == dh0.shape
     assert _rel(o1, o0) < 1e-4, ("out", _rel(o1, o0))

@@ -32,6 +32,10 @@ bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
 int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
 int launch_scan_bwd_complex(const vms_scan_bwd_params& q, bool vec, hipStream_t stream);   // selective_scan_complex.hip
+bool scan_bwd_short_eligible(const vms_scan_bwd_params& q);                                  // selective_scan_short.hip
+bool scan_short_takes(const vms_scan_fwd_params& p);
+int launch_scan_bwd_short(const vms_scan_bwd_params& q, hipStream_t stream);
+int64_t scan_bwd_short_ws_bytes(const vms_scan_bwd_params& q);
 
 constexpr int kBwdRows = 4;
 constexpr int kTilePad = 65;  // tile index = i * 65 + lane : conflict-free ds_add, 2-way flush
@@ -357,12 +361,14 @@ static void scan_bwd_sub_batches(const vms_scan_bwd_params& q, vms_scan_bwd_para
 extern "C" int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params* q) {
     if (q != nullptr && q->f.is_complex) return 0;
     if (q != nullptr && q->f.reverse_from > 0 && q->f.reverse_from < q->f.batch &&
-        !(scan_impl_level(q->f) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(*q, true) && scan_bwd_pair_native_mixed(*q))) {
+        !(scan_impl_level(q->f) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(*q, true) && scan_bwd_pair_native_mixed(*q) && !scan_short_takes(q->f))) {
         vms_scan_bwd_params lo, hi;
         scan_bwd_sub_batches(*q, lo, hi);
         const int64_t wl = vms_scan_bwd_workspace_bytes(&lo), wh = vms_scan_bwd_workspace_bytes(&hi);
         return wl + wh > 0 ? round256b(wl) + wh : 0;
     }
+    // the lane-per-row kernels: per-row dA / dD / ddelta_bias, summed by a second kernel instead of 1,568-way atomics
+    if (q != nullptr && scan_impl_level(q->f) >= VMS_IMPL_PAIR && q->f.x_has_sub == 0 && scan_bwd_short_eligible(*q)) return scan_bwd_short_ws_bytes(*q);
     if (q == nullptr || scan_impl_level(q->f) < VMS_IMPL_PAIR || !scan_bwd_pair_eligible(*q, true)) return 0;
     return scan_bwd_pair_segments(*q) > 1 ? scan_bwd_pair_ws_bytes(*q) : 0;
 }
@@ -375,7 +381,8 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     VMS_CHECK(q.dout && q.du && q.ddelta && q.dA && q.dB && q.dC, "dout, du, ddelta, dA, dB, dC are required");
     if (p.reverse_from != 0) {
         VMS_CHECK(p.reverse_from > 0 && p.reverse_from <= p.batch && p.reverse == 0, "reverse_from must be in (0, batch] with reverse == 0");
-        const bool native = p.is_complex || (scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q));
+        const bool native = p.is_complex || (scan_impl_level(p) >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, true) && scan_bwd_pair_native_mixed(q) &&
+                                             !scan_short_takes(p));
         if (p.reverse_from < p.batch && !native) {
             vms_scan_bwd_params lo, hi;
             scan_bwd_sub_batches(q, lo, hi);
@@ -404,6 +411,8 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
     if (p.is_complex) return launch_scan_bwd_complex(q, vec, s);
     const int level = scan_impl_level(p);
+    // short rows (selective_scan_short.hip): the states are rebuilt from h = 0 in the lane, x is not read
+    if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_bwd_short_eligible(q)) return launch_scan_bwd_short(q, s);
     if (level >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
 #ifdef VMS_EXPERIMENTAL
     if (level >= VMS_IMPL_FAST && !p.reverse && scan_bwd_mfma_eligible(q, vec)) {

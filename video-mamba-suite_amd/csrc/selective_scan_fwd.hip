@@ -205,6 +205,9 @@ int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p);
 int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
 
 int launch_scan_fwd_complex(const vms_scan_fwd_params& p, bool vec, hipStream_t stream);   // selective_scan_complex.hip
+bool scan_short_eligible(const vms_scan_fwd_params& p);                                      // selective_scan_short.hip
+bool scan_short_takes(const vms_scan_fwd_params& p);
+int launch_scan_fwd_short(const vms_scan_fwd_params& p, hipStream_t stream);
 
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
     const int es = p.dtype == VMS_F32 ? 4 : 2;
@@ -274,7 +277,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
             // one launch when the paired LDS kernel takes the problem as it is; otherwise the two sub-batches as two problems
             // (the complex kernels take the direction per batch entry as it is)
             const bool native = p.is_complex || (scan_impl_level(p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, scan_fwd_vec_ok(p)) &&
-                                                 scan_fwd_pair_native_mixed(p));
+                                                 scan_fwd_pair_native_mixed(p) && !scan_short_takes(p));
             if (!native) return scan_fwd_mixed(p, stream);
         }
     }
@@ -299,6 +302,8 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 #else
     VMS_CHECK(p.x_has_sub != 2, "x_has_sub == 2 (rows layout) needs a library built with EXPERIMENTAL=1");
 #endif
+    // short rows, many of them (TimeMamba's scans along time: seqlen 4 ... 16, batch x 196 rows per channel): a lane per row
+    if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_short_eligible(p)) return launch_scan_fwd_short(p, s);
     if (level >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, vec)) return launch_scan_fwd_pair(p, s);
 #ifdef VMS_EXPERIMENTAL
     if (level >= VMS_IMPL_FAST && scan_fwd_fast_eligible(p, vec)) {
@@ -317,7 +322,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
 extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
     if (p == nullptr || p->is_complex) return 0;
     if (p->reverse_from > 0 && p->reverse_from < p->batch) {
-        if (scan_impl_level(*p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_native_mixed(*p)) return 0;
+        if (scan_impl_level(*p) >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_native_mixed(*p) && !scan_short_takes(*p)) return 0;
         vms_scan_fwd_params lo, hi;
         scan_fwd_sub_batches(*p, lo, hi);
         const int64_t wl = vms_scan_fwd_workspace_bytes(&lo), wh = vms_scan_fwd_workspace_bytes(&hi);
@@ -337,6 +342,9 @@ extern "C" int64_t vms_scan_x_pitch(const vms_scan_fwd_params* pp, int32_t mode)
     const vms_scan_fwd_params& p = *pp;
     if (p.is_complex) return (mode == 0 ? 2 : 6) * (int64_t)p.dstate;   // complex elements (vms_hip.h is_complex)
     if (mode == 0) return 2 * (int64_t)p.dstate;
+    // the lane-per-row kernels of short sequences keep no checkpoints: the reference's x and nothing behind it (the 8-element
+    // layout costs 16.5 KB per row whatever its length: 20 GB per scan at (1568, 8, 768))
+    if (vms::scan_short_takes(p)) return 2 * (int64_t)p.dstate;
     if ((mode == 3 || mode == -1) && vms::scan_bwd_pair_lane_ckpt_ok(p)) return 258 * (int64_t)p.dstate;
     return 18 * (int64_t)p.dstate;
 }

@@ -1,0 +1,412 @@
+// selective_scan_short.hip -- forward and backward selective scan for SHORT sequences and many rows: one LANE per (batch, dim) row.
+//
+// The suite's TimeMamba blocks (egocentric-understanding/avion/models/timemamba.py:135-140, attention style "frozen-in-time") run
+// the mixer along TIME: x is rearranged 'b (n t) d -> (b n) t d', i.e. sequences of t = 4 ... 16 frames and a batch of b x 196
+// spatial tokens -- (1568, 8, 768) for 8 clips of 8 frames.  The kernels built for long rows (selective_scan_fwd_pair.hip: a wave
+// per row, a lane owns 16 consecutive elements; selective_scan_bwd_pair.hip: 16 lanes x 8 elements per row) keep 1 lane of 16 ... 64
+// busy there: a ViM block step at (1568, 8, 768) took 13.6 ms, 11.5 of them in the two scans, and the 8-element checkpoint layout
+// behind x cost 16.5 KB per row (20 GB per scan at this shape) whatever the length.  The reference serves such rows with one
+// 32-thread block each (selective_scan_fwd_kernel.cuh:310-333: kNThreads = 32, kNItems = 4 up to 128 elements).
+//
+// Here a row is ONE lane's sequential loop: no cross-lane scan, no LDS, no checkpoints -- the backward rebuilds a row's states from
+// h = 0.  Lanes run over consecutive channels d of one batch entry, so B / C (shared by the channels of a group) are wave-uniform
+// loads and dA / dD / ddelta_bias meet no address conflicts inside a wave; dB / dC -- sums over the channels -- are reduced over the
+// wave with DPP and leave as one atomic per (wave, state, position).  seqlen <= 16, dstate 16, variable B / C, real A.
+// x keeps the reference's shape and nothing behind it (vms_scan_x_pitch = 2 * dstate for these problems): the running state at the
+// row's end in both slots of its one chunk (selective_scan_fwd_kernel.cuh:255-258).
+#include "vms_common.h"
+
+namespace vms {
+
+constexpr int kSN = 16;        // dstate
+constexpr int kSMaxL = 16;     // longest row served
+
+bool scan_short_eligible(const vms_scan_fwd_params& p) {
+    if (p.is_complex || !p.is_variable_B || !p.is_variable_C || p.dstate != kSN || p.seqlen < 1 || p.seqlen > kSMaxL) return false;
+    if (p.n_chunks != 1 || p.n_groups < 1 || p.dim % p.n_groups != 0 || p.x_has_sub == 2) return false;
+    if (p.reverse_from > 0 && p.reverse_from < p.batch) return false;   // (the entry points split mixed directions into two problems)
+    // the backward's wave sums of dB / dC need whole waves inside one (batch entry, group); forward and backward go together
+    // (x carries no checkpoints for the long-row backward kernels)
+    if ((p.dim / p.n_groups) % 64 != 0) return false;
+    // below a few thousand rows the long-row kernels' launch is as good; the lane-per-row form needs rows to fill waves
+    return (int64_t)p.batch * p.dim >= 4096;
+}
+// the same for a problem with a direction per batch entry (reverse_from): both sub-batches
+bool scan_short_takes(const vms_scan_fwd_params& p) {
+    if (p.reverse_from > 0 && p.reverse_from < p.batch) {
+        vms_scan_fwd_params lo = p, hi = p;
+        lo.batch = p.reverse_from; lo.reverse_from = 0;
+        hi.batch = p.batch - p.reverse_from; hi.reverse_from = 0;
+        return scan_impl_level(p) >= VMS_IMPL_PAIR && scan_short_eligible(lo) && scan_short_eligible(hi);
+    }
+    return scan_impl_level(p) >= VMS_IMPL_PAIR && scan_short_eligible(p);
+}
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p, int64_t i) { return static_cast<float>(p[i]); }
+
+// A row's L (<= LP) elements in LOGICAL order (REV: logical i = physical L - 1 - i), zeros behind them and for !ok.
+// VEC (seqlen % 8 == 0, 16-byte aligned rows): whole 16-byte vectors -- element by element a row cost 16 two-byte loads per tensor,
+// every one touching 64 different lines per wave ((1568, 16, 768): 1.27 ms per forward call instead of 0.2).
+template <typename T, int LP, bool REV, bool VEC>
+__device__ __forceinline__ void load_row(const T* __restrict__ row, int L, bool ok, float (&v)[LP]) {
+    if constexpr (VEC) {
+        constexpr int EPV = 16 / sizeof(T);
+#pragma unroll
+        for (int k = 0; k < LP / EPV; ++k) {
+            if (ok && k * EPV < L) {
+                const vec_t<T, EPV> t = *reinterpret_cast<const vec_t<T, EPV>*>(row + (REV ? L - (k + 1) * EPV : k * EPV));
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v[k * EPV + e] = static_cast<float>(t[REV ? EPV - 1 - e : e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v[k * EPV + e] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LP; ++i) v[i] = ok && i < L ? static_cast<float>(row[REV ? L - 1 - i : i]) : 0.f;
+    }
+}
+template <typename T, int LP, bool REV, bool VEC>
+__device__ __forceinline__ void store_row(T* __restrict__ row, int L, const float (&v)[LP]) {
+    if constexpr (VEC) {
+        constexpr int EPV = 16 / sizeof(T);
+#pragma unroll
+        for (int k = 0; k < LP / EPV; ++k) {
+            if (k * EPV < L) {
+                vec_t<T, EPV> t;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) t[REV ? EPV - 1 - e : e] = static_cast<T>(v[k * EPV + e]);
+                *reinterpret_cast<vec_t<T, EPV>*>(row + (REV ? L - (k + 1) * EPV : k * EPV)) = t;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < LP; ++i)
+            if (i < L) row[REV ? L - 1 - i : i] = static_cast<T>(v[i]);
+    }
+}
+
+// the wave's sum of v in lane 63 (4 in-row DPP steps + 2 row broadcasts)
+__device__ __forceinline__ float wave_sum_to_last(float v) {
+    v += dpp_mov<DPP_ROW_SHR1, 0xf>(0.f, v);
+    v += dpp_mov<DPP_ROW_SHR2, 0xf>(0.f, v);
+    v += dpp_mov<DPP_ROW_SHR4, 0xf>(0.f, v);
+    v += dpp_mov<DPP_ROW_SHR8, 0xf>(0.f, v);
+    v += dpp_mov<DPP_ROW_BCAST15, 0xa>(0.f, v);
+    v += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.f, v);
+    return v;
+}
+
+// LP: the register arrays' length (8 or 16) >= seqlen.  Logical element i of a right-to-left row is physical element L - 1 - i.
+template <typename T, bool HZ, bool REV, int LP, bool VEC>
+__global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_params p) {
+    constexpr int N = kSN;
+    // a wave = 64 consecutive channels of ONE batch entry and ONE group (dim / n_groups is a multiple of 64): uniform B / C addresses;
+    // the workgroup's 4 waves = the same channels of 4 CONSECUTIVE batch entries: in the blocks' channel-slowest layout those rows
+    // are neighbours in memory (4 x 32 bytes = one line), so the line a wave touches is the line its three neighbours touch
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dblocks = p.dim / 64;
+    const int d = ((int)blockIdx.x % dblocks) * 64 + lane;
+    const int bq = __builtin_amdgcn_readfirstlane(((int)blockIdx.x / dblocks) * 4 + wave);
+    const bool row_ok = bq < p.batch;
+    const int b = row_ok ? bq : p.batch - 1;
+    const int g = __builtin_amdgcn_readfirstlane(d / (p.dim / p.n_groups));
+    const int L = p.seqlen;
+    const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
+    const T* dt = static_cast<const T*>(p.delta) + (int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride;
+    T* out = static_cast<T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride;
+    const T* Bp = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* Cp = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    const float* Af = static_cast<const float*>(p.A) + (int64_t)d * p.A_d_stride;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+    float dl[LP], du[LP], y[LP];
+    load_row<T, LP, REV, VEC>(dt, L, row_ok, dl);
+    load_row<T, LP, REV, VEC>(u, L, row_ok, du);
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        float t = dl[i] + bias;
+        if (p.delta_softplus) t = softplusf_(t);
+        t = i < L && row_ok ? t : 0.f;    // past the end: a = 1, b = 0
+        const float uv = du[i];
+        dl[i] = t;
+        du[i] = t * uv;
+        y[i] = Dd * uv;
+    }
+    // (the state loop is NOT unrolled: unrolled, the 16 states' B / C loads were all hoisted to the top -- 306 registers at 16 elements)
+    const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
+    float* xr = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * xpitch;
+    const bool x16 = (xpitch & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
+#pragma unroll 1
+    for (int n0 = 0; n0 < N; n0 += 2) {
+        float hq[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int n = n0 + k;
+            const float An = Af[(int64_t)n * p.A_dstate_stride] * kLog2e;
+            float Bv[LP], Cv[LP];
+            load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
+            load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+            float h = 0.f;
+#pragma unroll
+            for (int i = 0; i < LP; ++i) {
+                h = fmaf(fast_exp2(dl[i] * An), h, du[i] * Bv[i]);
+                y[i] = fmaf(Cv[i], h, y[i]);
+            }
+            hq[k] = h;
+        }
+        if (row_ok) {   // the state at the row's end in both slots of the one chunk; 16 bytes per two states (4-byte stores of 64
+                        // lanes 128 bytes apart cost the forward more than its arithmetic)
+            if (x16) *reinterpret_cast<float4*>(xr + 2 * n0) = float4{hq[0], hq[0], hq[1], hq[1]};
+            else { xr[2 * n0] = hq[0]; xr[2 * n0 + 1] = hq[0]; xr[2 * n0 + 2] = hq[1]; xr[2 * n0 + 3] = hq[1]; }
+        }
+    }
+    if (!row_ok) return;
+    store_row<T, LP, REV, VEC>(out, L, y);
+    if (HZ) {
+        const T* z = static_cast<const T*>(p.z) + (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride;
+        T* oz = static_cast<T*>(p.out_z) + (int64_t)b * p.out_z_batch_stride + (int64_t)d * p.out_z_d_stride;
+        float zv[LP], old[LP];
+        load_row<T, LP, REV, VEC>(z, L, true, zv);
+        if (p.out_z_accumulate) load_row<T, LP, REV, VEC>(oz, L, true, old);
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            y[i] = y[i] * zv[i] * sigmoidf_(zv[i]);
+            if (p.out_z_accumulate) y[i] += old[i];
+        }
+        store_row<T, LP, REV, VEC>(oz, L, y);
+    }
+}
+
+// Backward.  A workgroup = blockDim consecutive channels of ONE batch entry (blockDim divides the channels of a group).
+// dB / dC -- sums over the channels -- are reduced over the wave with DPP, over the workgroup's waves through LDS, and leave as ONE
+// atomic instruction of 2 L lanes per (workgroup, state).  dA / dD / ddelta_bias -- sums over the batch -- go to the workspace as
+// ws[batch entry][18][channel] (coalesced stores, no atomics) and are summed by short_reduce_kernel: as atomics straight from the
+// rows, 1,568 of them onto each of 12 K addresses, they were 1.1 of the kernel's 2.0 ms at (1568, 16, 768).  No workspace: atomics.
+template <typename T, bool HZ, bool REV, int LP, bool VEC>
+__global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_params q, float* __restrict__ ws) {
+    const vms_scan_fwd_params& p = q.f;
+    constexpr int N = kSN;
+    __shared__ float red[4][2 * LP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    const int wg_per_b = p.dim / (int)blockDim.x;
+    const int d = ((int)blockIdx.x % wg_per_b) * (int)blockDim.x + (int)threadIdx.x;
+    const int b = (int)blockIdx.x / wg_per_b;                          // (workgroup-uniform)
+    const int g = __builtin_amdgcn_readfirstlane(d / (p.dim / p.n_groups));
+    const int L = p.seqlen;
+    const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
+    const T* dt = static_cast<const T*>(p.delta) + (int64_t)b * p.delta_batch_stride + (int64_t)d * p.delta_d_stride;
+    const T* dout = static_cast<const T*>(q.dout) + (int64_t)b * q.dout_batch_stride + (int64_t)d * q.dout_d_stride;
+    const T* Bp = static_cast<const T*>(p.B) + (int64_t)b * p.B_batch_stride + (int64_t)g * p.B_group_stride;
+    const T* Cp = static_cast<const T*>(p.C) + (int64_t)b * p.C_batch_stride + (int64_t)g * p.C_group_stride;
+    float* dBp = q.dB + (int64_t)b * q.dB_batch_stride + (int64_t)g * q.dB_group_stride;
+    float* dCp = q.dC + (int64_t)b * q.dC_batch_stride + (int64_t)g * q.dC_group_stride;
+    const float* Af = static_cast<const float*>(p.A) + (int64_t)d * p.A_d_stride;
+    const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
+    const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
+    float* wsr = ws ? ws + (int64_t)b * 18 * p.dim + d : nullptr;
+    float dl[LP], uv[LP], dy[LP], sg[LP], dua[LP], dda[LP];
+    float dD = 0.f;
+    load_row<T, LP, REV, VEC>(dt, L, true, dl);
+    load_row<T, LP, REV, VEC>(u, L, true, uv);
+    load_row<T, LP, REV, VEC>(dout, L, true, dy);
+    if (HZ) {
+        const T* z = static_cast<const T*>(p.z) + (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride;
+        const T* o_ = static_cast<const T*>(p.out) + (int64_t)b * p.out_batch_stride + (int64_t)d * p.out_d_stride;
+        T* dz = static_cast<T*>(q.dz) + (int64_t)b * q.dz_batch_stride + (int64_t)d * q.dz_d_stride;
+        float zv[LP], ov[LP], dzv[LP];
+        load_row<T, LP, REV, VEC>(z, L, true, zv);
+        load_row<T, LP, REV, VEC>(o_, L, true, ov);
+        if (q.dz_accumulate) load_row<T, LP, REV, VEC>(dz, L, true, dzv);
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            const float sz = sigmoidf_(zv[i]), silu = zv[i] * sz;
+            const float t = dy[i] * ov[i] * sz * (1.f + zv[i] * (1.f - sz));
+            dzv[i] = q.dz_accumulate ? dzv[i] + t : t;
+            ov[i] *= silu;          // the gated output, should the caller want it recomputed
+            dy[i] *= silu;
+        }
+        store_row<T, LP, REV, VEC>(dz, L, dzv);
+        if (p.out_z) store_row<T, LP, REV, VEC>(static_cast<T*>(p.out_z) + (int64_t)b * p.out_z_batch_stride + (int64_t)d * p.out_z_d_stride, L, ov);
+    }
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        float t = dl[i] + bias, s = 1.f;
+        if (p.delta_softplus) {
+            const float ex = fast_exp(t), w = 1.f + ex, rw = fast_rcp(w);
+            const float sp = fmaf(ex - (w - 1.f), rw, fast_log(w));
+            s = t <= 20.f ? ex * rw : 1.f;
+            t = t <= 20.f ? sp : t;
+        }
+        dl[i] = i < L ? t : 0.f;
+        sg[i] = s;
+        dua[i] = Dd * dy[i];
+        dda[i] = 0.f;
+        dD = fmaf(dy[i], uv[i], dD);
+    }
+#pragma unroll 1
+    for (int n = 0; n < N; ++n) {
+        const float Araw = Af[(int64_t)n * p.A_dstate_stride], An = Araw * kLog2e;
+        float a[LP], x[LP], Bv[LP], Cv[LP];
+        load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
+        load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+        float h = 0.f;
+#pragma unroll
+        for (int i = 0; i < LP; ++i) {
+            a[i] = fast_exp2(dl[i] * An);
+            h = fmaf(a[i], h, dl[i] * uv[i] * Bv[i]);
+            x[i] = h;
+        }
+        float gr = 0.f, dA = 0.f;
+#pragma unroll
+        for (int i = LP - 1; i >= 0; --i) {
+            gr = fmaf(i == LP - 1 ? 0.f : a[i + 1], gr, Cv[i] * dy[i]);       // g_i = a_{i+1} g_{i+1} + C_i dy_i
+            const float ax = a[i] * (i == 0 ? 0.f : x[i - 1]);               // a_i x_{i-1}
+            dua[i] = fmaf(gr * dl[i], Bv[i], dua[i]);
+            dda[i] = fmaf(gr, fmaf(Araw, ax, uv[i] * Bv[i]), dda[i]);
+            dA = fmaf(gr * dl[i], ax, dA);
+            const float sb = wave_sum_to_last(gr * dl[i] * uv[i]);
+            const float sc = wave_sum_to_last(dy[i] * x[i]);
+            if (lane == 63) {
+                red[wave][i] = sb;
+                red[wave][LP + i] = sc;
+            }
+        }
+        if (wsr) wsr[(int64_t)n * p.dim] = dA;
+        else atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)n * q.dA_dstate_stride, dA);
+        __syncthreads();
+        if (threadIdx.x < 2 * LP) {                     // position i of dB (threads 0 .. LP-1) or dC (LP .. 2 LP-1)
+            float v = red[0][threadIdx.x];
+            for (int w = 1; w < n_waves; ++w) v += red[w][threadIdx.x];
+            const int i = (int)threadIdx.x & (LP - 1);
+            float* dst = threadIdx.x < LP ? dBp + (int64_t)n * q.dB_dstate_stride : dCp + (int64_t)n * q.dC_dstate_stride;
+            if (i < L) atomicAdd(dst + (REV ? L - 1 - i : i), v);
+        }
+        __syncthreads();
+    }
+    float dbias = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+        dda[i] = i < L ? dda[i] * sg[i] : 0.f;
+        dbias += dda[i];
+    }
+    store_row<T, LP, REV, VEC>(static_cast<T*>(q.du) + (int64_t)b * q.du_batch_stride + (int64_t)d * q.du_d_stride, L, dua);
+    store_row<T, LP, REV, VEC>(static_cast<T*>(q.ddelta) + (int64_t)b * q.ddelta_batch_stride + (int64_t)d * q.ddelta_d_stride, L, dda);
+    if (wsr) {
+        wsr[(int64_t)16 * p.dim] = dD;
+        wsr[(int64_t)17 * p.dim] = dbias;
+    } else {
+        if (q.dD) atomicAdd(q.dD + d, dD);
+        if (q.ddelta_bias) atomicAdd(q.ddelta_bias + d, dbias);
+    }
+}
+
+// dA / dD / ddelta_bias += the sum over the batch of ws[batch][18][dim]: a thread sums kRB batch entries of one (slot, channel)
+constexpr int kRB = 32;
+__global__ __launch_bounds__(256) void short_reduce_kernel(const float* __restrict__ ws, const vms_scan_bwd_params q) {
+    const vms_scan_fwd_params& p = q.f;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per_chunk = (int64_t)18 * p.dim;
+    const int chunk = (int)(t / per_chunk);
+    const int64_t idx = t - chunk * per_chunk;            // slot * dim + d
+    const int b0 = chunk * kRB, b1 = b0 + kRB < p.batch ? b0 + kRB : p.batch;
+    if (b0 >= p.batch) return;
+    float v = 0.f;
+    for (int b = b0; b < b1; ++b) v += ws[(int64_t)b * per_chunk + idx];
+    const int slot = (int)(idx / p.dim), d = (int)(idx - (int64_t)slot * p.dim);
+    if (slot < 16) atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)slot * q.dA_dstate_stride, v);
+    else if (slot == 16) { if (q.dD) atomicAdd(q.dD + d, v); }
+    else if (q.ddelta_bias) atomicAdd(q.ddelta_bias + d, v);
+}
+int64_t scan_bwd_short_ws_bytes(const vms_scan_bwd_params& q) { return (int64_t)q.f.batch * 18 * q.f.dim * 4; }
+
+// whole 16-byte vectors per row: seqlen a multiple of 8, every row 16-byte aligned
+static bool rows16(const void* ptr, int64_t bs, int64_t ds, int es) {
+    return ptr == nullptr || ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && (bs * es) % 16 == 0 && (ds * es) % 16 == 0);
+}
+static bool short_vec_fwd(const vms_scan_fwd_params& p) {
+    const int es = p.dtype == VMS_F32 ? 4 : 2;
+    return p.seqlen % 8 == 0 && rows16(p.u, p.u_batch_stride, p.u_d_stride, es) && rows16(p.delta, p.delta_batch_stride, p.delta_d_stride, es) &&
+           rows16(p.out, p.out_batch_stride, p.out_d_stride, es) && rows16(p.z, p.z_batch_stride, p.z_d_stride, es) &&
+           rows16(p.out_z, p.out_z_batch_stride, p.out_z_d_stride, es) && rows16(p.B, p.B_batch_stride, p.B_group_stride, es) &&
+           rows16(p.C, p.C_batch_stride, p.C_group_stride, es) && (p.B_dstate_stride * es) % 16 == 0 && (p.C_dstate_stride * es) % 16 == 0;
+}
+static bool short_vec_bwd(const vms_scan_bwd_params& q) {
+    const int es = q.f.dtype == VMS_F32 ? 4 : 2;
+    return short_vec_fwd(q.f) && rows16(q.dout, q.dout_batch_stride, q.dout_d_stride, es) && rows16(q.du, q.du_batch_stride, q.du_d_stride, es) &&
+           rows16(q.ddelta, q.ddelta_batch_stride, q.ddelta_d_stride, es) && rows16(q.dz, q.dz_batch_stride, q.dz_d_stride, es);
+}
+
+template <typename T>
+static int launch_fwd_short_t(const vms_scan_fwd_params& p, hipStream_t stream) {
+    const dim3 grid((unsigned)((p.dim / 64) * ((p.batch + 3) / 4))), block(256);
+    const bool vec = short_vec_fwd(p);
+#define VMS_S(Z_, R_)                                                                                                    \
+    do {                                                                                                                \
+        if (p.seqlen <= 8) {                                                                                            \
+            if (vec) hipLaunchKernelGGL((scan_fwd_short_kernel<T, Z_, R_, 8, true>), grid, block, 0, stream, p);         \
+            else hipLaunchKernelGGL((scan_fwd_short_kernel<T, Z_, R_, 8, false>), grid, block, 0, stream, p);            \
+        } else {                                                                                                        \
+            if (vec) hipLaunchKernelGGL((scan_fwd_short_kernel<T, Z_, R_, 16, true>), grid, block, 0, stream, p);        \
+            else hipLaunchKernelGGL((scan_fwd_short_kernel<T, Z_, R_, 16, false>), grid, block, 0, stream, p);           \
+        }                                                                                                               \
+    } while (0)
+    if (p.z) { if (p.reverse) VMS_S(true, true); else VMS_S(true, false); }
+    else { if (p.reverse) VMS_S(false, true); else VMS_S(false, false); }
+#undef VMS_S
+    VMS_LAUNCH_CHECK();
+    set_last_kernel("scan_fwd_short");
+    return VMS_OK;
+}
+int launch_scan_fwd_short(const vms_scan_fwd_params& p, hipStream_t stream) {
+    switch (p.dtype) {
+        case VMS_F32: return launch_fwd_short_t<float>(p, stream);
+        case VMS_F16: return launch_fwd_short_t<f16_t>(p, stream);
+        default: return launch_fwd_short_t<bf16_t>(p, stream);
+    }
+}
+
+bool scan_bwd_short_eligible(const vms_scan_bwd_params& q) { return scan_short_eligible(q.f); }
+
+template <typename T>
+static int launch_bwd_short_t(const vms_scan_bwd_params& q, hipStream_t stream) {
+    const vms_scan_fwd_params& p = q.f;
+    // a workgroup = blockDim consecutive channels of one group of kSNB batch entries; blockDim divides the channels of a group
+    const int cpg = p.dim / p.n_groups;
+    const int bd = cpg % 256 == 0 ? 256 : cpg % 128 == 0 ? 128 : 64;
+    const dim3 grid((unsigned)((p.dim / bd) * p.batch)), block(bd);
+    const bool vec = short_vec_bwd(q);
+    float* ws = p.workspace != nullptr && p.workspace_bytes >= scan_bwd_short_ws_bytes(q) && (reinterpret_cast<uintptr_t>(p.workspace) & 3) == 0
+                    ? static_cast<float*>(p.workspace) : nullptr;
+#define VMS_S(Z_, R_)                                                                                                    \
+    do {                                                                                                                \
+        if (p.seqlen <= 8) {                                                                                            \
+            if (vec) hipLaunchKernelGGL((scan_bwd_short_kernel<T, Z_, R_, 8, true>), grid, block, 0, stream, q, ws);         \
+            else hipLaunchKernelGGL((scan_bwd_short_kernel<T, Z_, R_, 8, false>), grid, block, 0, stream, q, ws);            \
+        } else {                                                                                                        \
+            if (vec) hipLaunchKernelGGL((scan_bwd_short_kernel<T, Z_, R_, 16, true>), grid, block, 0, stream, q, ws);        \
+            else hipLaunchKernelGGL((scan_bwd_short_kernel<T, Z_, R_, 16, false>), grid, block, 0, stream, q, ws);           \
+        }                                                                                                               \
+    } while (0)
+    if (p.z) { if (p.reverse) VMS_S(true, true); else VMS_S(true, false); }
+    else { if (p.reverse) VMS_S(false, true); else VMS_S(false, false); }
+#undef VMS_S
+    if (ws) {
+        const int64_t threads = (int64_t)((p.batch + kRB - 1) / kRB) * 18 * p.dim;
+        hipLaunchKernelGGL(short_reduce_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, ws, q);
+    }
+    VMS_LAUNCH_CHECK();
+    set_last_kernel("scan_bwd_short");
+    return VMS_OK;
+}
+int launch_scan_bwd_short(const vms_scan_bwd_params& q, hipStream_t stream) {
+    switch (q.f.dtype) {
+        case VMS_F32: return launch_bwd_short_t<float>(q, stream);
+        case VMS_F16: return launch_bwd_short_t<f16_t>(q, stream);
+        default: return launch_bwd_short_t<bf16_t>(q, stream);
+    }
+}
+
+}  // namespace vms

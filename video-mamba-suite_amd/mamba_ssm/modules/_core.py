@@ -356,11 +356,16 @@ class MambaCore(nn.Module):
         """positions to append so that the block's kernels see whole 16-element vectors (0: none, or not applicable: CPU tensors,
         fp32 activations -- the whole-vector kernels are 16-bit ones --, an in_proj bias, which would make the padding's xz nonzero)"""
         seqlen = hidden_states.shape[1]
-        if not _SEQ_PAD or seqlen % _SEQ_PAD == 0 or not hidden_states.is_cuda or self.in_proj.bias is not None:
+        # sequences of a few frames (TimeMamba's scans along time) run on the lane-per-row scan kernels, which take any length up to
+        # 16: only the 16-byte vectors of the conv / projection kernels ask for a multiple of 8 there (8 frames stay 8, 4 become 8)
+        unit = 8 if _SEQ_PAD and seqlen <= 16 else _SEQ_PAD
+        if not unit or seqlen % unit == 0 or not hidden_states.is_cuda or self.in_proj.bias is not None:
             return 0
         low = (torch.bfloat16, torch.float16)
         if not (_SEQ_PAD_FP32 or hidden_states.dtype in low or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in low)):
             return 0
+        if unit == 8:
+            return 8 - seqlen % 8
         return _padded_len(hidden_states.shape[0], seqlen) - seqlen
 
     def _forward_dbm(self, hidden_states, inference_params):
