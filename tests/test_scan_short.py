@@ -121,3 +121,31 @@ def test_short_rows_mixed_directions_and_accumulate():
     selective_scan_cuda.fwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, True, reverse=True, out_z_into=into)
     both = selective_scan_cuda.fwd(u[:rf], delta[:rf], A, B[:rf], C[:rf], D, z[:rf], bias, True, reverse=True)[2]
     assert _rel(into, lo[2].float() + both.float()) <= 1e-2
+
+
+@pytest.mark.parametrize("seqlen", [8, 4, 16])
+def test_short_sequence_block_matches_fp32(seqlen):
+    """the ViM mixer on a TimeMamba shape -- (b x n, t, d) = many rows, a few frames -- under bf16 autocast: the lane-per-row scans,
+    x_dbl stored row-major over (batch, position), the folded small projections; outputs and every gradient against the fp32 run
+    (long-row / generic kernels, library GEMMs)"""
+    import vms_hip
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    d_model, batch = 64, 96                      # d_inner 128: 12,288 rows
+    mod = Mamba(d_model, d_state=16, d_conv=4, expand=2, bimamba_type="v2").cuda()
+    hidden = torch.randn(batch, seqlen, d_model, device=DEV)
+    gout = torch.randn(batch, seqlen, d_model, device=DEV)
+
+    def run(autocast):
+        mod.zero_grad(set_to_none=True)
+        h = hidden.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = mod(h)
+        out.float().backward(gout)
+        return out.detach().float(), h.grad.float(), {n: p.grad.float().clone() for n, p in mod.named_parameters()}
+    ref = run(False)
+    got = run(True)
+    assert vms_hip.last_kernel() != "", vms_hip.last_kernel()
+    assert _rel(got[0], ref[0]) < 2e-2 and _rel(got[1], ref[1]) < 3e-2
+    for n in ref[2]:
+        assert _rel(got[2][n], ref[2][n]) < 4e-2, (n, _rel(got[2][n], ref[2][n]))

@@ -1318,8 +1318,20 @@ static int dispatch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stre
 
 using namespace vms;
 
+// Batch entries that follow each other without a gap in both operands (batch stride == seqlen: the blocks' channel-slowest
+// tensors, x_dbl stored row-major over (batch, position)) are ONE problem of batch x seqlen positions: these products know no
+// sequence boundary.  What it buys is short sequences -- TimeMamba's (1568, 8, 768): tiles of 64 positions of one batch entry are an
+// eighth full there (vms_proj_wgrad 200 -> 20 us).
 extern "C" int vms_proj_apply(const vms_proj_apply_params* pp, void* stream) {
     VMS_CHECK(pp != nullptr, "null parameter block");
+    vms_proj_apply_params folded;
+    if (pp->batch > 1 && pp->seqlen > 0 && pp->seqlen < 64 && pp->in_batch_stride == pp->seqlen && pp->out_batch_stride == pp->seqlen &&
+        (int64_t)pp->batch * pp->seqlen < ((int64_t)1 << 30)) {
+        folded = *pp;
+        folded.seqlen = pp->batch * pp->seqlen;
+        folded.batch = 1;
+        pp = &folded;
+    }
     const vms_proj_apply_params& p = *pp;
     VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_apply: 16-bit activations only (bf16 / fp16)");
     VMS_CHECK(p.batch > 0 && p.rows > 0 && p.seqlen > 0, "empty problem");
@@ -1337,6 +1349,14 @@ extern "C" int vms_proj_apply(const vms_proj_apply_params* pp, void* stream) {
 
 extern "C" int vms_proj_wgrad(const vms_proj_wgrad_params* pp, void* stream) {
     VMS_CHECK(pp != nullptr, "null parameter block");
+    vms_proj_wgrad_params folded;      // (see vms_proj_apply)
+    if (pp->batch > 1 && pp->seqlen > 0 && pp->seqlen < 64 && pp->p_batch_stride == pp->seqlen && pp->q_batch_stride == pp->seqlen &&
+        (int64_t)pp->batch * pp->seqlen < ((int64_t)1 << 30)) {
+        folded = *pp;
+        folded.seqlen = pp->batch * pp->seqlen;
+        folded.batch = 1;
+        pp = &folded;
+    }
     const vms_proj_wgrad_params& p = *pp;
     VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_wgrad: 16-bit activations only (bf16 / fp16)");
     VMS_CHECK(p.batch > 0 && p.n > 0 && p.seqlen > 0, "empty problem");

@@ -445,7 +445,11 @@ std::vector<Tensor> conv_xproj_dual(const Tensor& x, const Tensor& weight, const
     if (((d - 1) * x.stride(1) + L) * 2 >= ((int64_t)1 << 31) || d * L * 2 >= ((int64_t)1 << 31)) return {};
     c10::DeviceGuard guard(x.device());
     Tensor out = at::empty(x.sizes(), x.options()), out_b = at::empty(x.sizes(), x.options());
-    Tensor xa = at::empty({b, m, L}, x.options()), xb = at::empty({b, m, L}, x.options());
+    // short sequences with many rows (the lane-per-row scans' shapes) and a channel-slowest x: x_dbl row-major over (batch, position)
+    // too, so that the products over it see batch x seqlen positions as one run (vms_proj_apply / vms_proj_wgrad fold such operands)
+    const bool kmajor = L <= 16 && b * d >= 4096 && b > 1 && x.stride(0) == L;
+    Tensor xa = kmajor ? at::empty({m, b, L}, x.options()).permute({1, 0, 2}) : at::empty({b, m, L}, x.options());
+    Tensor xb = kmajor ? at::empty({m, b, L}, x.options()).permute({1, 0, 2}) : at::empty({b, m, L}, x.options());
     vms_conv_xproj_dual_params Q{};
     fill_conv(Q.c.f, x, weight, bias_, out, true, false, 0);
     Q.c.weight_b = weight_b.data_ptr(); Q.c.bias_b = cptr(bias_b_); Q.c.out_b = out_b.data_ptr();
@@ -714,7 +718,10 @@ std::vector<Tensor> inner_fwd(const Tensor& xz, const Tensor& conv_w, const OptT
     Tensor delta;                                                        // (b, d, l) = dt_proj_w @ x_dbl[:, :R]
     {
         const Tensor dt_in = x_dbl.narrow(1, 0, R);
-        delta = at::empty({x_dbl.size(0), d, x_dbl.size(2)}, x_dbl.options());
+        // (x_dbl row-major over (batch, position) -- conv_xproj_dual's layout for short sequences: delta channel-slowest likewise)
+        const bool kmajor = x_dbl.size(0) > 1 && x_dbl.stride(0) == x_dbl.size(2) && x_dbl.stride(2) == 1;
+        delta = kmajor ? at::empty({d, x_dbl.size(0), x_dbl.size(2)}, x_dbl.options()).permute({1, 0, 2})
+                       : at::empty({x_dbl.size(0), d, x_dbl.size(2)}, x_dbl.options());
         if ((proj_flags & 1) && proj_apply_eligible(dt_proj_w, dt_in, delta)) proj_apply(dt_proj_w, dt_in, delta, false);
         else at::matmul_out(delta, dt_proj_w, dt_in);
         // seq_valid: the positions behind it are the mixer's zero padding to whole vectors (modules/_core.py): softplus(-inf) = 0 makes
