@@ -149,3 +149,43 @@ def test_short_sequence_block_matches_fp32(seqlen):
     assert _rel(got[0], ref[0]) < 2e-2 and _rel(got[1], ref[1]) < 3e-2
     for n in ref[2]:
         assert _rel(got[2][n], ref[2][n]) < 4e-2, (n, _rel(got[2][n], ref[2][n]))
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("L", [8, 16])
+def test_folded_small_projections_equal_unfolded(L, reverse, accumulate):
+    """batches of short sequences that follow each other without a gap (channel-slowest activations, x_dbl row-major over (batch,
+    position)) run as ONE row whose entries the kernels keep apart: vms_proj_conv_bwd, vms_proj_apply and vms_proj_wgrad on those
+    layouts == the same calls on batch-major copies (which the library does not fold), dx bit for bit"""
+    import vms_hip
+    torch.manual_seed(L)
+    b, d, k, R, dt = 80, 128, 36, 4, torch.bfloat16
+    cs = lambda rows: torch.randn(rows, b, L, device=DEV).to(dt).permute(1, 0, 2)          # (b, rows, L) with strides (L, b L, 1)
+    x, du, dx_dbl = cs(d), cs(d), cs(k)
+    w_x = (torch.randn(k, d, device=DEV) * d ** -0.5).to(dt)
+    conv_w, conv_b = torch.randn(d, 4, device=DEV) * 0.3, torch.randn(d, device=DEV) * 0.3
+    w_dt = (torch.randn(d, R, device=DEV) * 0.5).to(dt)
+    res = []
+    for fold in (True, False):
+        cp = (lambda t: t) if fold else (lambda t: t.contiguous())
+        xx, dd, dxd = cp(x), cp(du), cp(dx_dbl)
+        assert (xx.stride(0) == L) == fold
+        dx = (cs(d) if fold else torch.empty(b, d, L, device=DEV, dtype=dt))
+        if accumulate:
+            torch.manual_seed(99)
+            init = torch.randn(b, d, L, device=DEV).to(dt)
+            dx.copy_(init)
+        dcw, dcb, dwx = torch.zeros(d, 4, device=DEV), torch.zeros(d, device=DEV), torch.zeros(k, d, device=DEV)
+        vms_hip.proj_conv_bwd(xx, dd, dxd, w_x, conv_w, conv_b, dx, dcw, dcb, dwx, reverse=reverse, dx_accumulate=accumulate)
+        # delta = W_dt x_dbl[:R] and its weight gradient on the same layouts
+        delta = cs(d) if fold else torch.empty(b, d, L, device=DEV, dtype=dt)
+        vms_hip.proj_apply(w_dt, dxd[:, :R], delta)
+        dw = torch.zeros(R, d, device=DEV)
+        vms_hip.proj_wgrad(dxd[:, :R], dd, dw)
+        res.append((dx.contiguous(), dcw, dcb, dwx, delta.contiguous(), dw))
+    a, r = res
+    assert torch.equal(a[0], r[0]), _rel(a[0], r[0])
+    assert torch.equal(a[4], r[4])
+    for i in (1, 2, 3, 5):
+        assert _rel(a[i], r[i]) < 1e-4, (i, _rel(a[i], r[i]))

@@ -373,7 +373,7 @@ template <> struct Mfma16<f16_t> {
 };
 
 template <typename T, int KS, bool REV, bool DXACC, bool RAG>
-__device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg, const int2 p_grid) {
+__device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_params& p, const int tiles_per_wg, const int2 p_grid, const int entry) {
     constexpr int MB = (KS * 16 + 31) / 32;      // 32-deep k steps of the first product
     constexpr int KP = MB * 32;                  // k padded to the matrix instructions' depth (rows beyond k are zero)
     constexpr int NPASS = MB;                    // dx_dbl tile: 32 rows of 8 x 16-byte pieces per pass of the workgroup
@@ -555,7 +555,9 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
         r.du = __builtin_bit_cast(vec_t<T, 8>, ld8(du_rs, (int64_t)d * p.du_c_stride, tl, okp));
         // the 3 positions before the piece: physical [pl - 4, pl) left-to-right, [pl + 8, pl + 12) right-to-left (always inside the
         // row: tl >= 8 there); zeros before the row
-        r.xh = __builtin_bit_cast(vec_t<T, 4>, __builtin_amdgcn_raw_buffer_load_b64(x_rs, okp && tl > 0 ? xo + (REV ? 16 : -8) : kOOB, 0, 0));
+        // entry (> 0: a power of two, a multiple of 8): the row is `seqlen / entry` independent sequences of `entry` positions laid end
+        // to end (vms_proj_conv_bwd folds gap-free batches of short sequences into one row): nothing crosses their boundaries
+        r.xh = __builtin_bit_cast(vec_t<T, 4>, __builtin_amdgcn_raw_buffer_load_b64(x_rs, okp && tl > 0 && (entry == 0 || (tl & (entry - 1)) != 0) ? xo + (REV ? 16 : -8) : kOOB, 0, 0));
     };
 
     // the tile after the range only feeds `carry`
@@ -638,7 +640,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
             for (int k = 0; k < 3; ++k) {
                 const float fromnext = dpp_mov<DPP_ROW_SHL1, 0xf>(0.f, gp[k]);
                 const float fromcarry = dpp_mov<0x117, 0xf>(0.f, carry[ss][k]);   // row_shr:7
-                gp[8 + k] = pc == 7 ? fromcarry : fromnext;
+                gp[8 + k] = entry != 0 && ((tl + 8) & (entry - 1)) == 0 ? 0.f : pc == 7 ? fromcarry : fromnext;
                 carry[ss][k] = gp[k];
             }
             {
@@ -719,13 +721,13 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
 }
 
 template <typename T, int KS, bool DXACC, bool RAG>
-__global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg, const int2 p_grid) {
+__global__ __launch_bounds__(kPT, 2) void proj_conv_bwd_kernel(const vms_proj_conv_bwd_params p, const int tiles_per_wg, const int2 p_grid, const int entry) {
     // the batch entry of this workgroup (same decode as in the body) decides the direction: workgroup-uniform
     const int pair = (((int)blockIdx.x >> 3) / p_grid.y) * 8 + ((int)blockIdx.x & 7);
     const int b = pair / p_grid.x;    // >= batch for the padding workgroups of the last group of 8, which return at once
     const bool rev = p.reverse != 0 || (p.reverse_from > 0 && b >= p.reverse_from);
-    if (rev) proj_conv_bwd_body<T, KS, true, DXACC, RAG>(p, tiles_per_wg, p_grid);
-    else proj_conv_bwd_body<T, KS, false, DXACC, RAG>(p, tiles_per_wg, p_grid);
+    if (rev) proj_conv_bwd_body<T, KS, true, DXACC, RAG>(p, tiles_per_wg, p_grid, entry);
+    else proj_conv_bwd_body<T, KS, false, DXACC, RAG>(p, tiles_per_wg, p_grid, entry);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1256,7 +1258,7 @@ static int dispatch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t 
 }
 
 template <typename T, int KS>
-static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream) {
+static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream, const int entry) {
     constexpr int MB = (KS * 16 + 31) / 32;
     const int n_tiles = (p.seqlen + kTL - 1) / kTL;
     const int d_tiles = (p.dim + kCD - 1) / kCD;
@@ -1295,7 +1297,7 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
             return VMS_ERR_LAUNCH;
         }
     }
-#define VMS_PCB_LAUNCH(A_, R_) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, A_, R_>), grid, block, smem, stream, p, tpw, pg)
+#define VMS_PCB_LAUNCH(A_, R_) hipLaunchKernelGGL((proj_conv_bwd_kernel<T, KS, A_, R_>), grid, block, smem, stream, p, tpw, pg, entry)
     if (p.dx_accumulate) { if (rag) VMS_PCB_LAUNCH(true, true); else VMS_PCB_LAUNCH(true, false); }
     else { if (rag) VMS_PCB_LAUNCH(false, true); else VMS_PCB_LAUNCH(false, false); }
 #undef VMS_PCB_LAUNCH
@@ -1305,12 +1307,12 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
 }
 
 template <typename T>
-static int dispatch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream) {
+static int dispatch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream, const int entry) {
     switch ((p.k + 15) / 16) {
-        case 3: return launch_conv_bwd<T, 3>(p, stream);
-        case 4: return launch_conv_bwd<T, 4>(p, stream);
-        case 5: return launch_conv_bwd<T, 5>(p, stream);
-        default: return launch_conv_bwd<T, 6>(p, stream);
+        case 3: return launch_conv_bwd<T, 3>(p, stream, entry);
+        case 4: return launch_conv_bwd<T, 4>(p, stream, entry);
+        case 5: return launch_conv_bwd<T, 5>(p, stream, entry);
+        default: return launch_conv_bwd<T, 6>(p, stream, entry);
     }
 }
 
@@ -1433,6 +1435,21 @@ extern "C" int vms_sizeof_proj_wgrad_params(void) { return (int)sizeof(vms_proj_
 
 extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* stream) {
     VMS_CHECK(pp != nullptr, "null parameter block");
+    // Batches of short sequences that follow each other without a gap in every operand (8 or 16 positions per entry: TimeMamba's
+    // scans along time in the blocks' layouts) run as ONE row of batch x seqlen positions whose entries the kernel keeps apart
+    // (`entry`): its tiles are 64 positions of one row -- an eighth full at 8 frames (2 x 480 us of a 2.5 ms block step).
+    vms_proj_conv_bwd_params folded;
+    int entry = 0;
+    if (pp->batch > 1 && (pp->seqlen == 8 || pp->seqlen == 16) && (pp->reverse_from == 0 || pp->reverse_from >= pp->batch) &&
+        pp->x_batch_stride == pp->seqlen && pp->du_batch_stride == pp->seqlen && pp->dx_batch_stride == pp->seqlen &&
+        pp->dxdbl_batch_stride == pp->seqlen && (int64_t)pp->batch * pp->seqlen < ((int64_t)1 << 30)) {
+        folded = *pp;
+        entry = pp->seqlen;
+        folded.seqlen = pp->batch * pp->seqlen;
+        folded.batch = 1;
+        folded.reverse_from = 0;
+        pp = &folded;
+    }
     const vms_proj_conv_bwd_params& p = *pp;
     VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_conv_bwd: 16-bit activations only (bf16 / fp16)");
     VMS_CHECK(p.wdtype == VMS_F32 || p.wdtype == VMS_F16 || p.wdtype == VMS_BF16, "conv weight dtype must be fp32/fp16/bf16");
@@ -1455,6 +1472,6 @@ extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* strea
                    aligned16(p.x) && aligned16(p.du) && aligned16(p.dx) && aligned16(p.dx_dbl)),
               "proj_conv_bwd: with seqlen % 8 == 0 the activation strides (elements) must be multiples of 8, bases 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return p.dtype == VMS_BF16 ? dispatch_conv_bwd<bf16_t>(p, s) : dispatch_conv_bwd<f16_t>(p, s);
+    return p.dtype == VMS_BF16 ? dispatch_conv_bwd<bf16_t>(p, s, entry) : dispatch_conv_bwd<f16_t>(p, s, entry);
 }
 extern "C" int vms_sizeof_proj_conv_bwd_params(void) { return (int)sizeof(vms_proj_conv_bwd_params); }

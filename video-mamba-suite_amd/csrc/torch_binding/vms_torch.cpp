@@ -444,7 +444,9 @@ std::vector<Tensor> conv_xproj_dual(const Tensor& x, const Tensor& weight, const
     if (L % 8 || d % 8 || x.stride(0) % 8 || x.stride(1) % 8 || x.stride(1) < L || !al16(x) || !al16(w_x) || !al16(w_x_b)) return {};
     if (((d - 1) * x.stride(1) + L) * 2 >= ((int64_t)1 << 31) || d * L * 2 >= ((int64_t)1 << 31)) return {};
     c10::DeviceGuard guard(x.device());
-    Tensor out = at::empty(x.sizes(), x.options()), out_b = at::empty(x.sizes(), x.options());
+    const bool cslow = L <= 16 && b * d >= 4096 && b > 1 && x.stride(0) == L;      // (see kmajor below: conv1d_out channel-slowest like x)
+    Tensor out = cslow ? at::empty({d, b, L}, x.options()).permute({1, 0, 2}) : at::empty(x.sizes(), x.options());
+    Tensor out_b = cslow ? at::empty({d, b, L}, x.options()).permute({1, 0, 2}) : at::empty(x.sizes(), x.options());
     // short sequences with many rows (the lane-per-row scans' shapes) and a channel-slowest x: x_dbl row-major over (batch, position)
     // too, so that the products over it see batch x seqlen positions as one run (vms_proj_apply / vms_proj_wgrad fold such operands)
     const bool kmajor = L <= 16 && b * d >= 4096 && b > 1 && x.stride(0) == L;
