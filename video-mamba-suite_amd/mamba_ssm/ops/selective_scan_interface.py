@@ -351,7 +351,9 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         x_dbl, delta = _proj_T(conv_out, x_proj_weight, delta_proj_weight)   # x_dbl: (b, R+2N, l)
     else:
         delta = torch.matmul(delta_proj_weight, x_dbl[:, :R])
-    delta = _mask_padding(delta, seq_valid, delta_softplus)
+    # (a one-element sequence: the size-1 axis may carry any stride)
+    conv_out, x_dbl = _last_dim_contiguous(conv_out), _last_dim_contiguous(x_dbl)
+    delta = _mask_padding(_last_dim_contiguous(delta), seq_valid, delta_softplus)
 
     if B is None:
         B = _bc_from_x_dblT(x_dbl, R, R + d_state, B_proj_bias)
