@@ -99,6 +99,33 @@ __device__ __forceinline__ float wave_sum_to_last(float v) {
     return v;
 }
 
+// 2 x LP per-lane values -> their sums over the wave, as a reduce-scatter: v_permlane32_swap on pairs (a swap + an add halve the
+// count: lanes 0-31 then hold the first value of the pair summed over both halves, lanes 32-63 the second), v_permlane16_swap on
+// pairs of those (rows 0 / 1 / 2 / 3 hold values 4 m + 0 / 2 / 1 / 3 summed over the four rows), then 4 DPP steps inside each row:
+// lane 16 r + 15 of z[m] = the wave's sum of value 4 m + {0, 2, 1, 3}[r].  40 instead of ~150 vector instructions per state at
+// 8 elements (six-step sums of every value, a v_readlane and two selects each): the backward kernel was 94 % VALU-bound.
+template <int V>
+__device__ __forceinline__ void wave_reduce_scatter(float (&v)[V], float (&z)[V / 4]) {
+    float w[V / 2];
+#pragma unroll
+    for (int k = 0; k < V / 2; ++k) {
+        float a = v[2 * k], b = v[2 * k + 1];
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        w[k] = a + b;
+    }
+#pragma unroll
+    for (int m = 0; m < V / 4; ++m) {
+        float a = w[2 * m], b = w[2 * m + 1];
+        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+        float t = a + b;
+        t += dpp_mov<DPP_ROW_SHR1, 0xf>(0.f, t);
+        t += dpp_mov<DPP_ROW_SHR2, 0xf>(0.f, t);
+        t += dpp_mov<DPP_ROW_SHR4, 0xf>(0.f, t);
+        t += dpp_mov<DPP_ROW_SHR8, 0xf>(0.f, t);
+        z[m] = t;
+    }
+}
+
 // LP: the register arrays' length (8 or 16) >= seqlen.  Logical element i of a right-to-left row is physical element L - 1 - i.
 template <typename T, bool HZ, bool REV, int LP, bool VEC>
 __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_params p) {
@@ -138,7 +165,12 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
     // (the state loop is NOT unrolled: unrolled, the 16 states' B / C loads were all hoisted to the top -- 306 registers at 16 elements)
     const int64_t xpitch = p.x_chunk_stride ? p.x_chunk_stride : 2 * N;
     float* xr = static_cast<float*>(p.x) + ((int64_t)b * p.dim + d) * xpitch;
+    // x: a wave's 64 rows are 64 x 128 contiguous bytes of the dense x.  Written from the lanes' own registers -- 16 bytes per
+    // lane, 128 bytes apart -- the forward moved 383 MB for 192 MB of results at (1568, 768, 8) and spent most of its 190 us on
+    // it; the final states go through LDS ([row][state], 17-float pitch) and leave as eight 1 KB-contiguous stores per wave.
+    __shared__ float hs[4][64 * 17];
     const bool x16 = (xpitch & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
+    const bool xdense = x16 && xpitch == 2 * N;
 #pragma unroll 1
     for (int n0 = 0; n0 < N; n0 += 2) {
         float hq[2];
@@ -157,13 +189,26 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
             }
             hq[k] = h;
         }
-        if (row_ok) {   // the state at the row's end in both slots of the one chunk; 16 bytes per two states (4-byte stores of 64
-                        // lanes 128 bytes apart cost the forward more than its arithmetic)
+        if (xdense) {
+            hs[wave][lane * 17 + n0] = hq[0];
+            hs[wave][lane * 17 + n0 + 1] = hq[1];
+        } else if (row_ok) {   // the state at the row's end in both slots of the one chunk
             if (x16) *reinterpret_cast<float4*>(xr + 2 * n0) = float4{hq[0], hq[0], hq[1], hq[1]};
             else { xr[2 * n0] = hq[0]; xr[2 * n0 + 1] = hq[0]; xr[2 * n0 + 2] = hq[1]; xr[2 * n0 + 3] = hq[1]; }
         }
     }
     if (!row_ok) return;
+    if (xdense) {   // (wave-private LDS: the wave's own writes are complete before its reads)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float* xw = static_cast<float*>(p.x) + ((int64_t)b * p.dim + (d - lane)) * (2 * N);     // the wave's 64 rows
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int flat = k * 64 + lane, row = flat >> 3, quad = flat & 7;
+            const float h0 = hs[wave][row * 17 + 2 * quad], h1 = hs[wave][row * 17 + 2 * quad + 1];
+            *reinterpret_cast<float4*>(xw + flat * 4) = float4{h0, h0, h1, h1};
+        }
+    }
     store_row<T, LP, REV, VEC>(out, L, y);
     if (HZ) {
         const T* z = static_cast<const T*>(p.z) + (int64_t)b * p.z_batch_stride + (int64_t)d * p.z_d_stride;
@@ -180,20 +225,22 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
     }
 }
 
-// Backward.  A workgroup = blockDim consecutive channels of ONE batch entry (blockDim divides the channels of a group).
-// dB / dC -- sums over the channels -- are reduced over the wave with DPP, over the workgroup's waves through LDS, and leave as ONE
-// atomic instruction of 2 L lanes per (workgroup, state).  dA / dD / ddelta_bias -- sums over the batch -- go to the workspace as
+// Backward.  Waves and workgroups as in the forward kernel (64 channels of one batch entry; 4 neighbouring entries per workgroup).
+// dB / dC -- sums over the channels -- are reduced over the wave with DPP, handed to lanes 0 .. 2 L - 1 (v_readlane + select) and
+// leave as ONE atomic instruction of 2 L lanes per (wave, state): no LDS, no barrier (a first version that also summed the
+// workgroup's waves -- then one batch entry per workgroup -- through LDS paid 32 barriers per row and had every wave fetch its own
+// lines: 338 us at (1568, 768, 8)).  dA / dD / ddelta_bias -- sums over the batch -- go to the workspace as
 // ws[batch entry][18][channel] (coalesced stores, no atomics) and are summed by short_reduce_kernel: as atomics straight from the
 // rows, 1,568 of them onto each of 12 K addresses, they were 1.1 of the kernel's 2.0 ms at (1568, 16, 768).  No workspace: atomics.
 template <typename T, bool HZ, bool REV, int LP, bool VEC>
 __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_params q, float* __restrict__ ws) {
     const vms_scan_fwd_params& p = q.f;
     constexpr int N = kSN;
-    __shared__ float red[4][2 * LP];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    const int wg_per_b = p.dim / (int)blockDim.x;
-    const int d = ((int)blockIdx.x % wg_per_b) * (int)blockDim.x + (int)threadIdx.x;
-    const int b = (int)blockIdx.x / wg_per_b;                          // (workgroup-uniform)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dblocks = p.dim / 64;
+    const int d = ((int)blockIdx.x % dblocks) * 64 + lane;
+    const int b = __builtin_amdgcn_readfirstlane(((int)blockIdx.x / dblocks) * 4 + wave);
+    if (b >= p.batch) return;                                          // (the whole wave; nothing below synchronises waves)
     const int g = __builtin_amdgcn_readfirstlane(d / (p.dim / p.n_groups));
     const int L = p.seqlen;
     const T* u = static_cast<const T*>(p.u) + (int64_t)b * p.u_batch_stride + (int64_t)d * p.u_d_stride;
@@ -260,6 +307,7 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
             x[i] = h;
         }
         float gr = 0.f, dA = 0.f;
+        float vals[2 * LP];      // this lane's dB (0 .. LP-1) and dC (LP .. 2 LP-1) terms of the state
 #pragma unroll
         for (int i = LP - 1; i >= 0; --i) {
             gr = fmaf(i == LP - 1 ? 0.f : a[i + 1], gr, Cv[i] * dy[i]);       // g_i = a_{i+1} g_{i+1} + C_i dy_i
@@ -267,24 +315,22 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
             dua[i] = fmaf(gr * dl[i], Bv[i], dua[i]);
             dda[i] = fmaf(gr, fmaf(Araw, ax, uv[i] * Bv[i]), dda[i]);
             dA = fmaf(gr * dl[i], ax, dA);
-            const float sb = wave_sum_to_last(gr * dl[i] * uv[i]);
-            const float sc = wave_sum_to_last(dy[i] * x[i]);
-            if (lane == 63) {
-                red[wave][i] = sb;
-                red[wave][LP + i] = sc;
-            }
+            vals[i] = gr * dl[i] * uv[i];
+            vals[LP + i] = dy[i] * x[i];
         }
         if (wsr) wsr[(int64_t)n * p.dim] = dA;
         else atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)n * q.dA_dstate_stride, dA);
-        __syncthreads();
-        if (threadIdx.x < 2 * LP) {                     // position i of dB (threads 0 .. LP-1) or dC (LP .. 2 LP-1)
-            float v = red[0][threadIdx.x];
-            for (int w = 1; w < n_waves; ++w) v += red[w][threadIdx.x];
-            const int i = (int)threadIdx.x & (LP - 1);
-            float* dst = threadIdx.x < LP ? dBp + (int64_t)n * q.dB_dstate_stride : dCp + (int64_t)n * q.dC_dstate_stride;
-            if (i < L) atomicAdd(dst + (REV ? L - 1 - i : i), v);
+        float z[LP / 2];
+        wave_reduce_scatter<2 * LP>(vals, z);
+        if ((lane & 15) == 15) {       // lane 16 r + 15 of z[m]: the wave's sum of value 4 m + {0, 2, 1, 3}[r]
+            const int r = lane >> 4, sub = r == 1 ? 2 : r == 2 ? 1 : r;
+#pragma unroll
+            for (int m = 0; m < LP / 2; ++m) {
+                const int v = 4 * m + sub, i = v & (LP - 1);
+                float* dst = v < LP ? dBp + (int64_t)n * q.dB_dstate_stride : dCp + (int64_t)n * q.dC_dstate_stride;
+                if (i < L) atomicAdd(dst + (REV ? L - 1 - i : i), z[m]);
+            }
         }
-        __syncthreads();
     }
     float dbias = 0.f;
 #pragma unroll
@@ -373,10 +419,7 @@ bool scan_bwd_short_eligible(const vms_scan_bwd_params& q) { return scan_short_e
 template <typename T>
 static int launch_bwd_short_t(const vms_scan_bwd_params& q, hipStream_t stream) {
     const vms_scan_fwd_params& p = q.f;
-    // a workgroup = blockDim consecutive channels of one group of kSNB batch entries; blockDim divides the channels of a group
-    const int cpg = p.dim / p.n_groups;
-    const int bd = cpg % 256 == 0 ? 256 : cpg % 128 == 0 ? 128 : 64;
-    const dim3 grid((unsigned)((p.dim / bd) * p.batch)), block(bd);
+    const dim3 grid((unsigned)((p.dim / 64) * ((p.batch + 3) / 4))), block(256);
     const bool vec = short_vec_bwd(q);
     float* ws = p.workspace != nullptr && p.workspace_bytes >= scan_bwd_short_ws_bytes(q) && (reinterpret_cast<uintptr_t>(p.workspace) & 3) == 0
                     ? static_cast<float*>(p.workspace) : nullptr;
