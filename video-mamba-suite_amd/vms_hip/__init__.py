@@ -446,7 +446,9 @@ def x_mode_for_shape(batch, dim, seqlen, dstate, device, for_backward=True):
     total = _total_mem.get(idx)
     if total is None:
         total = _total_mem[idx] = torch.cuda.get_device_properties(idx).total_memory
-    need = batch * dim * (seqlen // 8) * dstate * 4
+    # what the 8-element layout allocates: 258 * dstate floats per (row, 2048-element chunk) whatever the row's length (a short
+    # row pays for a whole chunk: 16.5 KB at dstate 16)
+    need = batch * dim * ((seqlen + 2047) // 2048) * 258 * dstate * 4
     used = _allocated_bytes(idx)
     return -1 if (4 * used <= total and 8 * need <= total - used) else 1
 
