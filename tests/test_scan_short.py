@@ -189,3 +189,33 @@ def test_folded_small_projections_equal_unfolded(L, reverse, accumulate):
     assert torch.equal(a[4], r[4])
     for i in (1, 2, 3, 5):
         assert _rel(a[i], r[i]) < 1e-4, (i, _rel(a[i], r[i]))
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_short_rows_groups_and_strided_layouts(oracle, reverse):
+    """two B / C groups (64 channels each), u / z as halves of one channel-slowest xz buffer, delta channel-slowest, B / C stored
+    row-major over (batch, position) -- the fused block's layouts for these shapes"""
+    import selective_scan_cuda
+    import vms_hip
+    torch.manual_seed(5)
+    b, d, L, N, G, dt = 72, 128, 8, 16, 2, torch.bfloat16
+    xz = torch.randn(2 * d, b, L, device=DEV).to(dt).permute(1, 0, 2)
+    u, z = xz[:, :d], xz[:, d:]
+    delta = (0.5 * torch.rand(d, b, L, device=DEV)).to(dt).permute(1, 0, 2)
+    A = -0.5 * torch.rand(d, N, device=DEV) - 0.1
+    BC = torch.randn(2 * G * N, b, L, device=DEV).to(dt).permute(1, 0, 2)          # (b, 2 G N, L), strides (L, b L, 1)
+    B, C = BC[:, :G * N].unflatten(1, (G, N)), BC[:, G * N:].unflatten(1, (G, N))
+    D, bias = torch.randn(d, device=DEV), 0.5 * torch.rand(d, device=DEV)
+    dout = torch.randn(d, b, L, device=DEV).to(dt).permute(1, 0, 2)
+    out, x, out_z = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_fwd_short"
+    g = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_bwd_short"
+    f = lambda t: t.detach().float().cpu().numpy()
+    lf = (lambda t: t.flip(-1)) if reverse else (lambda t: t)
+    o = oracle.scan_fwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), True, prec="f64")
+    ob = oracle.scan_bwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), f(lf(dout)), True, prec="f64")
+    assert _rel(lf(out_z), o["out_z"]) <= 1e-2 and _rel(x, o["x"]) <= 1e-3
+    for name, got in zip(NAMES, g):
+        gg = lf(got) if got.ndim >= 3 and got.shape[-1] == L else got
+        assert _rel(gg, ob[name]) <= 5e-2 if name in ("dA", "dD", "ddelta_bias", "dB", "dC") else _rel(gg, ob[name]) <= 2e-2, name
