@@ -219,3 +219,30 @@ def test_short_rows_groups_and_strided_layouts(oracle, reverse):
     for name, got in zip(NAMES, g):
         gg = lf(got) if got.ndim >= 3 and got.shape[-1] == L else got
         assert _rel(gg, ob[name]) <= 5e-2 if name in ("dA", "dD", "ddelta_bias", "dB", "dC") else _rel(gg, ob[name]) <= 2e-2, name
+
+
+@pytest.mark.parametrize("L", [8, 16])
+def test_folded_conv_xproj_head_equals_unfolded(L):
+    """vms_conv_xproj_dual on the short-sequence layouts (x channel-slowest: the library folds the gap-free batch into one row whose
+    entries it keeps apart) == the same call on a batch-major copy of x: both conv1d outputs and both x_dbl bit for bit"""
+    import vms_hip
+    ext = vms_hip.ext()
+    if ext is None or not hasattr(ext, "conv_xproj_dual"):
+        pytest.skip("needs the compiled binding")
+    torch.manual_seed(L)
+    b, d, m, dt = 80, 128, 36, torch.bfloat16
+    x_cs = torch.randn(d, b, L, device=DEV).to(dt).permute(1, 0, 2)            # strides (L, b L, 1): folded
+    x_bm = x_cs.contiguous()                                                   # batch-major: not folded
+    w, wb_ = torch.randn(d, 4, device=DEV) * 0.4, torch.randn(d, 4, device=DEV) * 0.4
+    bias, bias_b = torch.randn(d, device=DEV) * 0.3, torch.randn(d, device=DEV) * 0.3
+    w_x, w_x_b = (torch.randn(m, d, device=DEV) * d ** -0.5).to(dt), (torch.randn(m, d, device=DEV) * d ** -0.5).to(dt)
+    got = ext.conv_xproj_dual(x_cs, w, bias, wb_, bias_b, w_x, w_x_b)
+    ref = ext.conv_xproj_dual(x_bm, w, bias, wb_, bias_b, w_x, w_x_b)
+    assert got[0].stride(0) == L and got[2].stride(0) == L and ref[0].stride(0) != L
+    for k in range(4):
+        assert torch.equal(got[k].contiguous(), ref[k].contiguous()), k
+    # and against the plain ops: causal conv1d + SiLU per direction
+    from causal_conv1d import causal_conv1d_fn
+    ca = causal_conv1d_fn(x_bm, w, bias, "silu")
+    cb = causal_conv1d_fn(x_bm.flip(-1), wb_, bias_b, "silu").flip(-1)
+    assert _rel(got[0], ca) < 1e-2 and _rel(got[1], cb) < 1e-2

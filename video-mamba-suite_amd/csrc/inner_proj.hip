@@ -904,7 +904,7 @@ __global__ __launch_bounds__(kPT, (NL <= 2 ? 4 : NL <= 4 ? 3 : 2)) void proj_kre
 // the outputs are bit-identical -- which it stores to HBM and into the two LDS tiles the matrix cores then read as B operands.
 // conv1d_out is never read back: 402 MB instead of 671 at (8, 1024, 8192), one launch instead of two.
 template <typename T, typename WT_, int MH, int NL>
-__global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_xproj_dual_params q) {
+__global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_xproj_dual_params q, const int entry) {
     const vms_conv_fwd_params& p = q.c.f;
     constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = KB + 8;
     constexpr int PPR = TL / 8, RPP = kPT / PPR;
@@ -1016,6 +1016,10 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
             u32 pr1 = (u32)__builtin_amdgcn_update_dpp(0, (int)md[1], DPP_WAVE_SHL1, 0xf, 0xf, false);
             if (ipc == 0) { pl2 = st.el[ps][0]; pl3 = st.el[ps][1]; }
             if (ipc == PPR - 1) { pr0 = st.er[ps][0]; pr1 = st.er[ps][1]; }
+            // entry (> 0: 8 or 16): the row is `seqlen / entry` independent sequences laid end to end (vms_conv_xproj_dual folds gap-free
+            // batches of short sequences): no filter reaches across their boundaries
+            if (entry != 0 && (l & (entry - 1)) == 0) { pl2 = 0; pl3 = 0; }
+            if (entry != 0 && ((l + 8) & (entry - 1)) == 0) { pr0 = 0; pr1 = 0; }
             float xv[8 + 6];     // xv[3 + i] = x[l + i]; [0..2] = the 3 positions before, [11..13] = the 3 after
             xv[0] = up(pl2, 1); xv[1] = up(pl3, 0); xv[2] = up(pl3, 1);
 #pragma unroll
@@ -1222,7 +1226,7 @@ static int dispatch_kred(const vms_proj_kred_params& p, hipStream_t stream) {
 }
 
 template <typename T, typename WT_, int MH, int NL>
-static int launch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream) {
+static int launch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream, const int entry) {
     constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = KB + 8;
     const dim3 grid((q.c.f.seqlen + TL - 1) / TL, 1, q.c.f.batch), block(kPT);
     const size_t smem = (size_t)(2 * KB * INP + 2 * MP * WP) * 2 + (size_t)2 * 2 * KB * 8 * sizeof(float);
@@ -1236,19 +1240,19 @@ static int launch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t st
             return VMS_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((conv_xproj_dual_kernel<T, WT_, MH, NL>), grid, block, smem, stream, q);
+    hipLaunchKernelGGL((conv_xproj_dual_kernel<T, WT_, MH, NL>), grid, block, smem, stream, q, entry);
     VMS_LAUNCH_CHECK();
     set_last_kernel(NL == 4 ? "conv_xproj_dual_128" : "conv_xproj_dual_64");
     return VMS_OK;
 }
 
 template <typename T, typename WT_>
-static int dispatch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream) {
+static int dispatch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream, const int entry) {
     // 64 positions per workgroup: two workgroups per CU; 128 (one per CU, 256 registers) measured 25-45 % slower on every shape
     // (profiles/r04_conv_xproj.md) and stays a knob
     const int tile = q.tile == 128 ? 128 : 64;
     const int mh = ((q.m + 15) / 16 + 1) / 2;
-#define VMS_CXP(MH_) (tile == 128 ? launch_conv_xproj<T, WT_, MH_, 4>(q, stream) : launch_conv_xproj<T, WT_, MH_, 2>(q, stream))
+#define VMS_CXP(MH_) (tile == 128 ? launch_conv_xproj<T, WT_, MH_, 4>(q, stream, entry) : launch_conv_xproj<T, WT_, MH_, 2>(q, stream, entry))
     switch (mh) {
         case 1: return VMS_CXP(1);
         case 2: return VMS_CXP(2);
@@ -1403,6 +1407,21 @@ extern "C" int vms_proj_kred(const vms_proj_kred_params* pp, void* stream) {
 extern "C" int vms_sizeof_proj_kred_params(void) { return (int)sizeof(vms_proj_kred_params); }
 extern "C" int vms_conv_xproj_dual(const vms_conv_xproj_dual_params* qq, void* stream) {
     VMS_CHECK(qq != nullptr, "null parameter block");
+    // gap-free batches of 8 / 16-position sequences as ONE row whose entries the kernel keeps apart (see vms_proj_conv_bwd)
+    vms_conv_xproj_dual_params folded;
+    int entry = 0;
+    {
+        const vms_conv_fwd_params& f = qq->c.f;
+        if (f.batch > 1 && (f.seqlen == 8 || f.seqlen == 16) && !f.reverse && !f.reverse_from && f.x_l_stride == 1 && f.out_l_stride == 1 &&
+            f.x_batch_stride == f.seqlen && f.out_batch_stride == f.seqlen && qq->c.out_b_batch_stride == f.seqlen &&
+            qq->xdbl_batch_stride == f.seqlen && (int64_t)f.batch * f.seqlen < ((int64_t)1 << 30)) {
+            folded = *qq;
+            entry = f.seqlen;
+            folded.c.f.seqlen = f.batch * f.seqlen;
+            folded.c.f.batch = 1;
+            qq = &folded;
+        }
+    }
     const vms_conv_xproj_dual_params& q = *qq;
     const vms_conv_fwd_params& p = q.c.f;
     VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "conv_xproj_dual: 16-bit activations only (bf16 / fp16)");
@@ -1426,8 +1445,8 @@ extern "C" int vms_conv_xproj_dual(const vms_conv_xproj_dual_params* qq, void* s
                   "conv_xproj_dual: a batch entry of x / out / out_b and w_x must each span < 2 GiB, rows must not overlap");
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (p.dtype == VMS_BF16) return p.wdtype == VMS_F32 ? dispatch_conv_xproj<bf16_t, float>(q, s) : dispatch_conv_xproj<bf16_t, bf16_t>(q, s);
-    return p.wdtype == VMS_F32 ? dispatch_conv_xproj<f16_t, float>(q, s) : dispatch_conv_xproj<f16_t, f16_t>(q, s);
+    if (p.dtype == VMS_BF16) return p.wdtype == VMS_F32 ? dispatch_conv_xproj<bf16_t, float>(q, s, entry) : dispatch_conv_xproj<bf16_t, bf16_t>(q, s, entry);
+    return p.wdtype == VMS_F32 ? dispatch_conv_xproj<f16_t, float>(q, s, entry) : dispatch_conv_xproj<f16_t, f16_t>(q, s, entry);
 }
 extern "C" int vms_sizeof_conv_xproj_dual_params(void) { return (int)sizeof(vms_conv_xproj_dual_params); }
 extern "C" int vms_sizeof_proj_apply_params(void) { return (int)sizeof(vms_proj_apply_params); }
