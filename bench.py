@@ -42,6 +42,9 @@ WORKLOADS = {
     "stack": ("configs[2]: 12 x Block(Add -> RMSNorm -> ViM), fused add+norm", 8, 3136, 768, 1, 12),
     "dbm": ("configs[3]: DBM bidirectional Mamba block (shared weights, fwd + reversed scan)", 2, 2304, 512, 1, 1),
     "long": ("configs[4]: ViM block, long-video regime (sequence-split scans)", 1, 65536, 768, 1, 1),
+    # not a BASELINE config: the suite's other regime -- TimeMamba's scans along time (timemamba.py:135-140): 8 clips x 196 tokens,
+    # 8 frames each (the lane-per-row scan kernels, the folded small projections; profiles/r04_short_rows.md)
+    "frames": ("extra: ViM block on short sequences with many rows (TimeMamba, 'b (n t) d -> (b n) t d')", 1568, 8, 768, 1, 1),
 }
 B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
