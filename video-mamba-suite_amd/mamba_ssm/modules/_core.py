@@ -214,24 +214,41 @@ class MambaCore(nn.Module):
             return None
         import vms_hip
         dev = hidden_states.device
-        sizes = [(w.numel() + 127) // 128 * 128 for w in ws]
-        flat = torch.empty(sum(sizes), dtype=dt, device=dev)
-        o, lows = 0, []
-        for w, n in zip(ws, sizes):
-            lows.append(flat[o:o + w.numel()])
-            o += n
         w_in, w_out = self.in_proj.weight.detach(), self.out_proj.weight.detach()
         ch, dm = w_in.shape                                      # channels = 2 halves x (2 d_inner), d_model
-        wt_in = lows[0].view(dm, ch)                             # column 2 c + half <- row half * ch/2 + c of the weight
-        w_x, w_dt = lows[1].view(self.x_proj.weight.shape), lows[2].view(self.dt_proj.weight.shape)
         C = w_out.shape[1]
-        wp_out = lows[3].view(w_out.shape[0], C)                 # column 2 c + half <- column half * C/2 + c of the weight
+        # (the descriptors once per module, re-aimed at the step's buffers: vms_hip.PrepPlan, as in _prepare_params)
+        srcs = (w_in, w_in[ch // 2:], self.x_proj.weight, self.dt_proj.weight, w_out, w_out[:, C // 2:], self.A_log)   # the jobs' sources
+        plan = _PREP_PLANS.get(self)
+        if plan is None or plan[0] != (dt, dev, "dbm") or not plan[1].matches(srcs):
+            offs, o = [], 0
+            for w in ws:
+                offs.append(o)
+                o += (w.numel() + 127) // 128 * 128
+            esz = 2
+            # wt_in (dm, ch): column 2 c + half <- row half * ch/2 + c of the weight; wp_out (rows, C): column 2 c + half <- column
+            # half * C/2 + c of the weight
+            jobs = [(w_in[h * (ch // 2):(h + 1) * (ch // 2)], 0, (offs[0] + h) * esz, (dm, ch // 2), (ch, 2), dt, vms_hip.PREP_CAST_T)
+                    for h in range(2)]
+            jobs += [(self.x_proj.weight.detach(), 0, offs[1] * esz, tuple(self.x_proj.weight.shape), (self.x_proj.weight.shape[1], 1), dt,
+                      vms_hip.PREP_CAST),
+                     (self.dt_proj.weight.detach(), 0, offs[2] * esz, tuple(self.dt_proj.weight.shape), (self.dt_proj.weight.shape[1], 1), dt,
+                      vms_hip.PREP_CAST)]
+            jobs += [(w_out[:, h * (C // 2):(h + 1) * (C // 2)], 0, (offs[3] + h) * esz, (w_out.shape[0], C // 2), (C, 2), dt, vms_hip.PREP_CAST)
+                     for h in range(2)]
+            jobs += [(self.A_log.detach(), 1, 0, tuple(self.A_log.shape), (self.A_log.shape[1], 1), torch.float32, vms_hip.PREP_NEG_EXP)]
+            pp = vms_hip.PrepPlan(jobs)
+            # (matches() compares the jobs' source pointers: the two halves of in_proj / out_proj are views of the parameters)
+            plan = ((dt, dev, "dbm"), pp, o, offs)
+            _PREP_PLANS[self] = plan
+        _, pp, total, offs = plan
+        flat = torch.empty(total, dtype=dt, device=dev)
         A = torch.empty_like(self.A_log)
-        jobs = [(w_in[h * (ch // 2):(h + 1) * (ch // 2)], wt_in[:, h::2], vms_hip.PREP_CAST_T) for h in range(2)]
-        jobs += [(self.x_proj.weight.detach(), w_x, vms_hip.PREP_CAST), (self.dt_proj.weight.detach(), w_dt, vms_hip.PREP_CAST)]
-        jobs += [(w_out[:, h * (C // 2):(h + 1) * (C // 2)], wp_out[:, h::2], vms_hip.PREP_CAST) for h in range(2)]
-        jobs += [(self.A_log.detach(), A, vms_hip.PREP_NEG_EXP)]
-        vms_hip.param_prep(jobs)
+        pp.run((flat.data_ptr(), A.data_ptr()), flat)
+        wt_in = flat.as_strided((dm, ch), (ch, 1), offs[0])
+        w_x = flat.as_strided(tuple(self.x_proj.weight.shape), (self.x_proj.weight.shape[1], 1), offs[1])
+        w_dt = flat.as_strided(tuple(self.dt_proj.weight.shape), (self.dt_proj.weight.shape[1], 1), offs[2])
+        wp_out = flat.as_strided((w_out.shape[0], C), (C, 1), offs[3])
         return dict(wt_in=wt_in, small=(w_x, w_dt), w_out=wp_out, A=A)
 
     def python_mamba_inner_fn_no_out_proj(self, xz, A, conv_state, ssm_state, seqlen, conv1d, x_proj, dt_proj, D,
