@@ -594,6 +594,9 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 //     softplus derivative sigmoid(delta_raw) is carried from the prologue (8 registers; round 3), u is
 //     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
 //     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
+#ifndef VMS_BWD_LDS_TR
+#define VMS_BWD_LDS_TR 0   /* 1 (A/B builds): the 4 rows of a wave summed through 4 KB of wave-private LDS instead of v_permlane32/16_swap: -14 % VALU time, +5 % run time at 2 waves per SIMD (profiles/r05_bwd_lds_tr.md) */
+#endif
 template <int W> struct B4 {
     static constexpr int kSG = 2;   // states between two workgroup barriers (= states per slab buffer)
     static constexpr int kPair = kSG * W * 4 * kWave;   // floats of one group of states: [state][wave][4 lane + k]
@@ -602,7 +605,9 @@ template <int W> struct B4 {
     // per-(row, state) records: 16 records of 16 bytes per row + one record of padding -- at a 256-byte pitch the four rows of a
     // wave sit on the same banks, and the record read every state makes (16 lanes of a row, one address) was a 4-way conflict
     static constexpr int kRecPitch = kBN + 1;
-    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4);
+    // wave-private transposition buffer of the 4-row dB / dC sums (VMS_BWD_LDS_TR): [piece = (tensor, element half)][lane] float4 = 4 KB per wave
+    static constexpr int kTr = VMS_BWD_LDS_TR ? W * 4 * 4 * kWave : 0;
+    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4 + kTr);
 };
 
 // DZM (two directions of a bidirectional block in one launch, vms_selective_scan_bwd_dual): 0 = dz from this launch's own
@@ -626,6 +631,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const int j = lane & 15, r = lane >> 4;
     lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * B4<W>::kRecPitch;
     __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
+    lds_f4* const tr4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair + kRows4 * B4<W>::kRecPitch * 4) + quad * (4 * kWave);
     const int wg_per_seg = nblk / n_seg;
     const int seg = bid / wg_per_seg, wg = bid - seg * wg_per_seg;
     const int b = wg % p.batch;
@@ -940,6 +946,23 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             }
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
+#if VMS_BWD_LDS_TR
+            // The 4 rows of the wave summed through LDS (round 5).  v_permlane32/16_swap cost 8.4 cycles of the VALU pipe each
+            // (profiles/r05_microbench_mix.txt: as much as v_exp_f32) -- 12 per state were 100 of the state's ~700 cycles; the LDS
+            // pipe is nearly idle.  Every lane writes its four 16-byte pieces (tensor, element half) to the wave's 4 KB; DPP row
+            // rho then reads piece rho of the four lanes (rows) that share its position group and sums them: it holds tensor
+            // rho >> 1, elements 4 (rho & 1) + k, all 4 rows, as the swaps left it.  Same association as before:
+            // (row 0 + row 2) + (row 1 + row 3).  Wave-private and the LDS executes a wave's accesses in order: no barrier, and the
+            // next state's writes cannot overtake these reads.
+            tr4[lane] = f32x4{vb[0], vb[1], vb[2], vb[3]};
+            tr4[kWave + lane] = f32x4{vb[4], vb[5], vb[6], vb[7]};
+            tr4[2 * kWave + lane] = f32x4{vc[0], vc[1], vc[2], vc[3]};
+            tr4[3 * kWave + lane] = f32x4{vc[4], vc[5], vc[6], vc[7]};
+            const lds_f4* const trs = tr4 + r * kWave + j;
+            const f32x4 q0 = trs[0], q1 = trs[16], q2 = trs[32], q3 = trs[48];
+            const f2 o0 = (f2{q0.x, q0.y} + f2{q2.x, q2.y}) + (f2{q1.x, q1.y} + f2{q3.x, q3.y});
+            const f2 o1 = (f2{q0.z, q0.w} + f2{q2.z, q2.w}) + (f2{q1.z, q1.w} + f2{q3.z, q3.w});
+#else
             // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
             // one asm statement per pair: with all 16 values tied to ONE statement the register allocator gathered them with ~9
             // v_mov per state (167 -> 59 per chunk, 2,511 -> 2,403 VALU instructions; the compiler's own permlane*_swap builtins
@@ -962,6 +985,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 #pragma unroll
             for (int i = 1; i < K / 2; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(t[i + 4]));
             const f2 o0 = f2{t[0], t[1]} + f2{t[4], t[5]}, o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
+#endif
             slab4[(buf * kB4Pair + st * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
                 __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
             {
@@ -1464,6 +1488,27 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
     // wave per SIMD (profiles/r04_dual_bwd.md)
     const bool w8 = (2 * n8) % cus == 0;
     const bool xl = p.x_has_sub == 3;
+    if (B4<8>::kSmem > 64 * 1024 || B4<4>::kSmem > 64 * 1024) {
+        static PerDeviceOnce attrd_once;
+        const hipError_t arc = attrd_once.run([&]() -> hipError_t {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 8, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<8>::kSmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 8, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<8>::kSmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 4, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 4, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem);
+            return e;
+        });
+        if (arc != hipSuccess) {
+            set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed: %s", hipGetErrorString(arc));
+            return VMS_ERR_LAUNCH;
+        }
+    }
     if (w8) {
         const dim3 grid(2 * n8), block(8 * kWave);
         if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 8, true>), grid, block, B4<8>::kSmem, stream, a, b);
@@ -1479,7 +1524,6 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
 }
 
 int launch_scan_bwd_pair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream) {
-    static_assert(B4<8>::kSmem <= 64 * 1024 && B4<4>::kSmem <= 64 * 1024, "the dual launch sets no LDS attribute");
     switch (a.f.dtype) {
         case VMS_BF16: return launch_bpair_dual<bf16_t>(a, b, stream);
         case VMS_F16: return launch_bpair_dual<f16_t>(a, b, stream);

@@ -1157,7 +1157,10 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
 #endif
     const bool mixed = p.reverse_from > 0 && p.reverse_from < p.batch;
     // 64 KB of fp32 B / C + (x_has_sub == 3) 16 KB of parked checkpoints: two workgroups fill a CU's 160 KB exactly
-    const size_t smem_l = sizeof(float) * 2 * kLGroupFloats + (p.x_has_sub == 3 ? sizeof(float) * 2 * kLG * kWave * kLW : 0);
+#ifndef VMS_FWD_LDS_PAD
+#define VMS_FWD_LDS_PAD 0   /* A/B builds (tools/variant.sh): bytes of unused LDS per workgroup = fewer resident waves per SIMD */
+#endif
+    const size_t smem_l = sizeof(float) * 2 * kLGroupFloats + (p.x_has_sub == 3 ? sizeof(float) * 2 * kLG * kWave * kLW : 0) + VMS_FWD_LDS_PAD;
     if (smem_l > 64 * 1024) {
         static PerDeviceOnce attr_once;
         const hipError_t arc = attr_once.run([&]() -> hipError_t {
@@ -1165,10 +1168,10 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
 #define VMS_AL(Z_, R_)                                                                                              \
             if (e == hipSuccess)                                                                                    \
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, false>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 + VMS_FWD_LDS_PAD);   \
             if (e == hipSuccess)                                                                                    \
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, true>),  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 + VMS_FWD_LDS_PAD)
             VMS_AL(true, 0); VMS_AL(true, 1); VMS_AL(true, 2); VMS_AL(false, 0); VMS_AL(false, 1); VMS_AL(false, 2);
 #undef VMS_AL
             return e;
