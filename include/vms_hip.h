@@ -68,7 +68,10 @@ typedef enum { VMS_F32 = 0, VMS_F16 = 1, VMS_BF16 = 2 } vms_dtype;
  * reference takes; the others are fast paths (variable B / C, dstate 16, ...).  FAST, ROWS and the MFMA
  * backward are experiments kept for tests and profiling, present only in a `make EXPERIMENTAL=1` build. */
 typedef enum {
-    VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_FAST = 2, VMS_IMPL_PAIR = 3, VMS_IMPL_ROWS = 4
+    VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_FAST = 2, VMS_IMPL_PAIR = 3, VMS_IMPL_ROWS = 4,
+    /* = PAIR, except that vms_selective_scan_bwd_dual runs its 128-VGPR kernel (csrc/selective_scan_bwd_occ4.hip: 4 waves per SIMD;
+     * round 5, measured 12-15 % slower than the 256-VGPR one -- profiles/r05_bwd_occ4.md -- hence opt-in) where it applies */
+    VMS_IMPL_OCC4 = 5
 } vms_scan_impl;
 #define VMS_BUILD_EXPERIMENTAL 1   /* bit of vms_build_flags(): the FAST / ROWS / MFMA generations are built in */
 

@@ -287,7 +287,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
     if (p.is_complex) return launch_scan_fwd_complex(p, vec, s);
-    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_ROWS && p.segments >= 0, "impl / segments out of range");
+    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_OCC4 && p.segments >= 0, "impl / segments out of range");
     const int level = scan_impl_level(p);
 #ifdef VMS_EXPERIMENTAL
     if (p.x_has_sub == 2) {

@@ -184,12 +184,12 @@ EXPORTS = (
 )
 
 # vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
-# VMS_SCAN_IMPL = generic | fast | pair | rows, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
+# VMS_SCAN_IMPL = generic | fast | pair | rows | occ4, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
 # per call, and travel in the parameter block.
 ABI_VERSION = 10   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
-IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS = 0, 1, 2, 3, 4
+IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS, IMPL_OCC4 = 0, 1, 2, 3, 4, 5
 BUILD_EXPERIMENTAL = 1
-_IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS}
+_IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS, "o": IMPL_OCC4}
 
 
 def scan_impl_from_env():
@@ -558,7 +558,7 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
     ws = None
     if x is None:
         batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
-        ne = rows_x_elems(P) if P.impl >= IMPL_ROWS else 0   # the row-major layout is opt-in
+        ne = rows_x_elems(P) if P.impl == IMPL_ROWS else 0   # the row-major layout is opt-in
         if ne:
             ref = batch * dim * n_chunks * 2 * dstate
             x = torch.empty(X_HEADER + ne, device=u.device, dtype=torch.float32)[X_HEADER:X_HEADER + ref]
@@ -586,7 +586,7 @@ def _fill_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du,
                    ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
-    if Q.f.impl >= IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
+    if Q.f.impl == IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
         Q.f.x_has_sub = 2
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
     Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
