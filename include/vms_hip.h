@@ -63,17 +63,17 @@ typedef enum {
 
 typedef enum { VMS_F32 = 0, VMS_F16 = 1, VMS_BF16 = 2 } vms_dtype;
 
-/* kernel generations of the selective scan: a call runs the highest one that is <= `impl`, built into this
- * library (vms_build_flags) and eligible for the problem; AUTO = PAIR.  GENERIC takes every problem the
- * reference takes; the others are fast paths (variable B / C, dstate 16, ...).  FAST, ROWS and the MFMA
- * backward are experiments kept for tests and profiling, present only in a `make EXPERIMENTAL=1` build. */
+/* kernel generations of the selective scan: a call runs the highest one that is <= `impl` and eligible for the
+ * problem; AUTO = PAIR.  GENERIC takes every problem the reference takes; PAIR is the fast paths (variable B / C,
+ * dstate 16, ...).  FAST and ROWS named the experimental generations of rounds 1-3 (removed in round 5): the values
+ * stay accepted, FAST runs the generic kernels, ROWS what PAIR runs. */
 typedef enum {
     VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_FAST = 2, VMS_IMPL_PAIR = 3, VMS_IMPL_ROWS = 4,
     /* = PAIR, except that vms_selective_scan_bwd_dual runs its 128-VGPR kernel (csrc/selective_scan_bwd_occ4.hip: 4 waves per SIMD;
      * round 5, measured 12-15 % slower than the 256-VGPR one -- profiles/r05_bwd_occ4.md -- hence opt-in) where it applies */
     VMS_IMPL_OCC4 = 5
 } vms_scan_impl;
-#define VMS_BUILD_EXPERIMENTAL 1   /* bit of vms_build_flags(): the FAST / ROWS / MFMA generations are built in */
+#define VMS_BUILD_EXPERIMENTAL 1   /* bit of vms_build_flags(): never set since round 5 (the FAST / ROWS / MFMA generations are gone) */
 
 /* ---- selective scan ------------------------------------------------------------------
  * u, delta, z, out, out_z : (batch, dim, seqlen), unit seqlen stride, free batch/dim strides
@@ -108,10 +108,7 @@ typedef struct {
      * backward kernel walk 128-element chunks; they live in the same allocation, behind the
      * reference-shaped (.., 2*dstate) view the Python layer hands out). */
     int64_t x_chunk_stride;
-    /* x_has_sub == 2: x is dense (pitch 2*dstate) and is FOLLOWED, in the same allocation, by the
-     * "rows" checkpoint region written by the row-major fast kernels: float hck[batch][dim/64][ceil(seqlen/128)]
-     * [dstate][64] = the state BEFORE 128-element chunk c of row (b, 64*rb + lane), in scan order
-     * (dstate == 16, (dim / n_groups) % 64 == 0 only).  vms_scan_x_elems() gives the total size. */
+    /* x_has_sub == 2 (the row-major layout of the experimental kernels of rounds 1-3): rejected since round 5. */
     /* x_has_sub == 3 ("lane checkpoints", ABI v7): the pitch is >= 258*dstate (even; x 8-byte aligned) and
      * x[b,d,c, 2*dstate + ((n/4)*256 + i)*4 + n%4], i = 0..255, holds state n after the first 8*(i+1) elements of chunk c,
      * in scan order (16x the data of x_has_sub == 1, of which every 16th entry is the same 128-element checkpoint).
@@ -211,8 +208,7 @@ int vms_scan_bwd_dual_fused(const vms_scan_bwd_params *a, const vms_scan_bwd_par
  * flags of *p are read */
 int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params *p);
 int64_t vms_scan_bwd_workspace_bytes(const vms_scan_bwd_params *p);
-/* number of floats of an x allocation that carries the "rows" checkpoint region (x_has_sub == 2),
- * or batch*dim*n_chunks*2*dstate when the shape is not eligible */
+/* batch*dim*n_chunks*2*dstate: the floats of the reference-shaped x (kept from the ABI of the row-major layout) */
 int64_t vms_scan_x_elems(const vms_scan_fwd_params *p);
 /* the x pitch (floats between x[b,d,c,:] and x[b,d,c+1,:]) to allocate for this problem; only sizes and flags of *p are
  * read.  mode 0: 2*dstate (the reference's tensor, selective_scan.cpp:313: no fast backward); 1: 18*dstate (x_has_sub == 1);

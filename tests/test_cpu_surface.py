@@ -370,7 +370,7 @@ def test_compiled_binding_speaks_the_packages_abi():
     header = open(os.path.join(ROOT, "include", "vms_hip.h")).read()
     assert int(re.search(r"#define VMS_ABI_VERSION (\d+)", header).group(1)) == vms_hip.ABI_VERSION
     so = os.path.join(ROOT, "video-mamba-suite_amd", "_vms_torch.so")
-    if not os.path.exists(so) or os.environ.get("VMS_NO_TORCH_EXT") == "1" or "VMS_HIP_LIB" in os.environ:
+    if not os.path.exists(so) or vms_hip.debug.no_torch_ext or "VMS_HIP_LIB" in os.environ:
         pytest.skip("compiled binding not built / disabled")
     ext = vms_hip.ext()
     assert ext is not None and ext.abi_version() == vms_hip.ABI_VERSION

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_hip_parity import DEV, TOL, check, rel_err, tol_for
+from test_hip_parity import _dbg, DEV, TOL, check, rel_err, tol_for
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +31,7 @@ def _run_pair(b, d, L, itype, layout1, monkeypatch, seed=0, o4=False):
     if layout1:
         monkeypatch.setenv("VMS_X_LAYOUT", "1")
     if o4:
-        monkeypatch.setenv("VMS_SCAN_IMPL", "occ4")   # vms_hip.h VMS_IMPL_OCC4: the dual call on its 128-VGPR kernel (opt-in)
+        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")   # vms_hip.h VMS_IMPL_OCC4: the dual call on its 128-VGPR kernel (opt-in)
     a, bb = _dir_inputs(b, d, L, itype, seed), _dir_inputs(b, d, L, itype, seed + 1)
     g = torch.Generator(device="cpu").manual_seed(seed + 2)
     z = torch.randn(b, d, L, generator=g).to(itype).to(DEV)
@@ -134,7 +134,7 @@ def test_dual_softplus_extremes(oracle, monkeypatch, o4):
     import selective_scan_cuda as ssc
     import vms_hip
     if o4:
-        monkeypatch.setenv("VMS_SCAN_IMPL", "occ4")
+        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")
     b, d, L = 8, 768, 272
     a, bb = list(_dir_inputs(b, d, L, torch.bfloat16, 50)), list(_dir_inputs(b, d, L, torch.bfloat16, 51))
     g = torch.Generator(device="cpu").manual_seed(52)
@@ -165,7 +165,7 @@ def test_dual_rejects_mismatched_dz():
     import selective_scan_cuda as ssc
     import vms_hip
     if vms_hip.ext() is not None:
-        pytest.skip("argument check of the C entry point: reached through the ctypes binding (VMS_NO_TORCH_EXT=1)")
+        pytest.skip("argument check of the C entry point: reached through the ctypes binding (VMS_DEBUG=no_torch_ext=1)")
     a, bb = _dir_inputs(1, 32, 64, torch.bfloat16, 0), _dir_inputs(1, 32, 64, torch.bfloat16, 1)
     z = torch.randn(1, 32, 64, device=DEV, dtype=torch.bfloat16)
     out, x, _ = ssc.fwd(*a[:6], z, a[6], True)
@@ -207,7 +207,7 @@ def test_dual_with_groups(monkeypatch, o4):
     import selective_scan_cuda as ssc
     import vms_hip
     if o4:
-        monkeypatch.setenv("VMS_SCAN_IMPL", "occ4")
+        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")
     b, d, L, G = 8, 768, 272, 2
     a, bb = list(_dir_inputs(b, d, L, torch.bfloat16, 30)), list(_dir_inputs(b, d, L, torch.bfloat16, 31))
     for t in (a, bb):

@@ -1,11 +1,11 @@
 """scan_fwd_sg_kernel (round 4): few rows, long sequences in ONE pass -- a row's 16 states over the four waves of a workgroup,
-the per-element work shared through LDS -- against the row-per-wave kernel it replaces at those shapes (unsplit: VMS_FWD_SEGMENTS=1)
+the per-element work shared through LDS -- against the row-per-wave kernel it replaces at those shapes (unsplit: vms_hip.debug.fwd_segments = 1)
 and against the f64 oracle.  Reference: the chunk loop of mamba/csrc/selective_scan/selective_scan_fwd_kernel.cuh:131-132, 236-254."""
 import numpy as np
 import pytest
 import torch
 
-from test_hip_parity import DEV, TOL, check, tol_for
+from test_hip_parity import _dbg, DEV, TOL, check, tol_for
 
 pytestmark = pytest.mark.gpu
 
@@ -40,10 +40,10 @@ def test_state_group_forward_equals_row_per_wave(monkeypatch, shape, groups, ity
     zz = z if has_z else None
     sg = ssc.fwd(u, delta, A, B, C, D, zz, bias, True, reverse)
     assert vms_hip.last_kernel() == "scan_fwd_sg", vms_hip.last_kernel()
-    monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+    monkeypatch.setattr(_dbg(), "fwd_segments", int("1"))
     ref = ssc.fwd(u, delta, A, B, C, D, zz, bias, True, reverse)
     assert vms_hip.last_kernel().startswith("scan_fwd_pair"), vms_hip.last_kernel()
-    monkeypatch.delenv("VMS_FWD_SEGMENTS")
+    monkeypatch.setattr(_dbg(), "fwd_segments", 0)
     assert vms_hip.x_layout_of(sg[1], 16) == vms_hip.x_layout_of(ref[1], 16) == (1 if layout1 else 3)
     # same arithmetic per state; y is summed over the states in another order (4 partial sums of 4): an ulp of the 16-bit output
     ulp = 2.0 ** -8 if itype == torch.bfloat16 else 2.0 ** -11
@@ -87,7 +87,7 @@ def test_state_group_forward_accumulates_and_mixes_directions(monkeypatch):
     res = {}
     for tag in ("sg", "rows"):
         if tag == "rows":
-            monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+            monkeypatch.setattr(_dbg(), "fwd_segments", int("1"))
         acc = base.clone()
         o = ssc.fwd(u, delta, A, B, C, D, z, bias, True, True, out_z_into=acc)
         k1 = vms_hip.last_kernel()
@@ -126,14 +126,11 @@ def test_state_group_forward_with_the_reference_shaped_x():
     for tag, seg in (("sg", None), ("rows", "1")):
         out, out_z = torch.empty_like(delta), torch.empty_like(z)
         x = torch.full((b, d, 2, 32), float("nan"), device=DEV)
-        if seg:
-            import os
-            os.environ["VMS_FWD_SEGMENTS"] = seg
+        vms_hip.debug.fwd_segments = int(seg) if seg else 0
         try:
             vms_hip.scan_fwd(u, delta, A, B, C, D, z, bias, out, out_z, x, True)
         finally:
-            if seg:
-                del os.environ["VMS_FWD_SEGMENTS"]
+            vms_hip.debug.fwd_segments = 0
         res[tag] = (out, out_z, x, vms_hip.last_kernel())
     assert res["sg"][3] == "scan_fwd_sg" and res["rows"][3].startswith("scan_fwd_pair"), (res["sg"][3], res["rows"][3])
     assert torch.equal(res["sg"][2], res["rows"][2]) and not torch.isnan(res["sg"][2]).any()

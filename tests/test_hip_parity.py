@@ -12,6 +12,12 @@ import torch
 
 from conftest import golden_names, load_golden
 
+
+def _dbg():
+    """vms_hip.debug: the one object that holds the test / profiling switches of the Python layers (set with monkeypatch.setattr)"""
+    import vms_hip
+    return vms_hip.debug
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda"
@@ -57,14 +63,6 @@ def rel_err(a, ref):
 def check(a, ref, tol, what):
     e = rel_err(a, ref)
     assert e <= tol, f"{what}: rel err {e:.3e} > {tol:.1e}"
-
-
-def need_impl(impl):
-    """The FAST / ROWS / MFMA kernel generations exist only in a `make EXPERIMENTAL=1` library (vms_hip.h)."""
-    import vms_hip
-    if impl in ("rows", "fast") and not vms_hip.has_experimental():
-        pytest.skip("needs the experimental kernel generations: make -C video-mamba-suite_amd/csrc EXPERIMENTAL=1 "
-                    "OUT=../vms_hip/libvms_hip_exp.so and VMS_HIP_LIB=<that file>")
 
 
 def itype_of(g):
@@ -360,9 +358,9 @@ def test_scan_bwd_fast_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
     g = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in g.items()}
     tol = TOL[itype]
     got, want = run_scan(g, itype, oracle)
-    monkeypatch.setenv("VMS_FORCE_GENERIC", "1")
+    monkeypatch.setattr(_dbg(), "force_generic", True)
     got_gen, _ = run_scan(g, itype, oracle)
-    monkeypatch.delenv("VMS_FORCE_GENERIC")
+    monkeypatch.setattr(_dbg(), "force_generic", False)
     for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
         if want.get(k) is not None:
             check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k} vs oracle")
@@ -383,9 +381,9 @@ def test_scan_ragged_lengths_vs_oracle(oracle, shape, itype, has_z, monkeypatch)
     g = _rows_problem(shape, itype, has_z, seed=L)
     tol = TOL[itype]
     got, want = run_scan(g, itype, oracle)
-    monkeypatch.setenv("VMS_FORCE_GENERIC", "1")
+    monkeypatch.setattr(_dbg(), "force_generic", True)
     got_gen, _ = run_scan(g, itype, oracle)
-    monkeypatch.delenv("VMS_FORCE_GENERIC")
+    monkeypatch.setattr(_dbg(), "force_generic", False)
     for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
         if want.get(k) is not None:
             check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k} vs oracle")
@@ -413,40 +411,30 @@ def _rows_problem(shape, itype, has_z, seed=0):
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize("shape", ROWS_SHAPES)
 @pytest.mark.parametrize("has_z", [True, False])
-def test_scan_rows_path_vs_oracle(oracle, shape, itype, has_z, monkeypatch):
-    """The row-major kernels (lane = row, packed state pairs, 128-element chunks; dstate 16,
-    (dim / groups) % 64 == 0, seqlen % 8 == 0): parity with the oracle for outputs and all gradients, and
-    agreement with the generic kernels on the same inputs."""
-    import selective_scan_cuda
-    import vms_hip
-    need_impl("rows")
-    monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
+def test_scan_pair_path_vs_oracle_and_generic(oracle, shape, itype, has_z, monkeypatch):
+    """dstate 16, variable B / C, (dim / groups) % 64 == 0, seqlen % 8 == 0 (the shape family of the row-major kernels of rounds
+    1-3, removed in round 5): the paired kernels' parity with the oracle for outputs and all gradients, and agreement with
+    the generic kernels on the same inputs."""
     g = _rows_problem(shape, itype, has_z)
     tol = TOL[itype]
-    # the raw extension really takes the rows layout for this problem
-    f = lambda k, dt=itype: G(g[k], dt)
-    res = selective_scan_cuda.fwd(f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
-                                  f("z") if has_z else None, f("delta_bias", torch.float32), True)
-    assert res[1].storage_offset() == vms_hip.X_HEADER and res[1].is_contiguous()
     got, want = run_scan(g, itype, oracle)
-    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    monkeypatch.setattr(_dbg(), "scan_impl", "generic")
     got_gen, _ = run_scan(g, itype, oracle)
     for k in ("out", "last_state", "du", "ddelta", "dB", "dC", "dz"):
         if want.get(k) is not None:
             check(got[k], want[k], tol * (2 if k != "out" else 1), f"{k} vs oracle")
-            check(got[k], got_gen[k].detach().float().cpu().numpy(), tol * 2, f"{k} rows vs generic kernel")
+            check(got[k], got_gen[k].detach().float().cpu().numpy(), tol * 2, f"{k} paired vs generic kernel")
     for k in ("dA", "dD", "ddelta_bias"):
         check(got[k], want[k], tol * 5, k)
 
 
-@pytest.mark.parametrize("impl", ["rows", "pair", "fast", "generic"])
+@pytest.mark.parametrize("impl", ["pair", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("shape", [(2, 64, 1024, 1), (1, 128, 2192, 2), (1, 64, 144, 1), (2, 64, 1569, 1)])
 def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     """reverse=True == flip(fwd(flip(every seqlen-indexed tensor))) for every forward implementation."""
     import selective_scan_cuda
-    need_impl(impl)
-    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    monkeypatch.setattr(_dbg(), "scan_impl", impl)
     g = _rows_problem(shape, itype, True, seed=3)
     f = lambda k, dt=itype: G(g[k], dt)
     u, dl, A, B, C, D, z, bias = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
@@ -466,7 +454,7 @@ def test_scan_fwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
 def test_scan_bwd_reverse_equals_flipped(shape, itype, impl, monkeypatch):
     """bwd(reverse=True) == the causal backward on flipped copies, gradients flipped back."""
     import selective_scan_cuda
-    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    monkeypatch.setattr(_dbg(), "scan_impl", impl)
     g = _rows_problem(shape, itype, True, seed=7)
     f = lambda k, dt=itype: G(g[k], dt)
     u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
@@ -524,12 +512,12 @@ def test_scan_fwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, r
     u, dl, A, B, C, D, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"), f("D", torch.float32),
                                      f("delta_bias", torch.float32), f("g"))
     z = f("z") if has_z else None
-    monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+    monkeypatch.setattr(_dbg(), "fwd_segments", int("1"))
     plain = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
     if segments is None:
-        monkeypatch.delenv("VMS_FWD_SEGMENTS")
+        monkeypatch.setattr(_dbg(), "fwd_segments", 0)
     else:
-        monkeypatch.setenv("VMS_FWD_SEGMENTS", segments)
+        monkeypatch.setattr(_dbg(), "fwd_segments", int(segments))
     split = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
     tol = 2e-5 if itype == torch.float32 else 1e-2
     for name, a, b_ in zip(("out", "x", "out_z"), split, plain):
@@ -558,12 +546,12 @@ def test_scan_bwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, r
     z = f("z") if has_z else None
     res = selective_scan_cuda.fwd(u, dl, A, B, C, D, z, bias, True, reverse)
     out, x = res[0], res[1]
-    monkeypatch.setenv("VMS_BWD_SEGMENTS", "1")
+    monkeypatch.setattr(_dbg(), "bwd_segments", int("1"))
     plain = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out if has_z else None, None, True, has_z, reverse)
     if segments is None:
-        monkeypatch.delenv("VMS_BWD_SEGMENTS")
+        monkeypatch.setattr(_dbg(), "bwd_segments", 0)
     else:
-        monkeypatch.setenv("VMS_BWD_SEGMENTS", segments)
+        monkeypatch.setattr(_dbg(), "bwd_segments", int(segments))
     split = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out if has_z else None, None, True, has_z, reverse)
     names = ("du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias", "dz", "out_z")
     tol = 2e-5 if itype == torch.float32 else 1e-2
@@ -572,14 +560,13 @@ def test_scan_bwd_sequence_split_equals_unsplit(shape, segments, itype, has_z, r
         check(a, b_.float().cpu().numpy(), tol * wide, name)
 
 
-@pytest.mark.parametrize("impl", ["pair", "fast", "generic"])
+@pytest.mark.parametrize("impl", ["pair", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_scan_bwd_accumulates_dz(itype, impl, reverse, monkeypatch):
     """accumulate_dz (vms_hip.h dz_accumulate): dz += this call's gradient, in every backward kernel."""
     import selective_scan_cuda
-    need_impl(impl)
-    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    monkeypatch.setattr(_dbg(), "scan_impl", impl)
     g = _rows_problem((2, 64, 1160, 1), itype, True, seed=11)
     f = lambda k, dt=itype: G(g[k], dt)
     u, dl, A, B, C, D, z, bias, dout = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
@@ -599,15 +586,14 @@ def test_scan_bwd_accumulates_dz(itype, impl, reverse, monkeypatch):
         selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse, accumulate_dz=True)
 
 
-@pytest.mark.parametrize("impl", ["rows", "pair", "fast", "generic"])
+@pytest.mark.parametrize("impl", ["pair", "generic"])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_scan_fwd_accumulates_out_z(itype, impl, reverse, monkeypatch):
     """out_z_into (vms_hip.h out_z_accumulate): out_z += this call's gated output; out and x are unchanged.  With
     the rows kernels selected the call is served by the next eligible kernel."""
     import selective_scan_cuda
-    need_impl(impl)
-    monkeypatch.setenv("VMS_SCAN_IMPL", impl)
+    monkeypatch.setattr(_dbg(), "scan_impl", impl)
     g = _rows_problem((2, 64, 1168, 1), itype, True, seed=13)
     f = lambda k, dt=itype: G(g[k], dt)
     u, dl, A, B, C, D, z, bias = (f("u"), f("delta"), f("A", torch.float32), f("B"), f("C"),
@@ -684,31 +670,6 @@ def test_bidirectional_node_equals_two_nodes(itype):
     check(out_a, out_b.float().detach().cpu().numpy(), tol, "out")
     for i, (a, b_) in enumerate(zip(g_a, g_b)):
         check(a, b_.float().cpu().numpy(), tol * (1 if i == 0 else 5), f"grad {i}")
-
-
-def test_scan_rows_checkpoint_region(oracle, monkeypatch):
-    """x returned by the rows forward: reference-shaped slots plus the chunk-start states that follow them
-    in the same allocation (include/vms_hip.h, x_has_sub == 2)."""
-    import selective_scan_cuda
-    import vms_hip
-    need_impl("rows")
-    monkeypatch.setenv("VMS_SCAN_IMPL", "rows")
-    g = _rows_problem((2, 128, 2448, 2), torch.float32, True, seed=5)
-    f = lambda k: G(g[k])
-    out, x, out_z = selective_scan_cuda.fwd(f("u"), f("delta"), f("A"), f("B"), f("C"), f("D"), f("z"), f("delta_bias"), True)
-    b, d, L, N = 2, 128, 2448, 16
-    nch = (L + 127) // 128
-    o = oracle.scan_fwd(g["u"], g["delta"], g["A"], g["B"], g["C"], g["D"], g["z"], g["delta_bias"], True, prec="f64")
-    check(x, o["x"], 1e-3, "reference-shaped x (mid + end slots)")
-    ref = x.numel()
-    full = torch.empty(0, device=DEV).set_(x.untyped_storage(), vms_hip.X_HEADER + ref, (b, d // 64, nch, N, 64))
-    for c in (1, 7, 16, 19):
-        t = oracle.scan_fwd(*(g[k][..., :c * 128] for k in ("u", "delta")), g["A"], g["B"][..., :c * 128],
-                            g["C"][..., :c * 128], g["D"], g["z"][..., :c * 128], g["delta_bias"], True, prec="f64")
-        got = full[:, :, c].permute(0, 1, 3, 2).reshape(b, d, N)  # (b, rb, lane, n) -> (b, d, n)
-        check(got, t["last_state"], 1e-3, f"state before chunk {c}")
-    assert float(full[:, :, 0].abs().max()) == 0.0
-
 
 
 # 2064 / 2304 / 1280 / 256 / 64: a last chunk of <= 256 elements -- the LDS forward's four-states-at-a-time tail form; 2512 / 1296: a
@@ -877,21 +838,21 @@ def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
             f("delta_bias", torch.float32), True)
     selective_scan_cuda.fwd(*args)
     assert vms_hip.last_kernel() == "scan_fwd_pair_lds+split"   # 64 rows: fewer waves than SIMDs -> ranges of chunks
-    monkeypatch.setenv("VMS_FWD_SEGMENTS", "1")
+    monkeypatch.setattr(_dbg(), "fwd_segments", int("1"))
     out, x, _ = selective_scan_cuda.fwd(*args)
     assert vms_hip.last_kernel() == "scan_fwd_pair_lds"         # the default kernel of whole-vector rows (B / C through LDS)
-    monkeypatch.setenv("VMS_BWD_SEGMENTS", "1")
+    monkeypatch.setattr(_dbg(), "bwd_segments", int("1"))
     selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
     assert vms_hip.last_kernel() == "scan_bwd_pair4"            # ... and of the backward (4 rows per wave)
-    monkeypatch.delenv("VMS_BWD_SEGMENTS")
+    monkeypatch.setattr(_dbg(), "bwd_segments", 0)
     selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
     assert vms_hip.last_kernel() == "scan_bwd_pair4+split"      # 2 workgroups for 256 CUs: the kernel's own choice is to split
-    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    monkeypatch.setattr(_dbg(), "scan_impl", "generic")
     out, x, _ = selective_scan_cuda.fwd(*args)
     assert vms_hip.last_kernel() == "scan_fwd_generic"
     selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
     assert vms_hip.last_kernel() == "scan_bwd_generic"
-    monkeypatch.delenv("VMS_SCAN_IMPL")
+    monkeypatch.setattr(_dbg(), "scan_impl", None)
     # dstate 8 is outside the fast paths: the generic kernels take it, and say so
     A8 = -torch.rand(64, 8, device=DEV)
     B8 = torch.randn(1, 1, 8, 16384, device=DEV, dtype=torch.bfloat16)
@@ -1164,9 +1125,9 @@ def test_compiled_inner_node_equals_python_node(variant, shape, monkeypatch):
             y = m(h)
         return y, torch.autograd.grad(y, [h] + params, gout)
     y1, g1 = run()
-    monkeypatch.setenv("VMS_NO_INNER_EXT", "1")
+    monkeypatch.setattr(_dbg(), "no_inner_ext", True)
     y2, g2 = run()
-    monkeypatch.delenv("VMS_NO_INNER_EXT")
+    monkeypatch.setattr(_dbg(), "no_inner_ext", False)
     assert torch.equal(y1, y2)
     for (k, _), a, c in zip([("dh", None)] + list(m.named_parameters()), g1, g2):
         check(a, c, 1e-2, f"grad {k}: compiled node vs Python node")   # bf16: one ulp of the fp32-atomics noise

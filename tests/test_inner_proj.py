@@ -366,7 +366,7 @@ def test_proj_kred_checks():
 def test_inner_node_variants_vs_library(shape, variant, reverse, monkeypatch):
     """The fused inner node (conv -> x_proj -> dt_proj -> scan, and its backward) with its small GEMMs on the hand-written
     kernels -- the default one-pass backward tail (vms_proj_conv_bwd), the opt-in one-for-one MFMA projections
-    (VMS_MFMA_PROJ=1), and both -- vs the same node on library GEMMs + vms_causal_conv1d_bwd (VMS_NO_FUSED_TAIL=1):
+    (vms_hip.debug.mfma_proj), and both -- vs the same node on library GEMMs + vms_causal_conv1d_bwd (debug.no_fused_tail):
     outputs and every gradient within the bf16 bar."""
     import vms_hip
     from mamba_ssm.ops.selective_scan_interface import mamba_inner_fn_no_out_proj
@@ -385,13 +385,11 @@ def test_inner_node_variants_vs_library(shape, variant, reverse, monkeypatch):
     params = (conv_w, conv_b, x_proj_w, dt_proj_w, A, D, bias)
 
     def run(env):
-        for k in ("VMS_MFMA_PROJ", "VMS_NO_FUSED_TAIL"):
-            monkeypatch.delenv(k, raising=False)
         import mamba_ssm.ops.selective_scan_interface as ssi
+        import vms_hip
         monkeypatch.setattr(ssi, "_PROJ_KRED", "NO_KRED" not in env)   # the library-GEMM node also runs x_proj / dt_proj^T on the library
-        for k in env:
-            if k != "NO_KRED":
-                monkeypatch.setenv(k, "1")
+        monkeypatch.setattr(vms_hip.debug, "mfma_proj", True if "VMS_MFMA_PROJ" in env else None)
+        monkeypatch.setattr(vms_hip.debug, "no_fused_tail", "VMS_NO_FUSED_TAIL" in env)
         xz = xz0.clone().requires_grad_()
         for t in params:
             t.grad = None

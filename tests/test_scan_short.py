@@ -5,6 +5,12 @@ import numpy as np
 import pytest
 import torch
 
+
+def _dbg():
+    """vms_hip.debug: the one object that holds the test / profiling switches of the Python layers (set with monkeypatch.setattr)"""
+    import vms_hip
+    return vms_hip.debug
+
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
@@ -80,7 +86,7 @@ def test_short_rows_equal_long_row_kernels(monkeypatch, itype, L):
     assert vms_hip.last_kernel() == "scan_fwd_short"
     g = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, res[1], res[0], None, True, True)
     assert vms_hip.last_kernel() == "scan_bwd_short"
-    monkeypatch.setenv("VMS_SCAN_IMPL", "generic")
+    monkeypatch.setattr(_dbg(), "scan_impl", "generic")
     ref = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True)
     assert vms_hip.last_kernel() == "scan_fwd_generic"
     gr = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, ref[1], ref[0], None, True, True)

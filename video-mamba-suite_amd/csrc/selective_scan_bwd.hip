@@ -28,8 +28,6 @@ bool scan_bwd_pair_dual_fusable(const vms_scan_bwd_params& a, const vms_scan_bwd
 int launch_scan_bwd_pair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream);
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q);
 int64_t scan_bwd_pair_ws_bytes(const vms_scan_bwd_params& q);
-bool scan_bwd_mfma_eligible(const vms_scan_bwd_params& q, bool vec);
-int launch_scan_bwd_mfma(const vms_scan_bwd_params& q, hipStream_t stream);
 
 int launch_scan_bwd_complex(const vms_scan_bwd_params& q, bool vec, hipStream_t stream);   // selective_scan_complex.hip
 bool scan_bwd_short_eligible(const vms_scan_bwd_params& q);                                  // selective_scan_short.hip
@@ -414,12 +412,6 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     // short rows (selective_scan_short.hip): the states are rebuilt from h = 0 in the lane, x is not read
     if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_bwd_short_eligible(q)) return launch_scan_bwd_short(q, s);
     if (level >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
-#ifdef VMS_EXPERIMENTAL
-    if (level >= VMS_IMPL_FAST && !p.reverse && scan_bwd_mfma_eligible(q, vec)) {
-        set_last_kernel("scan_bwd_mfma");
-        return launch_scan_bwd_mfma(q, s);
-    }
-#endif
     set_last_kernel("scan_bwd_generic");
     switch (p.dtype) {
         case VMS_F32: return dispatch_bwd<float, 16>(q, vec, s);

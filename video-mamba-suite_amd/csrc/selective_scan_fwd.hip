@@ -191,13 +191,6 @@ int validate_scan_common(const vms_scan_fwd_params& p) {
     return VMS_OK;
 }
 
-bool scan_fwd_fast_eligible(const vms_scan_fwd_params& p, bool vec);
-int launch_scan_fwd_fast(const vms_scan_fwd_params& p, hipStream_t stream);
-bool scan_rows_eligible(const vms_scan_fwd_params& p);
-int64_t scan_rows_hck_elems(const vms_scan_fwd_params& p);
-int64_t scan_rows_fwd_ws_bytes(const vms_scan_fwd_params& p);
-int launch_scan_fwd_rows(const vms_scan_fwd_params& p, hipStream_t stream);
-
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec);
 bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p);   // selective_scan_bwd_pair.hip
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p);
@@ -289,28 +282,10 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     if (p.is_complex) return launch_scan_fwd_complex(p, vec, s);
     VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_OCC4 && p.segments >= 0, "impl / segments out of range");
     const int level = scan_impl_level(p);
-#ifdef VMS_EXPERIMENTAL
-    if (p.x_has_sub == 2) {
-        // the caller laid x out for the row-major kernels: nothing else fills its checkpoint region
-        VMS_CHECK(level >= VMS_IMPL_ROWS && vec && scan_rows_eligible(p), "x_has_sub == 2 needs a problem the rows kernels accept");
-        VMS_CHECK(p.x_chunk_stride == 0 || p.x_chunk_stride == 2 * p.dstate, "x_has_sub == 2 needs a dense x");
-        VMS_CHECK(p.workspace != nullptr && aligned16(p.workspace) && p.workspace_bytes >= scan_rows_fwd_ws_bytes(p),
-                  "workspace of vms_scan_fwd_workspace_bytes() bytes is required with x_has_sub == 2");
-        set_last_kernel("scan_fwd_rows");
-        return launch_scan_fwd_rows(p, s);
-    }
-#else
-    VMS_CHECK(p.x_has_sub != 2, "x_has_sub == 2 (rows layout) needs a library built with EXPERIMENTAL=1");
-#endif
+    VMS_CHECK(p.x_has_sub != 2, "x_has_sub == 2 (the row-major layout of rounds 1-3) is no longer built");
     // short rows, many of them (TimeMamba's scans along time: seqlen 4 ... 16, batch x 196 rows per channel): a lane per row
     if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_short_eligible(p)) return launch_scan_fwd_short(p, s);
     if (level >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(p, vec)) return launch_scan_fwd_pair(p, s);
-#ifdef VMS_EXPERIMENTAL
-    if (level >= VMS_IMPL_FAST && scan_fwd_fast_eligible(p, vec)) {
-        set_last_kernel("scan_fwd_fast");
-        return launch_scan_fwd_fast(p, s);
-    }
-#endif
     set_last_kernel("scan_fwd_generic");
     switch (p.dtype) {
         case VMS_F32: return dispatch_fwd<float, 16>(p, vec, s);
@@ -329,9 +304,6 @@ extern "C" int64_t vms_scan_fwd_workspace_bytes(const vms_scan_fwd_params* p) {
         return wl + wh > 0 ? round256(wl) + wh : 0;
     }
     const int level = scan_impl_level(*p);
-#ifdef VMS_EXPERIMENTAL
-    if (level >= VMS_IMPL_ROWS && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return scan_rows_fwd_ws_bytes(*p);
-#endif
     // the paired kernel's (P, q) state carries when it wants to split long rows into ranges
     if (level >= VMS_IMPL_PAIR && scan_fwd_pair_eligible(*p, true) && scan_fwd_pair_segments(*p) > 1)
         return scan_fwd_pair_ws_bytes(*p);
@@ -352,8 +324,5 @@ extern "C" int64_t vms_scan_x_pitch(const vms_scan_fwd_params* pp, int32_t mode)
 extern "C" int64_t vms_scan_x_elems(const vms_scan_fwd_params* p) {
     if (p == nullptr) return 0;
     const int64_t ref = (int64_t)p->batch * p->dim * p->n_chunks * 2 * p->dstate;
-#ifdef VMS_EXPERIMENTAL
-    if (scan_impl_level(*p) >= VMS_IMPL_ROWS && scan_rows_eligible(*p) && scan_fwd_vec_ok(*p)) return ref + scan_rows_hck_elems(*p);
-#endif
     return ref;
 }

@@ -181,7 +181,6 @@ std::vector<Tensor> scan_fwd(const Tensor& u, const Tensor& delta, const Tensor&
     const ScanDims s = scan_checks(u, delta, A, B, C, D_, z_, delta_bias_);
     // before the workspace query and the allocations: the split decision reads the CU count of the CURRENT device
     c10::DeviceGuard guard(u.device());
-    TORCH_CHECK(impl != VMS_IMPL_ROWS, "the row-major layout (VMS_SCAN_IMPL=rows) is served by the ctypes binding");
     Tensor out = at::empty_like(delta);   // inherits delta's (d-slowest) layout, selective_scan.cpp:310-311
     OptT out_z;
     if (z_.has_value()) out_z = at::empty_like(*z_);

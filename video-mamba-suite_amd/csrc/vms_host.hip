@@ -40,7 +40,7 @@ int device_cu_count() {
 extern "C" const char* vms_last_error(void) { return vms::last_error(); }
 extern "C" const char* vms_last_kernel(void) { return vms::g_kernel; }
 extern "C" int vms_abi_version(void) { return VMS_ABI_VERSION; }
-extern "C" int vms_build_flags(void) { return vms::kExperimental ? VMS_BUILD_EXPERIMENTAL : 0; }
+extern "C" int vms_build_flags(void) { return 0; }   // (bit VMS_BUILD_EXPERIMENTAL: the kernel generations of rounds 1-3, removed in round 5)
 extern "C" int vms_sizeof_scan_fwd_params(void) { return (int)sizeof(vms_scan_fwd_params); }
 extern "C" int vms_sizeof_scan_bwd_params(void) { return (int)sizeof(vms_scan_bwd_params); }
 extern "C" int vms_sizeof_conv_fwd_params(void) { return (int)sizeof(vms_conv_fwd_params); }

@@ -32,19 +32,21 @@ from mamba_ssm.ops.triton.layernorm import RMSNorm, layer_norm_fn, rms_norm_fn
 from mamba_ssm.ops.triton.selective_state_update import selective_state_update, selective_state_update_ref
 
 
-# VMS_NO_REVERSE=1: run the backward direction the reference's way (flipped copies through the causal ops)
-_USE_REVERSE_KERNELS = os.environ.get("VMS_NO_REVERSE", "0") != "1"
+from vms_hip import debug as _dbg   # the switches below take their defaults from it (vms_hip.debug.__doc__; VMS_DEBUG at import)
+
+# debug.no_reverse: run the backward direction the reference's way (flipped copies through the causal ops)
+_USE_REVERSE_KERNELS = not _dbg.no_reverse
 # Recompute policy of the fused nodes.  The reference rebuilds conv_out and delta in backward (checkpoint_lvl=1,
 # selective_scan_interface.py:167, written for 40-80 GB parts); with 288 GB of HBM per MI355X the blocks keep
 # them (2 x batch x d_inner x seqlen elements per direction) and skip a conv forward and a GEMM per direction.
 # VMS_CHECKPOINT_LVL=1 restores the reference's policy; the values are identical either way.
 _CHECKPOINT_LVL = int(os.environ.get("VMS_CHECKPOINT_LVL", "0"))
 # The DBM block as ONE node on a batch of 2 B whose second half is scanned right-to-left (vms_hip.h reverse_from), with
-# the stacking and un-stacking folded into the projections' weight layouts.  VMS_DBM_TWO_NODES=1: one node per direction.
-_DBM_STACKED = os.environ.get("VMS_DBM_TWO_NODES", "0") != "1"
+# the stacking and un-stacking folded into the projections' weight layouts.  debug.dbm_two_nodes: one node per direction.
+_DBM_STACKED = not _dbg.dbm_two_nodes
 # The block's per-step parameter preparation (weight casts, in_proj's transposed copy, -exp(A_log)) as one launch
-# (vms_param_prep).  VMS_NO_PARAM_PREP=1: every node prepares its own, one small kernel per tensor.
-_PARAM_PREP = os.environ.get("VMS_NO_PARAM_PREP", "0") != "1"
+# (vms_param_prep).  debug.no_param_prep: every node prepares its own, one small kernel per tensor.
+_PARAM_PREP = not _dbg.no_param_prep
 
 
 # Ragged sequences (the suite's T x 196 + 1 tokens with a cls token: 1569, 3137) are padded to the next multiple of 16 INSIDE the
@@ -52,9 +54,9 @@ _PARAM_PREP = os.environ.get("VMS_NO_PARAM_PREP", "0") != "1"
 # Every kernel of the block then runs its whole-vector form -- the one-grid backward of both directions, the LDS forward with lane
 # checkpoints, the fused conv1d + x_proj head -- instead of the element-wise ragged ones: a 2-layer (8, 3137, 768) stack 4.62 ->
 # 3.3 ms per step, the aligned (8, 3136, 768) one 3.04; also on the host the padded step is the cheaper one (fewer launches: a
-# 2-layer stack at (1, 65, 768), all host time, 3.1 -> 2.3 ms).  VMS_NO_SEQ_PAD=1: ragged rows as they come.
-_SEQ_PAD = 0 if os.environ.get("VMS_NO_SEQ_PAD", "0") == "1" else 16
-_SEQ_PAD_TILES = os.environ.get("VMS_SEQ_PAD_TILES", "1") != "0"   # extend the padding to a GEMM-friendly token count (_seq_padding)
+# 2-layer stack at (1, 65, 768), all host time, 3.1 -> 2.3 ms).  debug.no_seq_pad: ragged rows as they come.
+_SEQ_PAD = 0 if _dbg.no_seq_pad else 16
+_SEQ_PAD_TILES = not _dbg.no_seq_pad_tiles   # extend the padding to a GEMM-friendly token count (_seq_padding)
 _SEQ_PAD_FP32 = False   # tests: pad fp32 activations too (the arithmetic of the padding checked without 16-bit rounding)
 
 

@@ -27,7 +27,7 @@ def _autocast_dtype():
     return torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype()
 
 
-_SUM_SLICES = __import__("os").environ.get("VMS_NO_SUM_SLICES", "0") != "1"   # =1: torch's reduction (A/B)
+_SUM_SLICES = True   # False (tests / A/B: monkeypatch.setattr): torch's reduction instead of vms_sum_slices
 _mm_out_dtype_ok = [None]   # does torch.mm(a, b, out_dtype=torch.float32) work for 16-bit operands on this build / device?
 
 

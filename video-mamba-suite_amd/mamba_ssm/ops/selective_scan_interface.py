@@ -160,19 +160,19 @@ def _inner_ext_module():
 def _inner_ext(xz, out_proj, A_b, B, C, B_proj_bias, C_proj_bias):
     """The compiled one-call form of the node (vms_torch.cpp inner_fwd / inner_bwd) when it applies: GPU tensors, the
     binding built, input-dependent B / C without projection biases, one direction, no fused out_proj -- what every module
-    of the suite runs.  VMS_NO_INNER_EXT=1 keeps the Python statement of the node (tests compare the two)."""
+    of the suite runs.  debug.no_inner_ext keeps the Python statement of the node (tests compare the two)."""
     if (out_proj is not None or A_b is not None or B is not None or C is not None or B_proj_bias is not None
-            or C_proj_bias is not None or not xz.is_cuda or os.environ.get("VMS_NO_INNER_EXT") == "1"):
+            or C_proj_bias is not None or not xz.is_cuda or _vms.debug.no_inner_ext):
         return None
     ext = _vms.ext()
-    if ext is None or not hasattr(ext, "inner_fwd") or _vms.scan_impl_from_env() >= _vms.IMPL_ROWS:
+    if ext is None or not hasattr(ext, "inner_fwd"):
         return None
     return ext
 
 
 # Bit 16 of proj_flags: x_dbl = x_proj.weight @ conv1d_out and dx_dbl[:R] = dt_proj.weight^T @ ddelta -- the node's two products
 # that contract over the channels -- as one streaming pass on the matrix cores (vms_proj_kred) instead of library GEMMs.
-_PROJ_KRED = os.environ.get("VMS_PROJ_KRED", "1") != "0"
+_PROJ_KRED = not _vms.debug.no_proj_kred
 
 
 def _mfma_proj(d_inner=None, dt_rank=None):
@@ -181,15 +181,14 @@ def _mfma_proj(d_inner=None, dt_rank=None):
     shape (d_inner 1024, dt_rank 64) the two are at parity (4.20-4.25 vs 4.26 ms per block step, profiles/r03_small_gemms.md, r04y);
     where dt_rank is not a multiple of 64 or d_inner not one of 256 -- every d_model 768 / 512 / 384 config of the suite -- the
     library picks poor tiles (38 and 36 us per call at (8, 768, 3136) for 1.9 GFLOP over 39 MB) and the hand-written ones win:
-    12-layer stack 20.3 -> 19.5 ms, long video 3.90 -> 3.88 (profiles/r04_mfma_proj_ab.txt).  VMS_MFMA_PROJ=1 / 0 forces.
-    Bit 2 (default on; VMS_NO_FUSED_TAIL=1 clears it): the backward's tail -- dx_proj.weight, dconv1d_out += W_x^T dx_dbl and the
+    12-layer stack 20.3 -> 19.5 ms, long video 3.90 -> 3.88 (profiles/r04_mfma_proj_ab.txt).  debug.mfma_proj = True / False forces.
+    Bit 2 (default on; debug.no_fused_tail clears it): the backward's tail -- dx_proj.weight, dconv1d_out += W_x^T dx_dbl and the
     conv1d backward -- as ONE pass over the activations (vms_proj_conv_bwd) instead of three kernels and seven."""
-    env = os.environ.get("VMS_MFMA_PROJ")
-    if env in ("0", "1"):
-        mfma = env == "1"
+    if _vms.debug.mfma_proj is not None:
+        mfma = bool(_vms.debug.mfma_proj)
     else:
         mfma = d_inner is not None and (d_inner % 256 != 0 or dt_rank % 64 != 0)
-    return (1 if mfma else 0) | (0 if os.environ.get("VMS_NO_FUSED_TAIL") == "1" else 2) | (16 if _PROJ_KRED else 0)
+    return (1 if mfma else 0) | (0 if _vms.debug.no_fused_tail else 2) | (16 if _PROJ_KRED else 0)
 
 
 def _for_backward(ctx):
@@ -495,7 +494,7 @@ def _inner_backward(ctx, dout, dxz_into=None):
                 dB_proj_bias=dB_proj_bias, dC_proj_bias=dC_proj_bias)
 
 
-_DUAL_BWD = os.environ.get("VMS_NO_DUAL_BWD", "0") != "1"   # =1: one backward-scan launch per direction (A/B, tests)
+_DUAL_BWD = not _vms.debug.no_dual_bwd   # debug.no_dual_bwd: one backward-scan launch per direction (A/B, tests)
 
 
 def _inner_backward_dual(first, second, dout):
@@ -606,7 +605,7 @@ class NegExpFn(torch.autograd.Function):
         return g * a, None   # d(-exp(x)) = -exp(x) dx
 
 
-_DUAL_CONV = os.environ.get("VMS_NO_DUAL_CONV", "0") != "1"   # =1: one conv1d launch per direction (A/B, tests)
+_DUAL_CONV = not _vms.debug.no_dual_conv   # debug.no_dual_conv: one conv1d launch per direction (A/B, tests)
 
 
 def _dual_conv(xz, conv_w, conv_b, conv_w_b, conv_b_b):
@@ -629,7 +628,7 @@ def _dual_conv(xz, conv_w, conv_b, conv_w_b, conv_b_b):
     return o, ob
 
 
-_CONV_XPROJ = os.environ.get("VMS_NO_CONV_XPROJ", "0") != "1"   # =1: conv1d and x_proj of a bidirectional block as separate launches (A/B, tests)
+_CONV_XPROJ = not _vms.debug.no_conv_xproj   # debug.no_conv_xproj: conv1d and x_proj of a bidirectional block as separate launches (A/B, tests)
 
 
 def _conv_xproj_dual(xz, conv_w, conv_b, conv_w_b, conv_b_b, x_proj_w, x_proj_w_b):

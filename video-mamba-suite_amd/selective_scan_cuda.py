@@ -103,7 +103,7 @@ def fwd(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse=False, o
         return _fwd_complex(u, delta, A, B, C, D_, z_, delta_bias_, delta_softplus, reverse, out_z_into, reverse_from)
     ext = _k.ext()
     impl = _k.scan_impl_from_env()
-    if ext is not None and impl != _k.IMPL_ROWS:   # compiled binding: same checks / allocations / launch in C++
+    if ext is not None:   # compiled binding: same checks / allocations / launch in C++
         if bc_pad is None:
             B, C, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         return ext.scan_fwd(u, delta, A, B, C, D_, z_, delta_bias_, bool(delta_softplus), bool(reverse), out_z_into,
@@ -241,7 +241,7 @@ def bwd(u, delta, A, B, C, D_, z_, delta_bias_, dout, x_, out_, dz_, delta_softp
     impl = _k.scan_impl_from_env()
     if A.is_complex():
         bc_pad = 0
-    if ext is not None and impl != _k.IMPL_ROWS:
+    if ext is not None:
         if bc_pad is None:
             Bk, Ck, bc_pad = pad_bc(B, C, reverse, reverse_from > 0)
         else:
@@ -268,7 +268,7 @@ def bwd_dual(dir_a, dir_b, z, dout, dz_, delta_softplus, zeroed_a=None, zeroed_b
     impl = _k.scan_impl_from_env()
     Bka, Cka, pad_a = pad_bc(Ba, Ca, False)
     Bkb, Ckb, pad_b = pad_bc(Bb, Cb, True)
-    if ext is not None and impl != _k.IMPL_ROWS and hasattr(ext, "scan_bwd_dual"):
+    if ext is not None and hasattr(ext, "scan_bwd_dual"):
         ra, rb = ext.scan_bwd_dual(ua, da, Aa, Bka, Cka, Da, ba, xa, oa, zeroed_a, Ba, Ca,
                                    ub, db, Ab, Bkb, Ckb, Db, bb, xb, ob, zeroed_b, Bb, Cb,
                                    z, dout, dz_, bool(delta_softplus), bool(keep_fp32), bool(accumulate_dz), pad_a, pad_b, impl,

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VMS_HIP_LIB", os.path.join(_HERE, "libvms_hip.so"))  # env: A/B builds in tools/
+_DEFAULT_LIB = os.path.join(_HERE, "libvms_hip.so")
+LIB_PATH = os.environ.get("VMS_HIP_LIB", _DEFAULT_LIB)  # env: A/B builds in tools/
 
 VMS_F32, VMS_F16, VMS_BF16 = 0, 1, 2
 _DTYPE = {torch.float32: VMS_F32, torch.float16: VMS_F16, torch.bfloat16: VMS_BF16}
@@ -183,30 +184,85 @@ EXPORTS = (
     "vms_conv_xproj_dual", "vms_sizeof_conv_xproj_dual_params", "vms_layer_norm_bwd_finish", "vms_sum_slices",
 )
 
-# vms_hip.h vms_scan_impl.  The library reads no environment variable (ABI v4): the test / profiling knobs
-# VMS_SCAN_IMPL = generic | fast | pair | rows | occ4, VMS_FORCE_GENERIC, VMS_FWD_SEGMENTS / VMS_BWD_SEGMENTS are read HERE,
-# per call, and travel in the parameter block.
 ABI_VERSION = 10   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
 IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS, IMPL_OCC4 = 0, 1, 2, 3, 4, 5
-BUILD_EXPERIMENTAL = 1
 _IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS, "o": IMPL_OCC4}
 
 
+class _Debug:
+    """Every test / profiling switch of the Python layers, in one place (`vms_hip.debug`).  Tests set attributes with
+    `monkeypatch.setattr(vms_hip.debug, name, value)`; A/B runs of the tools pass `VMS_DEBUG="name=value,name=value"`, parsed
+    ONCE at import.  The C ABI reads no environment at all (kernel generation and range counts travel in the parameter block).
+    User-facing environment variables are only VMS_HIP_LIB (another build of the library), VMS_X_LAYOUT (checkpoint layout policy:
+    1 | 3 | auto) and VMS_CHECKPOINT_LVL (the modules' recompute policy).
+
+    scan_impl        None | "generic" | "pair" | "occ4": vms_scan_impl of every scan call (vms_hip.h; None = the library's choice)
+    force_generic    every scan on the generic kernels (the reference's full contract)
+    fwd_segments     forced range count of the sequence-split forward scan (0 = the library's choice, 1 = never split)
+    bwd_segments     the same for the backward scan
+    no_torch_ext     serve every call through the ctypes binding instead of the compiled one (_vms_torch.so)
+    no_inner_ext     the fused inner nodes as Python compositions instead of the compiled one-call node
+    mfma_proj        True / False: the inner node's dt_proj products on the hand-written MFMA kernels / the library; None = by shape
+    no_fused_tail    the backward's tail as three kernels (library GEMMs + conv1d backward) instead of vms_proj_conv_bwd
+    no_proj_kred     x_proj / d_dt as library GEMMs instead of vms_proj_kred
+    no_dual_bwd      one backward-scan launch per direction of a bidirectional block
+    no_dual_conv     one conv1d launch per direction
+    no_conv_xproj    conv1d and x_proj of a bidirectional block as separate launches
+    no_reverse       modules: the backward direction on flipped copies (the reference's way) instead of the kernels' reverse mode
+    dbm_two_nodes    the DBM block as one node per direction instead of the stacked one-node form
+    no_param_prep    every node prepares its own parameters instead of one vms_param_prep launch per block
+    no_seq_pad       ragged sequences as they come instead of padded to whole vectors inside the mixer
+    no_seq_pad_tiles pad to the next multiple of 16 only (not up to whole 256-token GEMM tiles)
+    """
+    scan_impl = None
+    force_generic = False
+    fwd_segments = 0
+    bwd_segments = 0
+    no_torch_ext = False
+    no_inner_ext = False
+    mfma_proj = None
+    no_fused_tail = False
+    no_proj_kred = False
+    no_dual_bwd = False
+    no_dual_conv = False
+    no_conv_xproj = False
+    no_reverse = False
+    dbm_two_nodes = False
+    no_param_prep = False
+    no_seq_pad = False
+    no_seq_pad_tiles = False
+
+    def __init__(self, spec=""):
+        for item in filter(None, (t.strip() for t in spec.split(","))):
+            k, _, v = item.partition("=")
+            if not hasattr(type(self), k):
+                raise ValueError(f"VMS_DEBUG: unknown switch {k!r} (see vms_hip.debug.__doc__)")
+            cur = getattr(type(self), k)
+            if k == "scan_impl":
+                val = v or None
+            elif k == "mfma_proj":
+                val = None if v == "" else v not in ("0", "false", "False")
+            elif isinstance(cur, bool):
+                val = v not in ("0", "false", "False")
+            else:
+                val = int(v)
+            setattr(self, k, val)
+
+
+debug = _Debug(os.environ.get("VMS_DEBUG", ""))
+
+
 def scan_impl_from_env():
-    if "VMS_FORCE_GENERIC" in os.environ:
+    """vms_scan_impl of the next scan call (name kept from the time this read the environment per call: see `debug`)"""
+    if debug.force_generic:
         return IMPL_GENERIC
-    e = os.environ.get("VMS_SCAN_IMPL")
+    e = debug.scan_impl
     return IMPL_AUTO if not e else _IMPL_NAMES.get(e[0], IMPL_AUTO)
 
 
 def _segments_from_env(name):
-    e = os.environ.get(name)
-    return max(int(e), 1) if e else 0
-
-
-def has_experimental():
-    """True when the loaded library carries the FAST / ROWS / MFMA kernel generations (make EXPERIMENTAL=1)."""
-    return bool(lib().vms_build_flags() & BUILD_EXPERIMENTAL)
+    n = debug.fwd_segments if "FWD" in name else debug.bwd_segments
+    return max(int(n), 1) if n else 0
 
 
 def last_kernel():
@@ -222,12 +278,12 @@ _ext = False   # the compiled PyTorch binding (_vms_torch.so, csrc/torch_binding
 
 
 def ext():
-    """The compiled binding of the scan / conv entry points, or None when it has not been built (or VMS_NO_TORCH_EXT=1):
+    """The compiled binding of the scan / conv entry points, or None when it has not been built (or debug.no_torch_ext):
     the ctypes path below then serves every call.  Both end in the same C ABI."""
     global _ext
     if _ext is False:
         _ext = None
-        if os.environ.get("VMS_NO_TORCH_EXT") != "1" and "VMS_HIP_LIB" not in os.environ:   # A/B libraries: ctypes only
+        if not debug.no_torch_ext and LIB_PATH == _DEFAULT_LIB:   # A/B libraries (VMS_HIP_LIB): ctypes only
             lib()
             try:
                 import _vms_torch
@@ -521,20 +577,6 @@ def fill_scan_fwd(P, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_s
         P.C_d_stride, P.C_dstate_stride = C.stride(0), C.stride(1)
 
 
-X_HEADER = 64  # floats in front of a rows-layout x allocation: its storage offset is how bwd recognises it
-
-
-def rows_x_elems(P):
-    """floats of the x allocation the row-major kernels want for the problem in P (reference part +
-    checkpoint region), or 0 when they do not apply."""
-    ref = P.batch * P.dim * P.n_chunks * 2 * P.dstate
-    n = lib().vms_scan_x_elems(ctypes.byref(P))
-    return n if n > ref else 0
-
-
-def is_rows_x(x, n_elems):
-    return (n_elems > 0 and x is not None and x.is_contiguous() and x.storage_offset() == X_HEADER
-            and x.untyped_storage().nbytes() == (X_HEADER + n_elems) * 4)
 
 
 def _ws_bytes(fn_name, params, ref_tensor):
@@ -558,21 +600,12 @@ def scan_fwd(u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus,
     ws = None
     if x is None:
         batch, dim, n_chunks, dstate = P.batch, P.dim, P.n_chunks, P.dstate
-        ne = rows_x_elems(P) if P.impl == IMPL_ROWS else 0   # the row-major layout is opt-in
-        if ne:
-            ref = batch * dim * n_chunks * 2 * dstate
-            x = torch.empty(X_HEADER + ne, device=u.device, dtype=torch.float32)[X_HEADER:X_HEADER + ref]
-            x = x.view(batch, dim, n_chunks, 2 * dstate)
-            ws = torch.empty(_ws_bytes("vms_scan_fwd_workspace_bytes", P, u), device=u.device, dtype=torch.uint8)
-            P.x, P.x_chunk_stride, P.x_has_sub = _ptr(x), 2 * dstate, 2
-            P.workspace, P.workspace_bytes = _ptr(ws), ws.numel()
-        else:
-            # the reference-shaped tensor is a view of a wider buffer whose tail carries 128-element
-            # sub-checkpoints for the backward kernel (include/vms_hip.h)
-            pitch = lib().vms_scan_x_pitch(ctypes.byref(P), x_mode_for(u, dstate, for_backward))
-            x = torch.empty(batch, dim, n_chunks, pitch, device=u.device, dtype=torch.float32)[..., :dstate * 2]
-            P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
-            P.x_has_sub = x_layout_of(x, dstate)
+        # the reference-shaped tensor is a view of a wider buffer whose tail carries the checkpoints for the backward
+        # kernel (include/vms_hip.h)
+        pitch = lib().vms_scan_x_pitch(ctypes.byref(P), x_mode_for(u, dstate, for_backward))
+        x = torch.empty(batch, dim, n_chunks, pitch, device=u.device, dtype=torch.float32)[..., :dstate * 2]
+        P.x, P.x_chunk_stride = _ptr(x), x.stride(2)
+        P.x_has_sub = x_layout_of(x, dstate)
     if not P.workspace:
         nws = _ws_bytes("vms_scan_fwd_workspace_bytes", P, u)   # state carries of a sequence-split forward
         if nws > 0:
@@ -586,8 +619,6 @@ def _fill_scan_bwd(u, delta, A, B, C, D, z, delta_bias, dout, x, out, out_z, du,
                    ddelta_bias, dz, delta_softplus, reverse=False, dz_accumulate=False, bc_pad=0, reverse_from=0):
     Q = ScanBwdParams()
     fill_scan_fwd(Q.f, u, delta, A, B, C, D, z, delta_bias, out, out_z, x, delta_softplus, reverse, reverse_from)
-    if Q.f.impl == IMPL_ROWS and is_rows_x(x, rows_x_elems(Q.f)):
-        Q.f.x_has_sub = 2
     Q.dout, Q.du, Q.ddelta, Q.dz = _ptr(dout), _ptr(du), _ptr(ddelta), _ptr(dz)
     Q.dA, Q.dB, Q.dC, Q.dD, Q.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
     Q.dout_batch_stride, Q.dout_d_stride = dout.stride(0), dout.stride(1)
