@@ -254,6 +254,46 @@ def gen_inner(ssi, name, kind, batch=2, dim=32, dstate=8, dt_rank=6, L=128, W=3,
          dD=npf(D.grad), ddelta_bias=npf(dt_bias.grad))
 
 
+def gen_inner768(ssi, name):
+    """The reference's own inner-function problem (test_selective_scan.py:152-199: dim 768, dstate 8, dt_rank 48, L 128, W 3) for
+    constant / variable B and C, real / complex A, with and without the projection biases (recipes.py).  The inputs are NOT
+    stored (rebuilt from the seed by the tests; their checksums are): the fixture holds every k-th element of the output and of
+    EVERY gradient the function returns, plus each tensor's sum and sum of squares."""
+    from recipes import INNER768_CASES, checksum, inner768_inputs, sample
+    fn, var_B, var_C, is_complex, pbias = INNER768_CASES[name]
+    t = inner768_inputs(var_B, var_C, is_complex, pbias)
+    leaves = {k: v.clone().requires_grad_() for k, v in t.items() if v is not None and not k.startswith("g_")}
+    a = lambda k: leaves.get(k)
+    if fn == "out_proj":
+        out = ssi.mamba_inner_ref(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                  a("out_proj_weight"), None, a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                  B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        g = t["g_out_proj"]
+    elif fn == "bi":
+        out = ssi.bimamba_inner_ref(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                    a("out_proj_weight"), None, a("A"), a("A_b"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                    B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        g = t["g_out_proj"]
+    else:
+        out = ssi.mamba_inner_fn_no_out_proj(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                             a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                             B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        g = t["g_no_out_proj"]
+    out.backward(g)
+    arrs = {}
+    for k, v in t.items():
+        if v is not None:
+            arrs["in_sum." + k] = np.array(checksum(v))
+    o, stride = sample(out.detach(), 16384)
+    arrs["out"], arrs["out.stride"], arrs["out.sums"] = o.numpy(), np.array(stride), np.array(checksum(out.detach()))
+    for k, v in leaves.items():
+        if v.grad is None:   # (A_b outside the bidirectional function, out_proj_weight outside the functions with an out_proj)
+            continue
+        sm, stride = sample(v.grad)
+        arrs["d" + k], arrs["d" + k + ".stride"], arrs["d" + k + ".sums"] = sm.numpy(), np.array(stride), np.array(checksum(v.grad))
+    save(name, **arrs)
+
+
 def gen_block(mods, name, which, d_model=32, L=33, batch=2, expand=2, d_state=8, seed=0, **kw):
     """Reference nn.Module forward+backward on CPU; state_dict + input + output + grads."""
     torch.random.manual_seed(seed)
@@ -384,6 +424,14 @@ def gen_norm(refs, name, shape, is_rms, has_residual, has_bias, prenorm, itype=t
 
 def main():
     torch.set_num_threads(8)
+    if os.environ.get("GOLDEN_ONLY") == "inner768":  # add the reference-shape inner-function fixtures without touching the others
+        sys.path.insert(0, HERE)
+        from recipes import INNER768_CASES
+        cci, ssi = load_reference()
+        load_reference_modules(ssi)
+        for name in INNER768_CASES:
+            gen_inner768(ssi, name)
+        return
     if os.environ.get("GOLDEN_ONLY") == "ssu":
         ref = load_reference_state_update_ref()
         gen_state_update(ref, "ssu_N16_full", 3, 70, 16, True, True, True, True, seed=1)
@@ -461,6 +509,10 @@ def main():
     gen_inner(ssi, "inner_out_proj", "out_proj")
     gen_inner(ssi, "inner_no_out_proj", "no_out_proj")
     gen_inner(ssi, "inner_bi", "bi")
+    sys.path.insert(0, HERE)
+    from recipes import INNER768_CASES
+    for name in INNER768_CASES:
+        gen_inner768(ssi, name)
     print("blocks:")
     gen_block(mods, "block_vim", "simple")
     gen_block(mods, "block_vim_div", "simple", if_devide_out=True, L=257, batch=1)

@@ -164,6 +164,56 @@ def test_fused_inner_host_logic(fake_extensions, kind):
             assert err <= 5e-4 * max(1.0, ref_g.abs().max().item()), (k, err)
 
 
+@pytest.mark.parametrize("name", ["inner768_out_proj_B0C0_f32", "inner768_out_proj_B0C1_f32", "inner768_out_proj_B1C0_f32_pbias",
+                                  "inner768_no_out_proj_B1C1_f32_pbias", "inner768_bi_B1C1_f32_pbias", "inner768_bi_B0C0_f32",
+                                  "inner768_out_proj_B1C1_c64_pbias"])
+def test_inner768_host_logic(fake_extensions, name):
+    """The nodes' branches that no suite model takes -- constant B / C, the projection biases (SSI:164, 324, 358-359), the
+    bidirectional function with either -- at the reference's own test problem (test_selective_scan.py:152-199), over the
+    oracle-backed extension stand-ins: the host side of tests/test_hip_parity.py::test_inner768_vs_reference_fixtures."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from recipes import INNER768_CASES, checksum, inner768_inputs, sample
+    fn, var_B, var_C, is_complex, pbias = INNER768_CASES[name]
+    g = load_golden(name)
+    t = inner768_inputs(var_B, var_C, is_complex, pbias)
+    for k, v in t.items():
+        if v is not None:
+            np.testing.assert_allclose(np.array(checksum(v)), g["in_sum." + k], rtol=1e-10, err_msg=f"input {k} differs from the fixture's")
+    leaves = {k: v.clone().requires_grad_() for k, v in t.items() if v is not None and not k.startswith("g_")}
+    a = leaves.get
+    if fn == "out_proj":
+        out = ssi.mamba_inner_fn(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                 a("out_proj_weight"), None, a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                 B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_out_proj"]
+    elif fn == "bi":
+        out = ssi.bimamba_inner_fn(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                   a("out_proj_weight"), None, a("A"), a("A_b"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                   B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_out_proj"]
+    else:
+        out = ssi.mamba_inner_fn_no_out_proj(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                             a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                             B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_no_out_proj"]
+
+    def cmp(got, key, tol):
+        sm, stride = sample(got.detach(), 16384 if key == "out" else 8192)
+        assert stride == int(g[key + ".stride"]), key
+        ref = torch.from_numpy(g[key])
+        assert (sm - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), key
+
+    cmp(out, "out", 1e-3)
+    out.backward(gout)
+    for k, leaf in leaves.items():
+        if "d" + k in g:
+            assert leaf.grad is not None, f"no gradient for {k}"
+            cmp(leaf.grad, "d" + k, 2e-3)
+        else:
+            assert leaf.grad is None or float(leaf.grad.abs().max()) == 0.0, k
+
+
 @pytest.mark.parametrize("name,which,kw", [
     ("block_vim", "mamba_simple", dict(bimamba_type="v2")),
     ("block_vim_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),

@@ -6,6 +6,9 @@ plus size-independent checks at BASELINE.json's full size.
 Tolerances (BASELINE.json north_star): 1e-3 for fp32 I/O, 1e-2 for bf16 I/O, relative to the
 tensor's scale (max |ref|); reductions over L*batch (dA, dD, dbias, dweight) get the factor the
 reference's own tests give them (test_selective_scan.py:137-149)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -1264,7 +1267,7 @@ def test_conv_update(oracle, name, itype):
 
 
 def test_scan_deterministic_outputs():
-    """The scan's non-atomic results -- out, out_z, the checkpoints x, du, ddelta, dz -- are bit-identical over 1,000
+    """The scan's non-atomic results -- out, out_z, the checkpoints x, du, ddelta, dz -- are bit-identical over 10,000
     forward + backward repeats (what test_causal_conv1d_race_condition asks of the conv, asked of the scan); dA / dB /
     dC / dD / ddelta_bias (fp32 atomics) agree to 1e-4 of their scale."""
     import selective_scan_cuda
@@ -1278,7 +1281,7 @@ def test_scan_deterministic_outputs():
         r = selective_scan_cuda.bwd(u, dl, A, B, C, D, z, bias, dout, x, out, None, True, False, keep_fp32=True)
         return [out, x, oz, r[0], r[1], r[7]], [r[2], r[3], r[4], r[5], r[6]]
     det0, at0 = run()
-    for it in range(1000):
+    for it in range(10000):
         det, at = run()
         for a, b_ in zip(det, det0):
             assert torch.equal(a, b_), it
@@ -1287,29 +1290,30 @@ def test_scan_deterministic_outputs():
                 assert (a - b_).abs().max() <= 1e-4 * b_.abs().max()
 
 
-def test_conv_deterministic_outputs():
-    """test_causal_conv1d_race_condition (test_causal_conv1d.py:117-173): out and dx are bit-identical across 1,000
-    repeats (the reference runs 10,000; same check, bounded run time); dweight/dbias (fp32 atomics) agree to 1e-4
-    relative."""
+@pytest.mark.parametrize("channel_last", [True, False])
+def test_conv_deterministic_outputs(channel_last):
+    """test_causal_conv1d_race_condition (causal-conv1d/tests/test_causal_conv1d.py:117-173) with its own 10,000 repeats, its
+    layouts (channel-last = the case it runs, a dim not divisible by 64 sliced out of a wider buffer; and the L-contiguous slice
+    it keeps commented out) and its tolerances: out and dx bit-identical to the first run every time, dweight / dbias (fp32
+    atomics over batch x L) within atol 1e-4 ... of a scale-relative 1e-4 (theirs is absolute at |dw| ~ 100).  dim is 520 here
+    instead of 4128 so that 10,000 forward + backward pairs stay within seconds."""
     from causal_conv1d import causal_conv1d_fn
     torch.manual_seed(0)
-    x = torch.randn(2, 2048, 512 + 8, device=DEV, dtype=torch.bfloat16)[:, :, :512].transpose(1, 2).requires_grad_()
-    w = torch.randn(512, 4, device=DEV, requires_grad=True)
-    b = torch.randn(512, device=DEV, requires_grad=True)
-    g = torch.randn(2, 512, 2048, device=DEV, dtype=torch.bfloat16)
-    first = None
-    for it in range(1000):
-        for t in (x, w, b):
-            t.grad = None
+    dim, L = 512 + 8, 2048
+    if channel_last:
+        x = torch.randn(2, L, 64 + dim + 24, device=DEV, dtype=torch.bfloat16)[:, :, 64:64 + dim].transpose(1, 2).requires_grad_()
+    else:
+        x = torch.randn(2, 64 + dim + 24, L, device=DEV, dtype=torch.bfloat16)[:, 64:64 + dim, :].requires_grad_()
+    w = torch.randn(dim, 4, device=DEV, requires_grad=True)
+    b = torch.randn(dim, device=DEV, requires_grad=True)
+    out0 = causal_conv1d_fn(x, w, b, "silu")
+    g = torch.randn_like(out0)
+    dx0, dw0, db0 = torch.autograd.grad(out0, (x, w, b), g)
+    for it in range(10000):
         out = causal_conv1d_fn(x, w, b, "silu")
-        out.backward(g)
-        if first is None:
-            first = (out.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
-            continue
-        assert torch.equal(out, first[0]) and torch.equal(x.grad, first[1]), it
-        if it % 100 == 0:
-            assert (w.grad - first[2]).abs().max() <= 1e-4 * first[2].abs().max()
-            assert (b.grad - first[3]).abs().max() <= 1e-4 * first[3].abs().max()
+        dx, dw, db = torch.autograd.grad(out, (x, w, b), g)
+        assert torch.equal(out, out0) and torch.equal(dx, dx0), it
+        assert (dw - dw0).abs().max() <= 1e-4 * dw0.abs().max() and (db - db0).abs().max() <= 1e-4 * db0.abs().max(), it
 
 
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16, torch.float32])
@@ -1408,6 +1412,66 @@ def test_fused_inner_vs_golden(kind):
     for k in INNER_KEYS:
         if "d" + k in g:
             check(t[k].grad, g["d" + k], 5e-3, "d" + k)
+
+
+def _inner768_cases():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from recipes import INNER768_CASES
+    return sorted(INNER768_CASES)
+
+
+@pytest.mark.parametrize("name", _inner768_cases())
+def test_inner768_vs_reference_fixtures(name):
+    """The three inner functions at the reference's OWN test problem (mamba/tests/ops/test_selective_scan.py:152-249: dim 768,
+    dstate 8, dt_rank 48, L 128, W 3, batch 2, seed 0) over its grid -- constant / variable B and C, real / complex A -- plus what
+    that test leaves out: the projection biases (SSI:164, 324, 358-359: dB_proj_bias = dB.sum over (batch, L)), the
+    no-out-proj and the bidirectional function.  Expected values: the reference's mamba_inner_ref / bimamba_inner_ref on CPU
+    (tests/golden/make_golden.py gen_inner768; the fixture holds every k-th element + sum and sum of squares of the output and of
+    EVERY gradient).  Every gradient slot the reference returns is asserted (the reference's test only prints them)."""
+    from recipes import INNER768_CASES, checksum, inner768_inputs, sample
+    from mamba_ssm.ops import selective_scan_interface as ssi
+    fn, var_B, var_C, is_complex, pbias = INNER768_CASES[name]
+    g = load_golden(name)
+    t = inner768_inputs(var_B, var_C, is_complex, pbias)
+    for k, v in t.items():   # the same problem as the generator's (torch's CPU generator, same seed, same order)
+        if v is not None:
+            np.testing.assert_allclose(np.array(checksum(v)), g["in_sum." + k], rtol=1e-10, err_msg=f"input {k} differs from the fixture's")
+    leaves = {k: v.to(DEV).requires_grad_() for k, v in t.items() if v is not None and not k.startswith("g_")}
+    a = leaves.get
+    if fn == "out_proj":
+        out = ssi.mamba_inner_fn(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                 a("out_proj_weight"), None, a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                 B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_out_proj"]
+    elif fn == "bi":
+        out = ssi.bimamba_inner_fn(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                   a("out_proj_weight"), None, a("A"), a("A_b"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                   B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_out_proj"]
+    else:
+        out = ssi.mamba_inner_fn_no_out_proj(a("xz"), a("conv1d_weight"), a("conv1d_bias"), a("x_proj_weight"), a("delta_proj_weight"),
+                                             a("A"), a("B"), a("C"), a("D"), delta_bias=a("delta_bias"),
+                                             B_proj_bias=a("B_proj_bias"), C_proj_bias=a("C_proj_bias"), delta_softplus=True)
+        gout = t["g_no_out_proj"]
+
+    def cmp(got, key, tol):
+        got = got.detach().cpu()
+        sm, stride = sample(got, 16384 if key == "out" else 8192)
+        assert stride == int(g[key + ".stride"]), key
+        check(sm, g[key], tol, key + " (sampled elements)")
+        s_got, s_ref = np.array(checksum(got)), g[key + ".sums"]
+        # sum of squares: a whole-tensor check of what the samples skip (2 x the element tolerance on the norm)
+        assert abs(np.sqrt(s_got[1]) - np.sqrt(s_ref[1])) <= 2 * tol * np.sqrt(s_ref[1]), f"{key}: norm {np.sqrt(s_got[1])} vs {np.sqrt(s_ref[1])}"
+
+    assert out.shape == tuple(gout.shape)
+    cmp(out, "out", 2e-3)
+    out.backward(gout.to(DEV))
+    for k, leaf in leaves.items():
+        if "d" + k in g:
+            assert leaf.grad is not None, f"no gradient for {k}"
+            cmp(leaf.grad, "d" + k, 5e-3 if k in ("xz",) else 1e-2)
+        else:   # (A_b outside the bidirectional function, out_proj_weight of the function without one)
+            assert leaf.grad is None or float(leaf.grad.abs().max()) == 0.0, k
 
 
 @pytest.mark.parametrize("name,which,kw", [

@@ -374,8 +374,13 @@ def _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_pro
         assert not A_b.is_complex(), "A should not be complex!!"
         # the second scan reads the same tensors in the opposite direction (the reference flips copies of
         # all of them, SSI:499-507); its outputs come back in the original order
+        # (A CONSTANT B / C is (dim, dstate): the reference's `.flip([-1])` of every scan input, SSI:506, reverses its STATES for the
+        # second direction -- state n of that scan meets B[:, dstate - 1 - n].  Odd, but it is what the function returns; the drop-in
+        # does the same, test_inner768_vs_reference_fixtures[inner768_bi_B0C0_f32].)
+        B_b = B if ctx.is_variable_B else B.flip(-1).contiguous()
+        C_b = C if ctx.is_variable_C else C.flip(-1).contiguous()
         out_b, ckpt_b, out_z_b = selective_scan_cuda.fwd(
-            conv_out, delta, A_b, B, C, D, z, delta_bias, delta_softplus, not reverse, for_backward=_for_backward(ctx))
+            conv_out, delta, A_b, B_b, C_b, D, z, delta_bias, delta_softplus, not reverse, for_backward=_for_backward(ctx))
         out_z = out_z + out_z_b
         saved_b = (A_b, ckpt_b, out_b)
 
@@ -443,14 +448,16 @@ def _inner_backward(ctx, dout, dxz_into=None):
     out_z = out_z[0] if out_z else None
     dA_b = None
     if ctx.bidirectional:
+        B_b = B if ctx.is_variable_B else B.flip(-1).contiguous()   # (constant B / C: the second scan saw the states reversed, forward)
+        C_b = C if ctx.is_variable_C else C.flip(-1).contiguous()
         dconv_b, ddelta_b, dA_b, dB_b, dC_b, dD_b, ddelta_bias_b, dz_b, *out_z_b = selective_scan_cuda.bwd(
-            conv_out, delta, A_b, B, C, D, z, delta_bias, dy,
+            conv_out, delta, A_b, B_b, C_b, D, z, delta_bias, dy,
             ckpt_b, out_b, dz, ctx.delta_softplus, want_out_z, not ctx.reverse,
             zeroed=zeros[n_scan:2 * n_scan], keep_fp32=True, accumulate_dz=True)
         dconv_out = dconv_out + dconv_b
         ddelta = ddelta + ddelta_b
-        dB = dB + dB_b
-        dC = dC + dC_b
+        dB = dB + (dB_b if ctx.is_variable_B else dB_b.flip(-1))
+        dC = dC + (dC_b if ctx.is_variable_C else dC_b.flip(-1))
         if dD is not None:
             dD = dD + dD_b
         if ddelta_bias is not None:
