@@ -118,6 +118,15 @@ def main():
     body = insts[t:i + 1]
     h = collections.Counter(classify(x) for x in body)
     nops = sum(int(x.split()[1]) + 1 for x in body if x.startswith("s_nop"))
+    if "--nest" in opt:   # --nest=K:M: loop K lies inside the selected loop and runs M times per iteration of it
+        k, m = (int(v) for v in opt["--nest"].split(":"))
+        t2, i2 = loops[k]
+        assert t <= t2 and i2 <= i, "the nested loop must lie inside the selected one"
+        inner = insts[t2:i2 + 1]
+        hi = collections.Counter(classify(x) for x in inner)
+        for key, v in hi.items(): h[key] += (m - 1) * v
+        nops += (m - 1) * sum(int(x.split()[1]) + 1 for x in inner if x.startswith("s_nop"))
+        print(f"\n(loop [{t2}, {i2}] = {len(inner)} instructions counted {m} times)")
     print(f"\nloop [{t}, {i}]: {len(body)} instructions, s_nop wait states {nops}; counts per 1/{per:g} of an iteration")
     print(f"| class | per iteration | per 1/{per:g} | price (cyc) | pipe cycles per 1/{per:g} |\n|---|---|---|---|---|")
     tot_v = tot_c = 0
