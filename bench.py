@@ -57,7 +57,7 @@ DDP_BUCKET_MB = 4
 # HBM bytes per call from the PMC passes of the same kernels at the config's size (FETCH_SIZE x2 + WRITE_SIZE, separate
 # rocprofv3 --pmc runs, main and carry kernels added up per entry point: tools/measure_cfg.sh, tools/pmc_table.py); a profile of
 # the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r04_{config}_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_{config}_traffic.json")
 
 
 def profiled_traffic(kernel, config="block"):

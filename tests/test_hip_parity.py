@@ -2106,6 +2106,40 @@ def test_block_param_prep_equals_per_node_casts(monkeypatch, d_model, b, L, kw):
     assert torch.isfinite(h32.grad).all()
 
 
+def test_prep_plan_rekeys_on_geometry_and_runs_from_two_threads():
+    """ADVICE r4 on the cached per-module preparation plan (vms_hip.PrepPlan): (a) a source re-viewed with another shape at the
+    SAME address must not reuse the cached rows / strides (the key is (data_ptr, shape, stride, dtype)); (b) run() builds its own
+    parameter block per call: two threads preparing into different buffers at once each get their own result."""
+    import threading
+    import vms_hip
+    torch.manual_seed(0)
+    w = torch.randn(64, 48, device=DEV)
+    plan = vms_hip.PrepPlan([(w, 0, 0, (64, 48), (48, 1), torch.bfloat16, vms_hip.PREP_CAST)])
+    assert plan.matches([w])
+    assert not plan.matches([w.view(48, 64)])          # same address, other geometry
+    assert not plan.matches([w.view(32, 96)[:, :48]])  # same address, other strides
+    outs = [torch.zeros(64 * 48, device=DEV, dtype=torch.bfloat16) for _ in range(2)]
+    errs = []
+
+    def work(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(200):
+                    plan.run((outs[k].data_ptr(),), outs[k])
+            s.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for o in outs:
+        assert torch.equal(o.view(64, 48), w.to(torch.bfloat16))
+
+
 # =================================================================================================
 # both conv directions in one pass (vms_causal_conv1d_fwd_dual)
 # =================================================================================================

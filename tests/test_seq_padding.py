@@ -158,3 +158,18 @@ def test_padding_block_stack_matches_ragged(monkeypatch):
     assert _rel(o1, o0) < 2e-2 and _rel(dh1, dh0) < 3e-2
     for a, b in zip(g1, g0):
         assert _rel(a, b) < 3e-2
+
+
+@pytest.mark.gpu
+def test_padded_path_returns_a_contiguous_tensor():
+    """the padded path used to return out[:, :seqlen], a non-contiguous slice of the padded result -- downstream code that
+    .view()s the block's output (the reference mixer returns a contiguous (B, L, D) tensor) failed for ragged lengths only."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(0)
+    m = Mamba(64, d_state=16, expand=1, bimamba_type="v2").cuda()
+    x = torch.randn(3, 197, 64, device="cuda", dtype=torch.bfloat16)
+    assert m._seq_padding(x) == 11
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = m(x)
+    assert y.shape == (3, 197, 64) and y.is_contiguous()
+    y.view(3 * 197, 64)   # what a caller may do with the reference's output

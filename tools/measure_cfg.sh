@@ -14,10 +14,10 @@ B="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_
 D="GRBM_GUI_ACTIVE GRBM_COUNT"
 for cfg in "$@"; do
   cd $R
-  python bench.py --config $cfg --no-cpu-baseline 2>/dev/null | tail -1 > $O/${cfg}_bench.json
+  python bench.py --config $cfg --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > $O/${cfg}_bench.json
   KB_SHAPE=${SHAPE[$cfg]} python tools/kbench.py fwd bwd ${DUAL[$cfg]} 2>&1 | grep -v amdgpu.ids > $O/${cfg}_kbench.txt
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $cfg --steps 10 --warmup 20 --no-projections --no-cpu-baseline > $O/${cfg}_prof.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $cfg --steps 10 --warmup 20 --no-projections --no-cpu-baseline --no-extra-configs > $O/${cfg}_prof.log 2>&1
   python $R/tools/prof_summary.py $O/prof/p_kernel_stats.csv 30 > $O/${cfg}_kernel_stats.md
   python $R/tools/step_trace.py $O/prof/p_kernel_trace.csv 10 > $O/${cfg}_step_trace.txt 2>/dev/null
   rm -rf $O/prof

@@ -236,14 +236,20 @@ __device__ __forceinline__ void scan_bwd_o4_body(const vms_scan_bwd_params& q, c
             const float bias = (*rowc).y;
             float dD_acc = 0.f;
             float dy[K], dlv[K];
+            // (ONE branch on the launch-uniform flag around the whole loop: inside it the compiler kept a branch per element, and the
+            // eight exp -> rcp -> log chains of a lane ran one behind the other)
+            if (p.delta_softplus) {
+#pragma unroll
+                for (int i = 0; i < K; ++i) dlv[i] = softplusf_(pdt.at(i) + bias);
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) dlv[i] = pdt.at(i) + bias;
+            }
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 dy[i] = ok ? pdo.at(i) : 0.f;   // past the end: c = 0, a = 1 (identity for the suffix scan)
-                float t = pdt.at(i) + bias;
-                if (p.delta_softplus) t = softplusf_(t);
-                t = ok ? t : 0.f;
-                dlv[i] = t;
-                if (i > 0) sdt += t;
+                dlv[i] = ok ? dlv[i] : 0.f;
+                if (i > 0) sdt += dlv[i];
             }
             {
                 float dzv[K];
@@ -391,7 +397,17 @@ __device__ __forceinline__ void scan_bwd_o4_body(const vms_scan_bwd_params& q, c
         {
             const float Dd = (*rowc).x;
             float dbias_acc = 0.f;
-            float duv[K], ddl[K];
+            float duv[K], ddl[K], sgv[K];
+            if (p.delta_softplus) {   // (one branch for the eight elements, as in the prologue)
+#pragma unroll
+                for (int i = 0; i < K; ++i) {
+                    const float dl = dl2[i / 2][i % 2];
+                    sgv[i] = dl < 9.765625e-4f ? dl * fmaf(-0.5f, dl, 1.f) : 1.f - fast_exp(-dl);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; ++i) sgv[i] = 1.f;
+            }
 #pragma unroll
             for (int i = 0; i < K; ++i) {
                 const float dl = dl2[i / 2][i % 2];
@@ -400,8 +416,7 @@ __device__ __forceinline__ void scan_bwd_o4_body(const vms_scan_bwd_params& q, c
                 // delta.  sigmoid(t) = 1 - exp(-softplus(t)) (exact identity; 1 above the reference's threshold of 20 by itself), as
                 // delta (1 - delta / 2) where the subtraction would cancel; u = (delta u) / delta, 0 where delta underflowed to 0
                 // (there sigmoid is 0 too: the reference's ddelta is ~1e-45 x (...) = 0).
-                float sg = 1.f;
-                if (p.delta_softplus) sg = dl < 9.765625e-4f ? dl * fmaf(-0.5f, dl, 1.f) : 1.f - fast_exp(-dl);
+                const float sg = sgv[i];
                 const float uv = dl > 0.f ? dlu2[i / 2][i % 2] * fast_rcp(dl) : 0.f;
                 duv[i] = fmaf(dl, s1, Dd * dy2[i / 2][i % 2]);
                 ddl[i] = fmaf(uv, s1, s2) * sg;

@@ -88,17 +88,6 @@ __device__ __forceinline__ void store_row(T* __restrict__ row, int L, const floa
     }
 }
 
-// the wave's sum of v in lane 63 (4 in-row DPP steps + 2 row broadcasts)
-__device__ __forceinline__ float wave_sum_to_last(float v) {
-    v += dpp_mov<DPP_ROW_SHR1, 0xf>(0.f, v);
-    v += dpp_mov<DPP_ROW_SHR2, 0xf>(0.f, v);
-    v += dpp_mov<DPP_ROW_SHR4, 0xf>(0.f, v);
-    v += dpp_mov<DPP_ROW_SHR8, 0xf>(0.f, v);
-    v += dpp_mov<DPP_ROW_BCAST15, 0xa>(0.f, v);
-    v += dpp_mov<DPP_ROW_BCAST31, 0xc>(0.f, v);
-    return v;
-}
-
 // 2 x LP per-lane values -> their sums over the wave, as a reduce-scatter: v_permlane32_swap on pairs (a swap + an add halve the
 // count: lanes 0-31 then hold the first value of the pair summed over both halves, lanes 32-63 the second), v_permlane16_swap on
 // pairs of those (rows 0 / 1 / 2 / 3 hold values 4 m + 0 / 2 / 1 / 3 summed over the four rows), then 4 DPP steps inside each row:

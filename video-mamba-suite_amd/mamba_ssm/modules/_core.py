@@ -339,14 +339,14 @@ class MambaCore(nn.Module):
                 out = self._merge_and_project(
                     bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                                  checkpoint_lvl=_CHECKPOINT_LVL, seq_valid=valid), None)
-                return out[:, :seqlen] if pad else out
+                return out[:, :seqlen].contiguous() if pad else out   # (contiguous like the reference's output: callers .view() it)
             xz = self._in_projection(hidden_states, prep["wt_in"])
             A, A_b = NegExpPairFn.apply(self.A_log, self.A_b_log, prep["A"], prep["A_b"])
             out = self._merge_and_project(
                 bimamba_inner_fn_no_out_proj(xz, self._direction_params("", A), self._direction_params("_b", A_b),
                                              checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"], seq_valid=valid), None,
                 w_prepared=None if self.if_devide_out and self.variant == "vim_norm" else prep["w_out"])
-            return out[:, :seqlen] if pad else out
+            return out[:, :seqlen].contiguous() if pad else out
         xz = self._in_projection(hidden_states)
         if self.bimamba_type == "v2":
             if fast:
@@ -381,7 +381,9 @@ class MambaCore(nn.Module):
         if not unit or seqlen % unit == 0 or not hidden_states.is_cuda or self.in_proj.bias is not None:
             return 0
         low = (torch.bfloat16, torch.float16)
-        if not (_SEQ_PAD_FP32 or hidden_states.dtype in low or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in low)):
+        ac = ((torch.get_autocast_dtype("cuda") if hasattr(torch, "get_autocast_dtype") else torch.get_autocast_gpu_dtype())
+              if torch.is_autocast_enabled() else None)
+        if not (_SEQ_PAD_FP32 or hidden_states.dtype in low or ac in low):
             return 0
         if unit == 8:
             return 8 - seqlen % 8

@@ -31,19 +31,31 @@ _SUM_SLICES = True   # False (tests / A/B: monkeypatch.setattr): torch's reducti
 _mm_out_dtype_ok = [None]   # does torch.mm(a, b, out_dtype=torch.float32) work for 16-bit operands on this build / device?
 
 
+def _mm_out_dtype(like):
+    """Probed ONCE, explicitly, on tiny operands of the caller's dtype and device (outside any stream capture): an unrelated first
+    failure of a real call -- an out-of-memory error is a RuntimeError too -- must not flip the kernel path of every later weight
+    gradient, and the batched branch of _in_proj_param_grads must not depend on which node ran first."""
+    if _mm_out_dtype_ok[0] is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False   # decided at the first call outside a capture; inside one the cast form is always valid
+        try:
+            t = torch.ones(16, 16, device=like.device, dtype=like.dtype)
+            torch.mm(t, t, out_dtype=torch.float32)
+            torch.bmm(t[None], t[None], out_dtype=torch.float32)
+            _mm_out_dtype_ok[0] = True
+        except torch.cuda.OutOfMemoryError:
+            raise
+        except (RuntimeError, TypeError):
+            _mm_out_dtype_ok[0] = False
+    return _mm_out_dtype_ok[0]
+
+
 def _mm_wgrad(a, b, w_dtype):
     """a (m, k) @ b (k, n) -> (m, n) in the parameter's dtype: an unsliced weight gradient.  With 16-bit operands and an fp32
     parameter the GEMM writes fp32 itself (out_dtype: no cast kernel behind it, no rounding to 16 bits in between) where the
     library offers that; otherwise the product in the operands' dtype, then the cast."""
-    if a.is_cuda and w_dtype == torch.float32 and a.dtype in (torch.bfloat16, torch.float16) and _mm_out_dtype_ok[0] is not False:
-        try:
-            r = torch.mm(a, b, out_dtype=torch.float32)
-            _mm_out_dtype_ok[0] = True
-            return r
-        except (RuntimeError, TypeError):
-            if _mm_out_dtype_ok[0]:
-                raise
-            _mm_out_dtype_ok[0] = False
+    if a.is_cuda and w_dtype == torch.float32 and a.dtype in (torch.bfloat16, torch.float16) and _mm_out_dtype(a):
+        return torch.mm(a, b, out_dtype=torch.float32)
     return torch.mm(a, b).to(w_dtype)
 
 
@@ -179,7 +191,7 @@ def _in_proj_param_grads(g2, x2, channels, d_model, w_dtype, stack_halves, want_
         s = _k_splits(rows, channels, d_model)
         if x2.dtype != g2.dtype:
             x2 = x2.to(g2.dtype)
-        if s == 1 and stack_halves and g2.is_cuda and w_dtype == torch.float32 and _mm_out_dtype_ok[0]:
+        if s == 1 and stack_halves and g2.is_cuda and w_dtype == torch.float32 and g2.dtype in (torch.bfloat16, torch.float16) and _mm_out_dtype(g2):
             # the rows of g2 are ordered [c][half]: as the strided (half, c, rows) view the two halves are two batched GEMMs whose
             # (2, C / 2, d_model) result IS the parameter's row order -- no un-stacking copy behind the GEMM
             g3 = g2.view(channels // 2, 2, rows).permute(1, 0, 2)

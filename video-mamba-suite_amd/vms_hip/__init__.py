@@ -991,7 +991,9 @@ class PrepPlan:
         assert 0 < len(jobs) <= PREP_MAX_JOBS
         self.P = PrepParams()
         self.P.n_jobs = len(jobs)
-        self.src_ptrs = tuple(src.data_ptr() for src, *_ in jobs)
+        # what a later call must still find: the sources' addresses AND their geometry (a parameter re-viewed or resized in place at
+        # the same address -- p.data = other_view, resize_ -- must not run on the stale rows / strides: ADVICE r4)
+        self.src_key = tuple(self._key(src) for src, *_ in jobs)
         self.dst = []
         codes = {torch.float32: VMS_F32, torch.float16: VMS_F16, torch.bfloat16: VMS_BF16}
         for j, (src, group, off, dshape, dstrides, ddtype, op) in zip(self.P.job, jobs):
@@ -1006,13 +1008,21 @@ class PrepPlan:
             j.src_dtype, j.dst_dtype, j.op = dtype_code(s2), codes[ddtype], op
             self.dst.append((group, off))
 
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
     def matches(self, srcs):
-        return self.src_ptrs == tuple(t.data_ptr() for t in srcs)
+        return self.src_key == tuple(self._key(t) for t in srcs)
 
     def run(self, bases, ref_tensor):
-        for j, (group, off) in zip(self.P.job, self.dst):
+        # every launch gets its OWN copy of the block with this step's destinations: two threads running the same module (two
+        # streams of inference) used to rewrite the one cached block under each other.  ~0.5 KB memmove.
+        P = PrepParams()
+        ctypes.memmove(ctypes.byref(P), ctypes.byref(self.P), ctypes.sizeof(PrepParams))
+        for j, (group, off) in zip(P.job, self.dst):
             j.dst = bases[group] + off
-        _call("vms_param_prep", self.P, ref_tensor)
+        _call("vms_param_prep", P, ref_tensor)
 
 
 def param_prep(jobs):
