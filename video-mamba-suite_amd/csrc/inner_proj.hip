@@ -916,9 +916,21 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g16 = lane >> 4;
     const int wl = wave & 1, wm = wave >> 1;
-    const int b = blockIdx.z;
     const int L = p.seqlen, K = p.dim, M = q.m;
-    const int l0 = blockIdx.x * TL;
+    // 1-D grid; workgroup id = position tile fastest (what the (tiles, 1, batch) grid of round 4 dispatched).  A tile reads 6 bytes of
+    // either neighbour's 128-byte line per channel row (the convolutions' halos); neighbouring tiles sit on different XCDs (id % 8),
+    // every L2 fetches those lines for itself and FETCH_SIZE reads 412 MB for 134 MB of x.  VMS_CXP_XCD=1 decodes the id per XCD
+    // instead (XCD x runs the x-th eighth of the (batch entry, tile) list in order): FETCH_SIZE 149 MB -- and 139-141 us instead of
+    // 132-134 on the same box (profiles/r05_fused_traffic.md): the re-fetched lines come out of the Infinity Cache, the kernel is
+    // not bound by them, and one batch entry per XCD walks the channels in lock-step on one L2.  Measured, not adopted.
+    const int n_tl = (L + TL - 1) / TL, n_wg = n_tl * p.batch, per_xcd = (n_wg + 7) >> 3;
+#ifndef VMS_CXP_XCD
+#define VMS_CXP_XCD 0   /* 1 (A/B builds): neighbouring position tiles on one XCD (see above) */
+#endif
+    const int lid = VMS_CXP_XCD ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+    if (lid >= n_wg) return;
+    const int b = lid / n_tl;
+    const int l0 = (lid - b * n_tl) * TL;
     lds_s16* const in_a = (lds_s16*)reinterpret_cast<short*>(smem);                        // [KB][INP] conv1d_out, left-to-right set
     lds_s16* const in_b = in_a + KB * INP;                                                 // [KB][INP] right-to-left set
     lds_s16* const w_a = in_b + KB * INP;                                                  // [MP][WP] x_proj.weight block
@@ -1228,7 +1240,8 @@ static int dispatch_kred(const vms_proj_kred_params& p, hipStream_t stream) {
 template <typename T, typename WT_, int MH, int NL>
 static int launch_conv_xproj(const vms_conv_xproj_dual_params& q, hipStream_t stream, const int entry) {
     constexpr int TL = 32 * NL, KB = 64, INP = TL == 64 ? 72 : TL + 16, MP = 32 * MH, WP = KB + 8;
-    const dim3 grid((q.c.f.seqlen + TL - 1) / TL, 1, q.c.f.batch), block(kPT);
+    const int n_wg = ((q.c.f.seqlen + TL - 1) / TL) * q.c.f.batch;
+    const dim3 grid(8 * ((n_wg + 7) / 8)), block(kPT);   // whole eighths: the kernel decodes (XCD, index on it)
     const size_t smem = (size_t)(2 * KB * INP + 2 * MP * WP) * 2 + (size_t)2 * 2 * KB * 8 * sizeof(float);
     if (smem > 64 * 1024) {
         static PerDeviceOnce attr_once;
