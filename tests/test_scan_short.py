@@ -157,6 +157,33 @@ def test_short_sequence_block_matches_fp32(seqlen):
         assert _rel(got[2][n], ref[2][n]) < 4e-2, (n, _rel(got[2][n], ref[2][n]))
 
 
+@pytest.mark.parametrize("d_model,batch", [(64, 4), (40, 96), (40, 3)])
+@pytest.mark.parametrize("seqlen", [4, 8, 12])
+def test_short_sequence_block_off_the_lane_per_row_path(seqlen, d_model, batch):
+    """short sequences that do NOT qualify for the lane-per-row kernels -- fewer than 4,096 rows (batch x d_inner: 4 x 128,
+    3 x 80) or d_inner % 64 != 0 (80) -- still go through the mixer's padding of seqlen <= 16 to a multiple of 8 and land on the
+    long-row / generic kernels at L = 8 / 16: outputs and every gradient against the fp32 run of the same module."""
+    from mamba_ssm.modules.mamba_simple import Mamba
+    torch.manual_seed(1)
+    mod = Mamba(d_model, d_state=16, d_conv=4, expand=2, bimamba_type="v2").cuda()
+    hidden = torch.randn(batch, seqlen, d_model, device=DEV)
+    gout = torch.randn(batch, seqlen, d_model, device=DEV)
+
+    def run(autocast):
+        mod.zero_grad(set_to_none=True)
+        h = hidden.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            out = mod(h)
+        assert out.shape == hidden.shape and out.is_contiguous()
+        out.float().backward(gout)
+        return out.detach().float(), h.grad.float(), {n: p.grad.float().clone() for n, p in mod.named_parameters()}
+    ref = run(False)
+    got = run(True)
+    assert _rel(got[0], ref[0]) < 2e-2 and _rel(got[1], ref[1]) < 3e-2
+    for n in ref[2]:
+        assert _rel(got[2][n], ref[2][n]) < 4e-2, (n, _rel(got[2][n], ref[2][n]))
+
+
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("L", [8, 16])

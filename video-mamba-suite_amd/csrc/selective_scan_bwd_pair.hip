@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 #define VMS_BWD_MFMA_SUM 0   /* 1 (A/B builds): the 4 rows of a wave summed by two bf16 MFMAs for 16-bit activations; faster, NOT parity-safe (see below) */
 #endif
 #ifndef VMS_BWD_LDS_TR
-#define VMS_BWD_LDS_TR 0   /* 1 (A/B builds): the 4 rows of a wave summed through 4 KB of wave-private LDS instead of v_permlane32/16_swap: -14 % VALU time, +5 % run time at 2 waves per SIMD (profiles/r05_bwd_lds_tr.md) */
+#define VMS_BWD_LDS_TR 0   /* 1 (A/B builds): the 4 rows of a wave summed through 4 KB of wave-private LDS instead of v_permlane32/16_swap: -14 % VALU time, +5 % run time at 2 waves per SIMD (profiles/r05_bwd_lds_tr.md); with the reads one state BEHIND the writes (no round trip in the dependency chain) still +6 %: the eight 16-byte LDS instructions cost more than the 12 swaps */
 #endif
 // timing-only ablations (wrong results): tools/variant.sh <tag> -DVMS_ABL_NOBAR=1 / -DVMS_ABL_NOATOM=1
 #ifndef VMS_ABL_NOBAR

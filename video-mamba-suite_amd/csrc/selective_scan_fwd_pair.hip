@@ -337,6 +337,13 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 // stored as [i / 4][lane][i % 4], so consecutive lanes hit consecutive 16-byte slots).  Per state and wave: 4
 // widening ops + 1 ds_write_b128 instead of 32 widening ops; one workgroup barrier per four states.  64 KB of LDS
 // per workgroup: two workgroups = 16 waves per CU, the same 4 waves per SIMD as before.
+// timing-only ablations (wrong results): tools/variant.sh <tag> -DVMS_ABL_FWD_NOBAR=1 / -DVMS_ABL_FWD_NOSTAGE=1
+#ifndef VMS_ABL_FWD_NOBAR
+#define VMS_ABL_FWD_NOBAR 0
+#endif
+#ifndef VMS_ABL_FWD_NOSTAGE
+#define VMS_ABL_FWD_NOSTAGE 0
+#endif
 constexpr int kX8Aux = 2;                    // cache policy of the checkpoint stores: nt (streaming); none of the bits changes their cost
 constexpr int kLW = 8;                       // waves (rows) per workgroup
 constexpr int kLG = 4;                       // states per staged group
@@ -616,7 +623,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
 #pragma unroll 1
         for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
             const int buf = gi & 1;
-            stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
+            if (!VMS_ABL_FWD_NOSTAGE) stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
             if constexpr (XC) flush_park(sg > 0 ? c : c - 1, (sg + kLG - 1) & (kLG - 1), sg > 0 || c > c_lo);   // the group before this one
             if constexpr (tail) {
                 do_quad(sg, buf);
@@ -627,7 +634,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
                 do_state(4 * sg + 3, buf);
             }
             stage_commit(buf ^ 1);   // every wave left that buffer at the previous barrier
-            __syncthreads();
+            if (!VMS_ABL_FWD_NOBAR) __syncthreads();
         }
         float y[K];
 #pragma unroll
