@@ -442,12 +442,10 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 //     softplus derivative sigmoid(delta_raw) is carried from the prologue (8 registers; round 3), u is
 //     widened again from its raw vector in the epilogue; the next chunk's row data and B / C pieces are requested
 //     after the last state, into registers the state temporaries just vacated (182 VGPRs instead of 250).
-#ifndef VMS_BWD_MFMA_SUM
-#define VMS_BWD_MFMA_SUM 0   /* 1 (A/B builds): the 4 rows of a wave summed by two bf16 MFMAs for 16-bit activations; faster, NOT parity-safe (see below) */
-#endif
-#ifndef VMS_BWD_LDS_TR
-#define VMS_BWD_LDS_TR 0   /* 1 (A/B builds): the 4 rows of a wave summed through 4 KB of wave-private LDS instead of v_permlane32/16_swap: -14 % VALU time, +5 % run time at 2 waves per SIMD (profiles/r05_bwd_lds_tr.md); with the reads one state BEHIND the writes (no round trip in the dependency chain) still +6 %: the eight 16-byte LDS instructions cost more than the 12 swaps */
-#endif
+// Measured in round 5 and removed from the source (profiles/r05_scan_ablations.md; the code: profiles/r05_bwd_rowsum_variants.patch): the 4-row
+// dB / dC sums through wave-private LDS (VALU time -14 %, run time +5-6 % even with the reads a state behind the writes) and on the matrix pipe
+// (two v_mfma_f32_16x16x32_bf16 with one-hot row selectors: run time -6 %, but the bf16-rounded products leave the reference's element-wise
+// tolerance at small row counts).
 // timing-only ablations (wrong results): tools/variant.sh <tag> -DVMS_ABL_NOBAR=1 / -DVMS_ABL_NOATOM=1
 #ifndef VMS_ABL_NOBAR
 #define VMS_ABL_NOBAR 0
@@ -475,9 +473,7 @@ template <int W> struct B4 {
     // per-(row, state) records: 16 records of 16 bytes per row + one record of padding -- at a 256-byte pitch the four rows of a
     // wave sit on the same banks, and the record read every state makes (16 lanes of a row, one address) was a 4-way conflict
     static constexpr int kRecPitch = kBN + 1;
-    // wave-private transposition buffer of the 4-row dB / dC sums (VMS_BWD_LDS_TR): [piece = (tensor, element half)][lane] float4 = 4 KB per wave
-    static constexpr int kTr = VMS_BWD_LDS_TR ? W * 4 * 4 * kWave : 0;
-    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4 + kTr);
+    static constexpr size_t kSmem = sizeof(float) * (kBcFloats + 2 * kPair + kRows * kRecPitch * 4);
 };
 
 // DZM (two directions of a bidirectional block in one launch, vms_selective_scan_bwd_dual): 0 = dz from this launch's own
@@ -501,7 +497,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const int j = lane & 15, r = lane >> 4;
     lds_f4* const rec4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair) + (quad * 4 + r) * B4<W>::kRecPitch;
     __attribute__((address_space(3))) float* const rec1 = (__attribute__((address_space(3))) float*)rec4;
-    [[maybe_unused]] lds_f4* const tr4 = (lds_f4*)(smem + kBcFloats + 2 * kB4Pair + kRows4 * B4<W>::kRecPitch * 4) + quad * (4 * kWave);
     const int wg_per_seg = nblk / n_seg;
     const int seg = bid / wg_per_seg, wg = bid - seg * wg_per_seg;
     const int b = wg % p.batch;
@@ -588,18 +583,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     float hck_next = 0.f;
     // XL (x_has_sub == 3): the forward left the state after every 8 elements; a lane takes the one entering its elements
     // instead of rebuilding it (its own 8-step recurrence from zero + the row scan of the lane aggregates)
-#ifndef VMS_BWD_XWIN
-#define VMS_BWD_XWIN VMS_BWD_MFMA_SUM   /* 0: all 16 entering states of the next chunk in registers a whole chunk ahead (rounds 3-4; the swap form does not spill and
-                                          runs 1 % faster that way: 1,510 vs 1,523 us) */
-#endif
-    // VMS_BWD_XWIN: a window of two state groups (the one in use + the next one, requested one group = 4 states ahead) instead of
-    // the next chunk's 16 states a whole chunk ahead: 8 registers less in a body that spilled 19 (the spilled values were 64-bit
-    // pointers reloaded from scratch behind an s_waitcnt vmcnt(0) -- i.e. behind every atomic and prefetch in flight)
-    // Only in the two-direction grid (DZM != 0): the single-direction kernels did not spill, and run 5 % slower with the shorter lead
-    // (same box, alternating: 714 -> 754 us at (8, 1024, 8192); the dual call 1,441 -> 1,425, (8, 768, 3136) 483 -> 470).
-    constexpr bool kWin = VMS_BWD_XWIN && DZM != 0;
-    constexpr int kXW = XL ? (kWin ? 8 : N) : 1;
-    float xin[kXW];
+    float xin[XL ? N : 1];
     // one buffer resource per batch entry (workgroup-uniform): a batch entry's x stays under 2 GiB (host)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x_b) + (XL ? (int64_t)b * p.dim * p.n_chunks * p.x_chunk_stride : 0), 0,
@@ -617,7 +601,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                                 : 0x80000000u;
         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo, n0 * 1024, 0));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xin[XL ? (n0 + i) & (kXW - 1) : 0] = v[i];
+        for (int i = 0; i < 4; ++i) xin[XL ? n0 + i : 0] = v[i];
     };
     auto request_row = [&](int cc) __attribute__((always_inline)) {
         const int ll = cc * CH + j * K;
@@ -657,7 +641,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     request_row(c_hi - 1);
     if constexpr (XL) {
 #pragma unroll
-        for (int n0 = 0; n0 < (kWin ? 4 : N); n0 += 4) request_x(c_hi - 1, n0);
+        for (int n0 = 0; n0 < N; n0 += 4) request_x(c_hi - 1, n0);
     }
     stage_issue(c_hi - 1);
     stage_commit();
@@ -665,20 +649,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     lds_barrier_b();
     f32x4 bc = rec4[0];
     const bool is_first = j == 0, is_last = j == 15;
-    // VMS_BWD_MFMA_SUM (16-bit activations): the 4 rows of a wave summed on the matrix pipe.  D = A1 B(dB) + A2 B(dC) with
-    // v_mfma_f32_16x16x32_bf16: lane (r, j) supplies B[8 r + e][j] = its 8 products of element e (k = 8 x row + element, n = the
-    // position group), A1[m][8 r + e] = (e == m) for m < 8 and A2[m][8 r + e] = (e == m - 8) for m >= 8 pick element m of every
-    // row: D[m][j] = sum over the 4 rows; lane (q, j) receives D[4 q .. 4 q + 3][j] = tensor q >> 1, elements 4 (q & 1) + k --
-    // the layout the swaps left.  A lane's A operands depend on lane & 15 only: one-hot bf16 1.0 vectors, built once.
-    typedef unsigned int u32x4_m __attribute__((ext_vector_type(4)));
-    u32x4_m mA1 = {0, 0, 0, 0}, mA2 = {0, 0, 0, 0};
-    if constexpr (VMS_BWD_MFMA_SUM && sizeof(T) == 2) {
-        const int m8 = j & 7;
-        const unsigned one = 0x3F80u << (16 * (m8 & 1));
-        u32x4_m oh = {m8 >> 1 == 0 ? one : 0u, m8 >> 1 == 1 ? one : 0u, m8 >> 1 == 2 ? one : 0u, m8 >> 1 == 3 ? one : 0u};
-        if (j < 8) mA1 = oh;
-        else mA2 = oh;
-    }
     for (int c = c_hi - 1; c >= c_lo; --c) {
         const int l0 = c * CH + j * K;
         const bool ok = l0 < L && row_ok;
@@ -799,7 +769,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             float xseed;
             if constexpr (XL) {
                 row_scan_suffix_b(ra, rg);
-                xseed = xin[n & (kXW - 1)];
+                xseed = xin[n];
             } else {
                 float px = 0.f;
 #pragma unroll
@@ -839,83 +809,8 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
                 vb[2 * k] = dBv.x; vb[2 * k + 1] = dBv.y;
                 vc[2 * k] = dCv.x; vc[2 * k + 1] = dCv.y;
             }
-#if VMS_BWD_MFMA_SUM
-            f2 o0, o1;
-            f32x4 acc_m;
-            if constexpr (sizeof(T) == 2) {   // issued here, consumed behind the dA row sum below: the matrix pipe works under its DPP chain
-                typedef __bf16 bf8_m __attribute__((ext_vector_type(8)));
-                bf8_m pb, pc;
-#pragma unroll
-                for (int i = 0; i < K; ++i) {
-                    pb[i] = static_cast<__bf16>(vb[i]);
-                    pc[i] = static_cast<__bf16>(vc[i]);
-                }
-                // (the second instruction accumulates into the first's destination: same opcode, SrcC = vDst -- the dependency the
-                // hardware interlocks; s_nop 1 in front covers the v_cvt_pk -> MFMA source wait states)
-                asm volatile("s_nop 1\n\t"
-                             "v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0\n\t"
-                             "v_mfma_f32_16x16x32_bf16 %0, %3, %4, %0"
-                             : "=&v"(acc_m)
-                             : "v"(mA1), "v"(__builtin_bit_cast(u32x4_m, pb)), "v"(mA2), "v"(__builtin_bit_cast(u32x4_m, pc)));
-            }
-#endif
             const float dA_tot = row_allsum_b(dA2.x + dA2.y);
             if (j == n) dAacc += dA_tot;
-#if VMS_BWD_MFMA_SUM
-            if constexpr (sizeof(T) == 2) {
-                // The 4 rows summed by two bf16 MFMAs (see mA1 / mA2 above): 8 v_cvt_pk_bf16_f32 + 2 matrix instructions instead of 12
-                // v_permlane*_swap (8.8 cycles of the VALU pipe each, profiles/r05_microbench_mix.txt) + 6 v_pk_add_f32.  The products are
-                // rounded to bf16 (RNE, 2^-9) BEFORE the 4-row sum; everything behind it (the workgroup's sum, the atomics) stays fp32.
-                // MEASURED AND NOT ADOPTED (round 5; opt-in -DVMS_BWD_MFMA_SUM=1): with 4-state slab groups and the two-group window of
-                // entering states the dual call runs 1,527 -> 1,410-1,445 us at (8, 1024, 8192) (VALU time -12 %), but a product rounded to
-                // bf16 carries 2^-9 of ITS OWN magnitude into a sum that may be far smaller: dB / dC leave the reference's own element-wise
-                // tolerance (mamba/tests/ops/test_selective_scan.py:45-51) at small row counts -- tests/test_parity_hardening.py
-                // test_scan_random_under_the_references_metric: -13.148 for -13.265 in fp16 (rtol 3e-3), -0.883 for -0.770 in bf16 -- and
-                // the 1e-4 full-size bars.  A hi + lo split that restores fp32 sums costs the VALU time the swaps do (40 instructions).
-                // The matrix instructions are asm: hipcc unpacks v_pk_*_f32 that it sees next to an MFMA, and this body lives
-                // on packed math.  Wait states by hand: 16 cycles behind the second MFMA before its result is read.
-                // a 4-pass matrix instruction's result needs 7 wait states before a VALU / LDS read; the asm statement owns `acc_m`, so nothing
-                // reads it earlier (the hazard recogniser does not look inside asm)
-                asm volatile("s_nop 7" : "+v"(acc_m));
-                const f32x4 acc = acc_m;
-                o0 = f2{acc.x, acc.y};
-                o1 = f2{acc.z, acc.w};
-            } else {
-                // fp32 activations: the swaps
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(vb[0]), "+v"(vc[0]));
-#pragma unroll
-                for (int i = 1; i < K; ++i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(vb[i]), "+v"(vc[i]));
-                f2 t2[K / 2];
-#pragma unroll
-                for (int k = 0; k < K / 2; ++k) t2[k] = f2{vb[2 * k], vb[2 * k + 1]} + f2{vc[2 * k], vc[2 * k + 1]};
-                float t[K];
-#pragma unroll
-                for (int i = 0; i < K; ++i) t[i] = VMS_EL(t2, i);
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(t[0]), "+v"(t[4]));
-#pragma unroll
-                for (int i = 1; i < K / 2; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(t[i + 4]));
-                o0 = f2{t[0], t[1]} + f2{t[4], t[5]};
-                o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
-            }
-#elif VMS_BWD_LDS_TR
-            // The 4 rows of the wave summed through LDS (round 5).  v_permlane32/16_swap cost 8.4 cycles of the VALU pipe each
-            // (profiles/r05_microbench_mix.txt: as much as v_exp_f32) -- 12 per state were 100 of the state's ~700 cycles; the LDS
-            // pipe is nearly idle.  Every lane writes its four 16-byte pieces (tensor, element half) to the wave's 4 KB; DPP row
-            // rho then reads piece rho of the four lanes (rows) that share its position group and sums them: it holds tensor
-            // rho >> 1, elements 4 (rho & 1) + k, all 4 rows, as the swaps left it.  Same association as before:
-            // (row 0 + row 2) + (row 1 + row 3).  Wave-private and the LDS executes a wave's accesses in order: no barrier, and the
-            // next state's writes cannot overtake these reads.
-            tr4[lane] = f32x4{vb[0], vb[1], vb[2], vb[3]};
-            tr4[kWave + lane] = f32x4{vb[4], vb[5], vb[6], vb[7]};
-            tr4[2 * kWave + lane] = f32x4{vc[0], vc[1], vc[2], vc[3]};
-            tr4[3 * kWave + lane] = f32x4{vc[4], vc[5], vc[6], vc[7]};
-            const lds_f4* const trs = tr4 + r * kWave + j;
-            const f32x4 q0 = trs[0], q1 = trs[16], q2 = trs[32], q3 = trs[48];
-            const f2 o0 = (f2{q0.x, q0.y} + f2{q2.x, q2.y}) + (f2{q1.x, q1.y} + f2{q3.x, q3.y});
-            const f2 o1 = (f2{q0.z, q0.w} + f2{q2.z, q2.w}) + (f2{q1.z, q1.w} + f2{q3.z, q3.w});
-#else
             // rows r and r + 2: after the swap lanes 0-31 hold vb (both rows), lanes 32-63 vc
             // one asm statement per pair: with all 16 values tied to ONE statement the register allocator gathered them with ~9
             // v_mov per state (167 -> 59 per chunk, 2,511 -> 2,403 VALU instructions; the compiler's own permlane*_swap builtins
@@ -938,7 +833,6 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 #pragma unroll
             for (int i = 1; i < K / 2; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(t[i]), "+v"(t[i + 4]));
             const f2 o0 = f2{t[0], t[1]} + f2{t[4], t[5]}, o1 = f2{t[2], t[3]} + f2{t[6], t[7]};
-#endif
             slab4[(buf * kB4Pair + st * (W * 4 * kWave) + quad * (4 * kWave)) / 4 + lane] =
                 __builtin_shufflevector(o0, o1, 0, 1, 2, 3);
             {
@@ -960,15 +854,11 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         if constexpr (XL) {   // unrolled: xin[n] is a register
 #pragma unroll
             for (int n = 0; n < N; n += 4) {
-                if constexpr (kWin) {   // the next group's (the next chunk's first group behind the last one), into the half the previous group left
-                    if (n + 4 < N) request_x(c, n + 4);
-                    else request_x(c - 1, 0);
-                }
                 do_state(n, 0);
                 do_state(n + 1, 1);
                 do_state(n + 2, 2);
                 do_state(n + 3, 3);
-                if constexpr (!kWin) request_x(c - 1, n);
+                request_x(c - 1, n);
             }
         } else {
 #pragma unroll 1

@@ -71,7 +71,12 @@ class GraphedStep:
                 views.append(self.flat[p.dtype][offs[p.dtype]:offs[p.dtype] + p.numel()].view_as(p))
                 offs[p.dtype] += p.numel()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # Under a process group the capture checks only THIS thread's calls: ProcessGroupNCCL's watchdog thread polls the events of earlier
+        # (eager) collectives with hipEventQuery, which a capture in the default "global" mode counts as an unsafe call -- the capture is
+        # invalidated, the next library call inside it fails, and the watchdog aborts the process (seen as an intermittent SIGABRT of
+        # tests/ddp_nccl_worker.py on a cold box, the hipBLASLt "will attempt to recover" warning in front of it).
+        mode = {"capture_error_mode": "thread_local"} if self.pg is not None else {}
+        with torch.cuda.graph(self.graph, **mode):
             outs = run(self.gout, self.params)
             if views is not None:
                 torch._foreach_copy_(views, list(outs[2:]))
