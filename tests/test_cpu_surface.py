@@ -460,6 +460,37 @@ def test_checkpoint_layout_policy(monkeypatch):
     assert DBM(32, expand=1).scan_checkpoints is None
 
 
+def test_auto_checkpoint_policy_is_decided_once_per_module_and_shape(monkeypatch):
+    """under the memory-aware "auto" policy a module asks the allocator ONCE per input shape (at its first training forward of
+    that shape) and keeps the answer -- the kernel choice must not follow unrelated allocations from step to step; an explicit
+    scan_checkpoints=, a process policy other than "auto", inference and CPU tensors never consult the cache."""
+    import types
+    import torch
+    import mamba_ssm.modules._core as core
+    from mamba_ssm.modules.mamba_simple import Mamba
+    monkeypatch.delenv("VMS_X_LAYOUT", raising=False)
+    answers = iter([1, -1, -1])
+    calls = []
+
+    def fake_mode(batch, dim, seqlen, dstate, device, for_backward=True):
+        calls.append((batch, dim, seqlen, dstate))
+        return next(answers)
+    monkeypatch.setattr(core._vms, "x_mode_for_shape", fake_mode)
+    m = Mamba(32, expand=2, d_state=16, bimamba_type="v2")
+    gpu = lambda b, l: types.SimpleNamespace(is_cuda=True, device=types.SimpleNamespace(index=0), shape=(b, l, 32))
+    assert m._checkpoint_policy(gpu(4, 64)) == "coarse" and calls == [(4, 64, 64, 16)]       # (batch, d_inner, seqlen, d_state)
+    assert m._checkpoint_policy(gpu(4, 64)) == "coarse" and len(calls) == 1                   # kept: no second query
+    assert m._checkpoint_policy(gpu(4, 128)) == "fine" and len(calls) == 2                    # another shape: its own decision
+    with torch.no_grad():
+        assert m._checkpoint_policy(gpu(4, 256)) is None and len(calls) == 2                  # no backward: the node picks coarse itself
+    with core._vms.x_layout_policy("fine"):
+        assert m._checkpoint_policy(gpu(4, 64)) is None and len(calls) == 2                   # an enclosing explicit policy stays in charge
+    assert m._checkpoint_policy(torch.zeros(4, 64, 32)) is None                               # CPU tensor
+    m.reset_checkpoint_policy()
+    assert m._checkpoint_policy(gpu(4, 64)) == "fine" and len(calls) == 3
+    assert Mamba(32, expand=2, bimamba_type="v2", scan_checkpoints="coarse")._checkpoint_policy(gpu(4, 64)) == "coarse" and len(calls) == 3
+
+
 def test_in_proj_weight_gradient_is_ready_before_the_input_gradient():
     """in_proj's weight gradient is the last parameter gradient of a block's backward: produced by its own autograd node AHEAD of
     the input-gradient GEMM, the reducer's all-reduce of the last DDP bucket overlaps that GEMM instead of trailing the step"""

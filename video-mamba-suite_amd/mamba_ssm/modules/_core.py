@@ -306,8 +306,28 @@ class MambaCore(nn.Module):
 
     # ---- forward --------------------------------------------------------------------------------
     def forward(self, hidden_states, inference_params=None):
-        with _vms.x_layout_policy(getattr(self, "scan_checkpoints", None)):
+        with _vms.x_layout_policy(self._checkpoint_policy(hidden_states)):
             return self._forward(hidden_states, inference_params)
+
+    def _checkpoint_policy(self, hidden_states):
+        """scan_checkpoints= as given; under the memory-aware "auto" policy THIS module's decision for this input shape, taken once (at
+        its first training forward of that shape) and kept: the allocator's state of one moment must not flip the scan kernels -- and
+        the low-order bits of the gradients -- between steps, layers of one shape's turn, or the ranks of a data-parallel job, nor be
+        re-read on every forward (a HIP-graph capture froze whatever the query returned anyway).  reset_checkpoint_policy()
+        forgets the decisions (after the memory situation has changed for good)."""
+        pol = getattr(self, "scan_checkpoints", None)
+        if pol is not None or not hidden_states.is_cuda or not torch.is_grad_enabled() or _vms.current_x_layout_policy() != "auto":
+            return pol
+        key = (hidden_states.device.index, hidden_states.shape[0], hidden_states.shape[1])
+        cache = self.__dict__.setdefault("_auto_checkpoints", {})
+        got = cache.get(key)
+        if got is None:
+            mode = _vms.x_mode_for_shape(hidden_states.shape[0], self.d_inner, hidden_states.shape[1], self.d_state, hidden_states.device)
+            got = cache[key] = "coarse" if mode == 1 else "fine"
+        return got
+
+    def reset_checkpoint_policy(self):
+        self.__dict__.pop("_auto_checkpoints", None)
 
     def _forward(self, hidden_states, inference_params=None):
         """hidden_states: (B, L, D) -> same shape"""
