@@ -69,9 +69,22 @@ def idle():
     torch.cuda._sleep(int(2e-3 * 2.4e9))
 
 
+oa = torch.randn(b * L, d, device=dev, dtype=dt)
+ow = torch.randn(d, d, device=dev, dtype=dt)
+oo = torch.empty(b * L, d, device=dev, dtype=dt)
+
+
+def small(n):   # n out_proj-sized GEMMs (137 GFLOP, ~120 us each): what precedes the dual call in the block's backward is two of them
+    def f():
+        for _ in range(n):
+            torch.mm(oa, ow, out=oo)
+    return f
+
+
 for _ in range(30):
     call()
-for name, fn in (("back to back", None), ("after two GEMMs", gemms), ("after a 256 MB fill", flush), ("after 2 ms idle", idle),
+for name, fn in (("back to back", None), ("after 1 out_proj-sized GEMM", small(1)), ("after 2 out_proj-sized GEMMs", small(2)),
+                 ("after 4 out_proj-sized GEMMs", small(4)), ("after two GEMMs", gemms), ("after a 256 MB fill", flush), ("after 2 ms idle", idle),
                  ("after GEMMs + fill", lambda: (gemms(), flush())), ("back to back again", None)):
     m, lo = replay(fn)
     print(f"{name:22s}: median {m:8.1f} us   min {lo:8.1f}", flush=True)
