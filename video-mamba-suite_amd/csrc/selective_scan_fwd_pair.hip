@@ -341,6 +341,12 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 #ifndef VMS_ABL_FWD_NOBAR
 #define VMS_ABL_FWD_NOBAR 0
 #endif
+#ifndef VMS_ABL_FWD_NOCKST
+#define VMS_ABL_FWD_NOCKST 0   /* no checkpoint stores (the LDS park and its reads stay) */
+#endif
+#ifndef VMS_ABL_FWD_NOPARK
+#define VMS_ABL_FWD_NOPARK 0   /* no LDS park: the stores write register values */
+#endif
 #ifndef VMS_ABL_FWD_NOSTAGE
 #define VMS_ABL_FWD_NOSTAGE 0
 #endif
@@ -466,14 +472,16 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         f4 va, vb;
 #pragma unroll
         for (int s4 = 0; s4 < kLG; ++s4) {
-            va[s4] = src[s4 * kWave];
-            vb[s4] = src[s4 * kWave + 32];
+            va[s4] = VMS_ABL_FWD_NOPARK ? hreg + (float)s4 : src[s4 * kWave];
+            vb[s4] = VMS_ABL_FWD_NOPARK ? hreg - (float)s4 : src[s4 * kWave + 32];
         }
         const int la = cc * CS + (lane >> 1) * K;
         const uint32_t voa = valid && la < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
         const uint32_t vob = valid && la + 32 * K < L && row_ok ? (uint32_t)lane * 16u : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, kX8Aux);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, kX8Aux);
+        if (!VMS_ABL_FWD_NOCKST) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, va), xrs, voa, so, kX8Aux);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_p, vb), xrs, vob, so + 1024, kX8Aux);
+        }
         // the first dword of the second store's data came out overwritten now and then (3-8 values per 65 K) when hipcc put
         // a VALU write of that register right behind the store (the 16-byte-store write-data hazard, which its hazard
         // recogniser takes to be absent with an SGPR offset): the data registers stay live up to two wait states behind the
@@ -559,8 +567,10 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             // 8-element checkpoints (vms_hip.h, x_has_sub == 3): the state after the lane's 8th and 16th element, parked in
             // a wave-private LDS slot until the next group's B / C requests are out (flush_park)
             if constexpr (XC) {
-                park[(n & 3) * kWave] = bx2[3].y;
-                park[(kLG + (n & 3)) * kWave] = bx2[7].y;
+                if (!VMS_ABL_FWD_NOPARK) {
+                    park[(n & 3) * kWave] = bx2[3].y;
+                    park[(kLG + (n & 3)) * kWave] = bx2[7].y;
+                }
             }
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
