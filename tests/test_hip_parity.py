@@ -1938,6 +1938,44 @@ def test_state_update_vs_oracle_and_golden(oracle, name, itype):
         check(state, g["state_out"], 1e-5, "state vs golden")
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("has_z", [False, True])
+@pytest.mark.parametrize("dstate", [16, 32, 64])
+@pytest.mark.parametrize("dim", [2048, 2048 + 16, 4096])
+def test_state_update_reference_grid(oracle, dim, dstate, has_z, itype):
+    """The reference's own test of the single-token step, as it runs it (mamba/tests/ops/triton/test_selective_state_update.py:12-52:
+    batch 2, dt_bias = U - 4, A = -U - 1, B / C / D fp32, softplus; kernel against selective_state_update_ref -- the PyTorch statement
+    whose contraction sees the STORED state -- under its element-wise rtol / atol), plus, where the state is fp32, the f64 oracle."""
+    from mamba_ssm.ops.triton.selective_state_update import selective_state_update, selective_state_update_ref
+    rtol, atol = (3e-4, 1e-3) if itype == torch.float32 else (5e-3, 1e-2)
+    if itype == torch.bfloat16:
+        rtol, atol = 1e-2, 5e-2
+    torch.manual_seed(0)
+    b = 2
+    state = torch.randn(b, dim, dstate, dtype=itype, device=DEV)
+    x = torch.randn(b, dim, device=DEV, dtype=itype)
+    dt = torch.randn(b, dim, device=DEV, dtype=itype)
+    dt_bias = torch.rand(dim, device=DEV) - 4.0
+    A = -torch.rand(dim, dstate, device=DEV) - 1.0
+    Bm, Cm = torch.randn(b, dstate, device=DEV), torch.randn(b, dstate, device=DEV)
+    D = torch.randn(dim, device=DEV)
+    z = torch.randn_like(x) if has_z else None
+    f = lambda a: None if a is None else a.detach().float().cpu().numpy()
+    st0 = f(state)
+    state_ref = state.detach().clone()
+    out = selective_state_update(state, x, dt, A, Bm, Cm, D=D, z=z, dt_bias=dt_bias, dt_softplus=True)
+    out_ref = selective_state_update_ref(state_ref, x, dt, A, Bm, Cm, D=D, z=z, dt_bias=dt_bias, dt_softplus=True)
+    assert out.dtype == out_ref.dtype and out.shape == out_ref.shape
+    assert torch.allclose(state.float(), state_ref.float(), rtol=rtol, atol=atol), (state.float() - state_ref.float()).abs().max().item()
+    assert torch.allclose(out.float(), out_ref.float(), rtol=rtol, atol=atol), (out.float() - out_ref.float()).abs().max().item()
+    if itype == torch.float32:
+        o_out, o_st = oracle.state_update(st0, f(x), f(dt), f(A), f(Bm), f(Cm), f(D), f(z), f(dt_bias), True, prec="f64")
+        for got, want, what in ((out, o_out, "out"), (state, o_st, "state")):
+            got = f(got).astype(np.float64)
+            bad = np.abs(got - want) > atol + rtol * np.abs(want)
+            assert not bad.any(), f"{what} vs oracle: {bad.sum()} elements outside rtol {rtol} / atol {atol}, worst {np.abs(got - want).max():.3e}"
+
+
 def test_state_update_keeps_dt_and_z_precision(oracle):
     """bf16 x with fp32 dt / z (Mamba.step under bf16 activations keeps dt in fp32): dt and z are loaded in their own
     dtypes (vms_hip.h dt_dtype / z_dtype), as the reference's kernel does -- the result matches the oracle fed the
