@@ -1266,6 +1266,33 @@ def test_conv_update(oracle, name, itype):
         check(out, g["out"], 1e-3, "out vs golden")
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("silu_activation", [False, True])
+@pytest.mark.parametrize("has_bias", [False, True])
+@pytest.mark.parametrize("width", [2, 3, 4])
+@pytest.mark.parametrize("dim", [2048, 2048 + 16, 4096])
+def test_conv_update_reference_grid(dim, width, has_bias, silu_activation, itype):
+    """The reference's own test of the single-token conv step, as it runs it (causal-conv1d/tests/test_causal_conv1d.py:78-114: batch 2,
+    fp32 weight / bias, kernel against causal_conv1d_update_ref under its rtol / atol, the rolled state bit for bit)."""
+    from causal_conv1d.causal_conv1d_interface import causal_conv1d_update, causal_conv1d_update_ref
+    rtol, atol = (3e-4, 1e-3) if itype == torch.float32 else (3e-3, 5e-3)
+    if itype == torch.bfloat16:
+        rtol, atol = 1e-2, 5e-2
+    torch.manual_seed(0)
+    b = 2
+    x = torch.randn(b, dim, device=DEV, dtype=itype)
+    conv_state = torch.randn(b, dim, width, device=DEV, dtype=itype)
+    weight = torch.randn(dim, width, device=DEV, dtype=torch.float32)
+    bias = torch.randn(dim, device=DEV, dtype=torch.float32) if has_bias else None
+    conv_state_ref = conv_state.detach().clone()
+    act = "silu" if silu_activation else None
+    out = causal_conv1d_update(x, conv_state, weight, bias, activation=act)
+    out_ref = causal_conv1d_update_ref(x, conv_state_ref, weight, bias, activation=act)
+    assert out.dtype == out_ref.dtype and out.shape == out_ref.shape
+    assert torch.equal(conv_state, conv_state_ref)
+    assert torch.allclose(out, out_ref, rtol=rtol, atol=atol), (out.float() - out_ref.float()).abs().max().item()
+
+
 def test_scan_deterministic_outputs():
     """The scan's non-atomic results -- out, out_z, the checkpoints x, du, ddelta, dz -- are bit-identical over 10,000
     forward + backward repeats (what test_causal_conv1d_race_condition asks of the conv, asked of the scan); dA / dB /
