@@ -40,8 +40,9 @@ struct RawB {
         }
     }
     // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad
-    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid) {
-        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0));
+    // (`safe`: the offset a lane beyond the row reads instead -- 0 left-to-right, seqlen - K right-to-left: see RawP::load_s)
+    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid, int32_t safe) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : safe));
 #pragma unroll
         for (int i = 0; i < kBK / EPV; ++i) v[i] = vp[i];
     }

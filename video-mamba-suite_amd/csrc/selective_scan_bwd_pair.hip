@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
     auto stage_issue = [&](int cc) __attribute__((always_inline)) {
         const int ll = cc * CH + j * K;
         st_ok = cc >= 0 && ll < L;
-        if (RAG) stg.load_s(st_src, REV ? L - ll - K : ll, st_ok);
+        if (RAG) stg.load_s(st_src, REV ? L - ll - K : ll, st_ok, REV ? L - K : 0);
         else stg.load(st_src, REV ? L - ll - K : ll, st_ok);
     };
     auto stage_commit = [&]() __attribute__((always_inline)) {

@@ -37,9 +37,13 @@ struct RawP {
 #pragma unroll
         for (int i = 0; i < kPK / EPV; ++i) v[i] = vp[i];
     }
-    // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad
-    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid) {
-        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0));
+    // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad.
+    // `safe`: where a lane beyond the row reads instead -- the piece of the row's FIRST lane, which the padding covers: offset 0
+    // left-to-right, seqlen - K right-to-left.  (Until round 5 such lanes read [0, K) of the row in both directions: K - seqlen
+    // elements past the end of a front-padded row shorter than K -- harmless zeros of the next row, except behind the tensor's
+    // last row: a memory fault when the padded copy ended a mapped segment; found by tools/fuzz_modules.py, tools/guard_probe.py.)
+    __device__ __forceinline__ void load_s(const T* __restrict__ base, int32_t off, bool valid, int32_t safe) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : safe));
 #pragma unroll
         for (int i = 0; i < kPK / EPV; ++i) v[i] = vp[i];
     }
@@ -191,8 +195,8 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
         const uint32_t pl0n = REV ? L - l0 - CS - K : l0 + CS;
         if (c == c_lo) {
             if (RAG) {
-                rB0.load_s(Bv, (int32_t)pl0, ok);
-                rC0.load_s(Cv, (int32_t)pl0, ok);
+                rB0.load_s(Bv, (int32_t)pl0, ok, REV ? L - K : 0);
+                rC0.load_s(Cv, (int32_t)pl0, ok, REV ? L - K : 0);
             } else {
                 rB0.load(Bv, pl0, ok);
                 rC0.load(Cv, pl0, ok);
@@ -229,8 +233,8 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
                 const uint32_t po = wrap ? pl0n : pl0;
                 const bool pok = wrap ? okn : ok;
                 if (RAG) {
-                    nB.load_s(Bv + (int64_t)nn * p.B_dstate_stride, (int32_t)po, pok);
-                    nC.load_s(Cv + (int64_t)nn * p.C_dstate_stride, (int32_t)po, pok);
+                    nB.load_s(Bv + (int64_t)nn * p.B_dstate_stride, (int32_t)po, pok, REV ? L - K : 0);
+                    nC.load_s(Cv + (int64_t)nn * p.C_dstate_stride, (int32_t)po, pok, REV ? L - K : 0);
                 } else {
                     nB.load(Bv + (int64_t)nn * p.B_dstate_stride, po, pok);
                     nC.load(Cv + (int64_t)nn * p.C_dstate_stride, po, pok);
