@@ -505,7 +505,12 @@ def x_mode_for_shape(batch, dim, seqlen, dstate, device, for_backward=True):
     # what the 8-element layout allocates: 258 * dstate floats per (row, 2048-element chunk) whatever the row's length (a short
     # row pays for a whole chunk: 16.5 KB at dstate 16)
     need = batch * dim * ((seqlen + 2047) // 2048) * 258 * dstate * 4
-    used = _allocated_bytes(idx)
+    try:
+        used = _allocated_bytes(idx)
+    except RuntimeError:
+        used = None
+    if used is None:         # nothing known about the device's memory: the layout that cannot surprise
+        return 1
     return -1 if (4 * used <= total and 8 * need <= total - used) else 1
 
 
@@ -515,7 +520,11 @@ def _allocated_bytes(idx):
     try:
         return torch._C._cuda_memoryStats(idx)["allocated_bytes"]["all"]["current"]
     except (AttributeError, KeyError, TypeError):
+        pass
+    try:
         return torch.cuda.memory_allocated(idx)
+    except RuntimeError:     # a pluggable allocator (torch.cuda.memory.CUDAPluggableAllocator) keeps no statistics
+        return None
 
 
 def x_mode_for(u, dstate, for_backward=True):
