@@ -454,6 +454,16 @@ def test_checkpoint_layout_policy(monkeypatch):
         vms_hip.set_x_layout_policy("auto")
     monkeypatch.setenv("VMS_X_LAYOUT", "1")
     assert vms_hip.x_mode_for_shape(*shp) == 1
+    # "auto" on a device: by the allocator's numbers -- and the small layout when the allocator keeps none (a pluggable allocator:
+    # torch.cuda.memory_allocated raises; tools/efence_run.py met it)
+    monkeypatch.delenv("VMS_X_LAYOUT")
+    monkeypatch.setitem(vms_hip._total_mem, 0, 256 << 30)
+    monkeypatch.setattr(vms_hip, "_allocated_bytes", lambda idx: 1 << 30)
+    assert vms_hip.x_mode_for_shape(8, 1024, 8192, 16, "cuda:0") == -1
+    monkeypatch.setattr(vms_hip, "_allocated_bytes", lambda idx: 200 << 30)
+    assert vms_hip.x_mode_for_shape(8, 1024, 8192, 16, "cuda:0") == 1
+    monkeypatch.setattr(vms_hip, "_allocated_bytes", lambda idx: None)
+    assert vms_hip.x_mode_for_shape(8, 1024, 8192, 16, "cuda:0") == 1
     from mamba_ssm.modules.mamba_simple import Mamba
     from mamba_ssm.modules.mamba_new import Mamba as DBM
     assert Mamba(32, expand=1, bimamba_type="v2", scan_checkpoints="coarse").scan_checkpoints == "coarse"
