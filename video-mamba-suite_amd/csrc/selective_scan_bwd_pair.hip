@@ -457,8 +457,8 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
 #define VMS_BWD_PRIO 1
 #endif
 // states between two workgroup barriers = states per slab buffer.  8-wave workgroups: 4 (round 5; 2 before: 16 -> 8 barriers per chunk,
-// the dual call at (8, 1024, 8192) 1,479 -> 1,440 us, 64 KB of slab; 8 needs 128 KB and spills: 2,100 us); 4-wave workgroups: 2 (4 measured
-// slower at (8, 768, 3136): 494 vs 483 us, their barriers already leave the SIMD to the other workgroup)
+// the dual call at (8, 1024, 8192) 1,533 -> 1,510 us, 64 KB of slab; 8 needs 128 KB and spills: 2,100 us); 4-wave workgroups: 2 (4 measured
+// slower at (8, 768, 3136), their barriers already leave the SIMD to the other workgroup).  profiles/r05_scan_ablations.md
 #ifndef VMS_BWD_SG
 #define VMS_BWD_SG 4
 #endif
