@@ -45,6 +45,14 @@ WORKLOADS = {
     # not a BASELINE config: the suite's other regime -- TimeMamba's scans along time (timemamba.py:135-140): 8 clips x 196 tokens,
     # 8 frames each (the lane-per-row scan kernels, the folded small projections; profiles/r04_short_rows.md)
     "frames": ("extra: ViM block on short sequences with many rows (TimeMamba, 'b (n t) d -> (b n) t d')", 1568, 8, 768, 1, 1),
+    # the secondary lines SURVEY.md section 8 wrote down (round 6; attached to the judged line as extra_configs):
+    #   section 8 "Decision recorded for the builder": the headline block with the module's default expand=2 (d_inner 2048)
+    "block_expand2": ("secondary line: configs[1]'s ViM block with expand=2 (the module default)", 8, 8192, 1024, 2, 1),
+    #   8(d) configs[2]: the ViViM-S-like stack, 24 x (d_model 384, expand 2) on 16 frames x 197 tokens (vivim.py:406-423, 555-556)
+    "vivim_s": ("configs[2] secondary: ViViM-S-like 24 x Block(Add -> RMSNorm -> ViM), fused add+norm", 8, 3152, 384, 2, 24),
+    #   8(d) configs[3]: the temporal-action-localization backbone's 7 DBM mixers (arch (2, 2, 5), backbones.py:282-288, blocks.py:899-942):
+    #   2 stem blocks at 2304, 5 branch blocks at 2304 / 1152 / 576 / 288 / 144 (each followed by the stride-2 max pool), LayerNorm + residual
+    "dbm_pyramid": ("configs[3] secondary: the TAL backbone's DBM pyramid, 7 x (LayerNorm -> DBM -> residual [-> maxpool/2]) at L = 2304 ... 144", 2, 2304, 512, 1, 7),
 }
 B, L, D_MODEL, EXPAND = WORKLOADS["block"][1:5]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -57,11 +65,15 @@ DDP_BUCKET_MB = 4
 # HBM bytes per call from the PMC passes of the same kernels at the config's size (FETCH_SIZE x2 + WRITE_SIZE, separate
 # rocprofv3 --pmc runs, main and carry kernels added up per entry point: tools/measure_cfg.sh, tools/pmc_table.py); a profile of
 # the committed build, not a live measurement
-TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r05_{config}_traffic.json")
+TRAFFIC_PROFILE = os.path.join(ROOT, "profiles", "r06_{config}_traffic.json")
 
 
-def profiled_traffic(kernel, config="block"):
-    path = TRAFFIC_PROFILE.format(config=config)
+def profiled_traffic(kernel, config="block", x_layout=3):
+    """x_layout 1 = the 128-element checkpoint layout (the `block_coarse_checkpoints` extra line): its scans move ~1 GB less per
+    launch than the default layout's, so it has its own profile (profiles/r06_block_coarse_traffic.json); no profile -> None."""
+    path = TRAFFIC_PROFILE.format(config=config + ("_coarse" if x_layout == 1 else ""))
+    if not os.path.exists(path) and x_layout != 1:   # a config this round did not re-profile: the previous round's profile of it
+        path = path.replace("r06_", "r05_")
     try:
         with open(path) as f:
             t = json.load(f)
@@ -384,6 +396,28 @@ class _Stack(torch.nn.Module):
                            residual_in_fp32=True)
 
 
+class _DbmPyramid(torch.nn.Module):
+    """configs[3] secondary line: the DBM mixers of the temporal-action-localization backbone (MambaBackbone, arch (2, 2, 5):
+    backbones.py:239-330; MaskMambaBlock: blocks.py:899-942) -- per block LayerNorm -> DBM(expand=1) -> residual, the five branch
+    blocks each followed by the stride-2 max pool (kernel 3, padding 1), so the mixers see L, L, L, L/2, L/4, L/8, L/16.  (The
+    mask multiply and the stochastic depth of the task code are identities on full-length eval-style inputs and left out.)"""
+
+    def __init__(self, d_model, n_stem=2, n_branch=5):
+        super().__init__()
+        from mamba_ssm.modules.mamba_new import Mamba as DBM
+        n = n_stem + n_branch
+        self.norms = torch.nn.ModuleList([torch.nn.LayerNorm(d_model) for _ in range(n)])
+        self.mixers = torch.nn.ModuleList([DBM(d_model, d_state=D_STATE, d_conv=D_CONV, expand=1) for _ in range(n)])
+        self.n_stem = n_stem
+
+    def forward(self, h):                         # (B, L, d_model) -> the coarsest level (B, L / 32, d_model)
+        for i, (norm, mixer) in enumerate(zip(self.norms, self.mixers)):
+            h = h + mixer(norm(h))
+            if i >= self.n_stem:
+                h = torch.nn.functional.max_pool1d(h.transpose(1, 2), 3, 2, 1).transpose(1, 2)
+        return h
+
+
 def make_workload(config, device, dims=None):
     """-> (module, per-GPU batch, seqlen, d_model).  dims = (batch, seqlen, d_model) overrides the sizes (CPU tests)."""
     what, b, l, d_model, expand, layers = WORKLOADS[config]
@@ -392,7 +426,9 @@ def make_workload(config, device, dims=None):
     if config == "dbm":
         from mamba_ssm.modules.mamba_new import Mamba as DBM
         m = DBM(d_model, d_state=D_STATE, d_conv=D_CONV, expand=expand)
-    elif config == "stack":
+    elif config == "dbm_pyramid":
+        m = _DbmPyramid(d_model) if dims is None else _DbmPyramid(d_model, 1, 1)
+    elif layers > 1:
         m = _Stack(d_model, layers if dims is None else 2, expand)
     else:
         from mamba_ssm.modules.mamba_simple import Mamba
@@ -449,7 +485,11 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
     # the block sits inside a network: its input gradient is part of the backward
     hidden = torch.randn(b, l, d_model, device=dev, dtype=act_dtype, requires_grad=True)
     # fixed upstream gradient: the step is exactly the block's forward + backward (no loss kernels)
-    gout = torch.randn(b, l, d_model, device=dev, dtype=act_dtype)
+    out_len = l
+    if config == "dbm_pyramid":     # every branch block halves the length (max pool, kernel 3, stride 2, padding 1)
+        for _ in range(len(block.mixers) - block.n_stem):
+            out_len = (out_len - 1) // 2 + 1
+    gout = torch.randn(b, out_len, d_model, device=dev, dtype=act_dtype)
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -534,8 +574,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
         d_inner = d_model * WORKLOADS[config][4]
         # the DBM block runs its two halves as ONE node on a batch of 2 b (vms_hip.h reverse_from) unless vms_hip.debug.dbm_two_nodes;
         # every other config's scans cover (b, d_inner, l) per launch
-        scan_b = 2 * b if config == "dbm" and not __import__("vms_hip").debug.dbm_two_nodes else b
-        ab = algorithmic_bytes(batch=scan_b, dim=d_inner, seqlen=l)
+        scan_b = 2 * b if config in ("dbm", "dbm_pyramid") and not __import__("vms_hip").debug.dbm_two_nodes else b
+        # (the pyramid's launches cover five different lengths: per-kernel times only, no per-launch byte count)
+        ab = algorithmic_bytes(batch=scan_b, dim=d_inner, seqlen=l) if config != "dbm_pyramid" else {}
         kern = {}
         for name, ts in kernel_ms.items():
             avg = sum(ts) / len(ts)
@@ -546,7 +587,7 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
             if name in ab:
                 kern[name]["algorithmic_GBs"] = ab[name] / (avg * 1e-3) / 1e9
                 kern[name]["hbm_frac"] = kern[name]["algorithmic_GBs"] / HBM_PEAK_GBS
-            vf = valu_floor_us(name, scan_b, d_inner, l)
+            vf = valu_floor_us(name, scan_b, d_inner, l) if ab else None
             if vf is not None:
                 kern[name]["valu_floor_us"] = vf
                 kern[name]["valu_frac"] = vf / (avg * 1e3)
@@ -562,8 +603,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                 comm["rccl_version"] = None
         res = {
             "metric": (f"Mamba-block fwd+bwd tokens/s at (B,L,D,d_state)=({b},{l},{d_model},{D_STATE}); % HBM roofline"
-                       if config != "stack" else
-                       f"{WORKLOADS[config][5]}-layer ViM stack fwd+bwd tokens/s at (B,L,D,d_state)=({b},{l},{d_model},{D_STATE}); % HBM roofline"),
+                       if WORKLOADS[config][5] == 1 else
+                       f"{WORKLOADS[config][5]}-layer {'DBM pyramid' if config == 'dbm_pyramid' else 'ViM stack'} fwd+bwd tokens/s at "
+                       f"(B,L,D,d_state)=({b},{l},{d_model},{D_STATE}); % HBM roofline"),
             "value": tokens / elapsed, "unit": "tokens/s", "n_gpus": world, "steps": steps,
             "warmup": warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if autocast else "f32", "data": "synthetic",
@@ -582,9 +624,9 @@ def run(config="block", steps=50, warmup=20, device=None, backend="nccl", dims=N
                        "x_layout": 1 if (os.environ.get("VMS_X_LAYOUT") == "1" or x_policy == "coarse") else 3, "comm": comm, "host": host},
             "kernels": kern,
         }
-        if kern:
+        if any(k in ab for k in kern):
             dom = max((k for k in kern if k in ab), key=lambda k: kern[k]["ms_per_step"])
-            traffic, src = profiled_traffic(dom, config)
+            traffic, src = profiled_traffic(dom, config, res["config"]["x_layout"])
             res["roofline"] = {"kernel": dom, "bound": "hbm", "binding_resource": "valu" if "valu_frac" in kern[dom] else "hbm",
                                "valu_frac": kern[dom].get("valu_frac"), "achieved": kern[dom]["algorithmic_GBs"],
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
@@ -671,11 +713,25 @@ def main(argv=None):
     # gets) on the same ranks; attached to the same JSON line, whose metric / config / value stay the judged block's.
     if args.config == "block" and not args.no_extra_configs and args.device is None:
         extra = {}
-        for name, kw in (("stack", {}), ("long", {}), ("dbm", {"graph": True}), ("block_coarse_checkpoints", {"x_policy": "coarse"})):
-            torch.cuda.empty_cache()
-            r = run("block" if name.startswith("block") else name, args.extra_steps, 5, backend=args.backend, cpu_base=False, projections=False, **kw)
-            if kw.get("x_policy"):
-                __import__("vms_hip").set_x_layout_policy("auto")
+        # each extra run is guarded: an out-of-memory stack, a failed graph capture or a collective hiccup in one of them
+        # is recorded under its name and the judged line -- already measured -- is still printed
+        for name, kw in (("stack", {}), ("long", {}), ("dbm", {"graph": True}), ("block_coarse_checkpoints", {"x_policy": "coarse"}),
+                         ("block_expand2", {}), ("vivim_s", {}), ("dbm_pyramid", {"graph": True})):
+            try:
+                torch.cuda.empty_cache()
+                r = run("block" if name == "block_coarse_checkpoints" else name, args.extra_steps, 5, backend=args.backend, cpu_base=False,
+                        projections=False, **kw)
+            except Exception as e:  # noqa: BLE001
+                r = None
+                if res is not None:
+                    extra[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+            finally:
+                if kw.get("x_policy"):
+                    __import__("vms_hip").set_x_layout_policy("auto")
             if r is not None:
                 rf = r.get("roofline", {})
                 extra[name] = {"workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "tokens_per_s": r["value"],

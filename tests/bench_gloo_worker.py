@@ -27,7 +27,8 @@ def main():
     import mamba_ssm.ops.triton.layernorm as lnm
     lnm.layer_norm_cuda = make_norm_fake(orc)
     import bench
-    dims = {"block": (2, 24, 32), "stack": (1, 20, 32), "dbm": (2, 24, 32), "long": (1, 48, 32)}[config]
+    dims = {"block": (2, 24, 32), "stack": (1, 20, 32), "dbm": (2, 24, 32), "long": (1, 48, 32), "block_expand2": (2, 24, 32),
+            "vivim_s": (1, 20, 32), "dbm_pyramid": (2, 24, 32)}[config]
     res = bench.run(config, steps=2, warmup=1, device="cpu", backend="gloo", dims=dims, autocast=False,
                     cpu_base=False, projections=False)
     assert (res is not None) == (rank == 0)

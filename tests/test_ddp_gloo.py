@@ -34,7 +34,7 @@ import json
 import pytest
 
 
-@pytest.mark.parametrize("config", ["block", "stack", "dbm", "long"])
+@pytest.mark.parametrize("config", ["block", "stack", "dbm", "long", "block_expand2", "vivim_s", "dbm_pyramid"])
 def test_bench_configs_under_gloo(tmp_path, oracle, config):
     """bench.py --config {block, stack, dbm, long} as a world_size-2 job (gloo, CPU, fake extensions, tiny sizes): the
     same bench.run() the driver launches with torch.distributed.run; rank 0 reports the whole-job aggregate."""
@@ -44,7 +44,8 @@ def test_bench_configs_under_gloo(tmp_path, oracle, config):
     for p in procs:
         assert p.wait(timeout=600) == 0
     res = json.load(open(out + f".{config}.json"))
-    b, l = {"block": (2, 24), "stack": (1, 20), "dbm": (2, 24), "long": (1, 48)}[config]
+    b, l = {"block": (2, 24), "stack": (1, 20), "dbm": (2, 24), "long": (1, 48), "block_expand2": (2, 24), "vivim_s": (1, 20),
+            "dbm_pyramid": (2, 24)}[config]
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 2 * b and res["config"]["name"] == config
     comm = res["config"]["comm"]
     assert comm["backend"] == "gloo" and comm["world_size"] == 2
