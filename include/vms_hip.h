@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define VMS_ABI_VERSION 10
+#define VMS_ABI_VERSION 11
 
 typedef enum {
     VMS_OK = 0,
@@ -65,14 +65,11 @@ typedef enum { VMS_F32 = 0, VMS_F16 = 1, VMS_BF16 = 2 } vms_dtype;
 
 /* kernel generations of the selective scan: a call runs the highest one that is <= `impl` and eligible for the
  * problem; AUTO = PAIR.  GENERIC takes every problem the reference takes; PAIR is the fast paths (variable B / C,
- * dstate 16, ...).  FAST and ROWS named the experimental generations of rounds 1-3 (removed in round 5): the values
- * stay accepted, FAST runs the generic kernels, ROWS what PAIR runs. */
-typedef enum {
-    VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_FAST = 2, VMS_IMPL_PAIR = 3, VMS_IMPL_ROWS = 4,
-    /* = PAIR, except that vms_selective_scan_bwd_dual runs its 128-VGPR kernel (csrc/selective_scan_bwd_occ4.hip: 4 waves per SIMD;
-     * round 5, measured 12-15 % slower than the 256-VGPR one -- profiles/r05_bwd_occ4.md -- hence opt-in) where it applies */
-    VMS_IMPL_OCC4 = 5
-} vms_scan_impl;
+ * dstate 4 / 8 / 16, ...).  ABI v11: the values 2 (FAST), 4 (ROWS) -- experimental generations of rounds 1-3, aliases since
+ * round 5 -- and 5 (OCC4: round 5's 128-VGPR two-direction backward, measured 12-20 % slower than the default and kept as
+ * profiles/r05_bwd_occ4.patch + profiles/r05_bwd_occ4.md) are gone: every kernel in the library is reachable by the default
+ * dispatch or is a generic one.  They are rejected as out of range. */
+typedef enum { VMS_IMPL_AUTO = 0, VMS_IMPL_GENERIC = 1, VMS_IMPL_PAIR = 3 } vms_scan_impl;
 #define VMS_BUILD_EXPERIMENTAL 1   /* bit of vms_build_flags(): never set since round 5 (the FAST / ROWS / MFMA generations are gone) */
 
 /* ---- selective scan ------------------------------------------------------------------

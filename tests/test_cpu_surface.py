@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(vms_hip.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert vms_hip.lib().vms_abi_version() == 10
+    assert vms_hip.lib().vms_abi_version() == vms_hip.ABI_VERSION == 11
 
 
 def test_no_cpu_fallback():

@@ -24,14 +24,12 @@ def _dir_inputs(b, d, L, itype, seed):
     return u, delta, A, B, C, D, bias
 
 
-def _run_pair(b, d, L, itype, layout1, monkeypatch, seed=0, o4=False):
+def _run_pair(b, d, L, itype, layout1, monkeypatch, seed=0):
     """-> (dual results, two-call results, kernel name, inputs) on identical inputs"""
     import selective_scan_cuda as ssc
     import vms_hip
     if layout1:
         monkeypatch.setenv("VMS_X_LAYOUT", "1")
-    if o4:
-        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")   # vms_hip.h VMS_IMPL_OCC4: the dual call on its 128-VGPR kernel (opt-in)
     a, bb = _dir_inputs(b, d, L, itype, seed), _dir_inputs(b, d, L, itype, seed + 1)
     g = torch.Generator(device="cpu").manual_seed(seed + 2)
     z = torch.randn(b, d, L, generator=g).to(itype).to(DEV)
@@ -55,44 +53,28 @@ def _run_pair(b, d, L, itype, layout1, monkeypatch, seed=0, o4=False):
 NAMES = ["du", "ddelta", "dA", "dB", "dC", "dD", "ddelta_bias"]
 
 
-def _want(name, layout1, shape, o4):
-    """The kernel a dual call lands on: the 256-VGPR body of rounds 3-4 (8-wave workgroups for whole rounds of them, else 4-wave)
-    by default; with VMS_SCAN_IMPL=occ4 and the forward's 8-element checkpoints (layout 3) the 128-VGPR body of round 5
-    (csrc/selective_scan_bwd_occ4.hip: 4-wave workgroups while 3 per CU hold the whole grid, else 8-wave)."""
-    if name is None or layout1 or not o4:
-        return name
-    b, d, _ = shape
-    return "scan_bwd_o4_dual_w8" if 2 * b * ((d + 15) // 16) > 3 * torch.cuda.get_device_properties(0).multi_processor_count else "scan_bwd_o4_dual_w4"
-
-
 def _ulp(itype):
     return 2 ** -8 if itype == torch.bfloat16 else 2 ** -11
 
 
-@pytest.mark.parametrize("layout1,o4", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("layout1", [False, True])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape,want", [((5, 1024, 1040), "scan_bwd_pair4_dual_w4"),      # 320 8-wave workgroups: not whole rounds -> 4-wave
                                         ((4, 1024, 528), "scan_bwd_pair4_dual_w8"),       # 256: whole rounds of 8-wave workgroups
                                         ((8, 1024, 528), "scan_bwd_pair4_dual_w8"),       # the benchmark's grid (2 x 256 workgroups of 8 waves)
                                         ((8, 768, 400), "scan_bwd_pair4_dual_w4"),        # the suite's grid: 2 x 192
                                         ((1, 64, 2048), None)])                             # too small to fill the chip: two launches
-def test_dual_equals_two_single_calls(monkeypatch, shape, want, itype, layout1, o4):
-    (da, db), (ra, rb), kernel, single_kernel, _ = _run_pair(*shape, itype, layout1, monkeypatch, o4=o4)
+def test_dual_equals_two_single_calls(monkeypatch, shape, want, itype, layout1):
+    (da, db), (ra, rb), kernel, single_kernel, _ = _run_pair(*shape, itype, layout1, monkeypatch)
     if want is None:
         assert "dual" not in kernel, kernel
     else:
-        assert kernel == _want(want, layout1, shape, o4), kernel
-    same_body = "pair4" in kernel or "dual" not in kernel
+        assert kernel == want, kernel
     for got, ref, tag in ((da, ra, "a"), (db, rb, "b")):
         for k, name in enumerate(NAMES):
-            if same_body:
-                # same kernel body, same order of operations within a row; the fp32 atomics (dB, dC over 32 / 16 rows, dA / dD /
-                # dbias over the batch) are order-dependent in the last bits and the dual grid sums 16-row partials
-                tol = 0.0 if name in ("du", "ddelta") else 2e-5
-            else:
-                # the 128-VGPR body: the same arithmetic in another association (S2 scaled by ln 2 once per chunk, u and the softplus
-                # derivative rebuilt from delta in the epilogue): du / ddelta within a rounding of the 16-bit result, fp32 sums 1e-4
-                tol = 2 * _ulp(itype) if name in ("du", "ddelta") else 1e-4
+            # same kernel body, same order of operations within a row; the fp32 atomics (dB, dC over 32 / 16 rows, dA / dD /
+            # dbias over the batch) are order-dependent in the last bits and the dual grid sums 16-row partials
+            tol = 0.0 if name in ("du", "ddelta") else 2e-5
             e = rel_err(got[k], ref[k])
             assert e <= tol, f"{tag}.{name}: {e:.3e}"
     # dz: one rounding of dout (out_a + out_b) dsilu(z) against the two-call form's two roundings: within an ulp of the dtype
@@ -102,16 +84,16 @@ def test_dual_equals_two_single_calls(monkeypatch, shape, want, itype, layout1, 
 
 # the oracle comparison at BOTH workgroup widths of the dual grid and with >= 2 chunks of 2048 (the headline's
 # instantiation, 8-wave workgroups, used to meet the oracle only through the two single calls), for both checkpoint layouts
-@pytest.mark.parametrize("layout1,o4", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("layout1", [False, True])
 @pytest.mark.parametrize("itype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape,want", [((8, 768, 272), "scan_bwd_pair4_dual_w4"),     # the suite's grid, short rows for the oracle
                                         ((8, 1024, 528), "scan_bwd_pair4_dual_w8"),    # the benchmark's grid: 8-wave workgroups in both bodies
                                         ((8, 512, 4368), "scan_bwd_pair4_dual_w8"),    # 3 chunks of 2048 (the last one partial), a 16-element tail chunk
                                         ((8, 1024, 2304), "scan_bwd_pair4_dual_w8")])  # 2 chunks of 2048, 8-wave workgroups
-def test_dual_vs_oracle(oracle, monkeypatch, itype, shape, want, layout1, o4):
+def test_dual_vs_oracle(oracle, monkeypatch, itype, shape, want, layout1):
     b, d, L = shape
-    (da, db), _, kernel, _, (a, bb, z, dout) = _run_pair(b, d, L, itype, layout1, monkeypatch, seed=5, o4=o4)
-    assert kernel == _want(want, layout1, shape, o4), kernel
+    (da, db), _, kernel, _, (a, bb, z, dout) = _run_pair(b, d, L, itype, layout1, monkeypatch, seed=5)
+    assert kernel == want, kernel
     f = lambda t: t.detach().float().cpu().numpy()
     dz_want = 0
     for got, inp, rev in ((da, a, False), (db, bb, True)):
@@ -127,14 +109,11 @@ def test_dual_vs_oracle(oracle, monkeypatch, itype, shape, want, layout1, o4):
     check(da[7], dz_want, tol_for("dz", itype, "oracle"), "dz (both directions) vs oracle")
 
 
-@pytest.mark.parametrize("o4", [False, True])
-def test_dual_softplus_extremes(oracle, monkeypatch, o4):
-    """delta + bias far below 0 (softplus underflows towards 0: the epilogue's u = (delta u) / delta and sigmoid = 1 - exp(-delta)
-    paths of the 128-VGPR body), around 0 and above the reference's threshold of 20 (softplus(t) = t, derivative 1)."""
+def test_dual_softplus_extremes(oracle, monkeypatch):
+    """delta + bias far below 0 (softplus underflows towards 0), around 0 and above the reference's threshold of 20
+    (softplus(t) = t, derivative 1)."""
     import selective_scan_cuda as ssc
     import vms_hip
-    if o4:
-        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")
     b, d, L = 8, 768, 272
     a, bb = list(_dir_inputs(b, d, L, torch.bfloat16, 50)), list(_dir_inputs(b, d, L, torch.bfloat16, 51))
     g = torch.Generator(device="cpu").manual_seed(52)
@@ -149,7 +128,7 @@ def test_dual_softplus_extremes(oracle, monkeypatch, o4):
     dout = torch.randn(b, d, L, generator=g).to(torch.bfloat16).to(DEV)
     fw = [ssc.fwd(*t[:6], z, t[6], True, reverse=(i == 1)) for i, t in enumerate((a, bb))]
     da, db = ssc.bwd_dual((*a[:6], a[6], fw[0][1], fw[0][0]), (*bb[:6], bb[6], fw[1][1], fw[1][0]), z, dout, torch.empty_like(z), True, keep_fp32=True)
-    assert vms_hip.last_kernel() == ("scan_bwd_o4_dual_w4" if o4 else "scan_bwd_pair4_dual_w4")
+    assert vms_hip.last_kernel() == "scan_bwd_pair4_dual_w4"
     f = lambda t: t.detach().float().cpu().numpy()
     for got, inp, rev in ((da, a, False), (db, bb, True)):
         u, delta, A, B, C, D, bias = [f(t) for t in inp]
@@ -201,13 +180,10 @@ def test_block_backward_dual_vs_two_launches(monkeypatch, shape):
         check(g1[k], g0[k], 2e-2, f"block {k}: dual vs two launches")
 
 
-@pytest.mark.parametrize("o4", [False, True])
-def test_dual_with_groups(monkeypatch, o4):
+def test_dual_with_groups(monkeypatch):
     """two B / C groups: a 16-row workgroup of the 4-wave grid never straddles a group ((dim / n_groups) % 32 == 0)"""
     import selective_scan_cuda as ssc
     import vms_hip
-    if o4:
-        monkeypatch.setattr(_dbg(), "scan_impl", "occ4")
     b, d, L, G = 8, 768, 272, 2
     a, bb = list(_dir_inputs(b, d, L, torch.bfloat16, 30)), list(_dir_inputs(b, d, L, torch.bfloat16, 31))
     for t in (a, bb):
@@ -220,10 +196,10 @@ def test_dual_with_groups(monkeypatch, o4):
     ra = ssc.bwd(*a[:6], z, a[6], dout, fw[0][1], fw[0][0], dz_ref, True, False, keep_fp32=True)
     rb = ssc.bwd(*bb[:6], z, bb[6], dout, fw[1][1], fw[1][0], dz_ref, True, False, reverse=True, keep_fp32=True, accumulate_dz=True)
     da, db = ssc.bwd_dual((*a[:6], a[6], fw[0][1], fw[0][0]), (*bb[:6], bb[6], fw[1][1], fw[1][0]), z, dout, torch.empty_like(z), True, keep_fp32=True)
-    assert vms_hip.last_kernel() == ("scan_bwd_o4_dual_w4" if o4 else "scan_bwd_pair4_dual_w4")
+    assert vms_hip.last_kernel() == "scan_bwd_pair4_dual_w4"
     for got, ref in ((da, ra), (db, rb)):
         for k, name in enumerate(NAMES):
-            tol = (2 ** -7 if name in ("du", "ddelta") else 1e-4) if o4 else (0.0 if name in ("du", "ddelta") else 2e-5)
+            tol = 0.0 if name in ("du", "ddelta") else 2e-5
             assert rel_err(got[k], ref[k]) <= tol, name
     check(da[7], ra[7], 2 ** -7, "dz")
 

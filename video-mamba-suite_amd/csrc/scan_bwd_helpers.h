@@ -1,4 +1,4 @@
-// scan_bwd_helpers.h -- what the whole-vector backward scan kernels share (selective_scan_bwd_pair.hip, selective_scan_bwd_occ4.hip):
+// scan_bwd_helpers.h -- what the whole-vector backward scan kernels share (selective_scan_bwd_pair.hip; round 5's 128-VGPR experiment, profiles/r05_bwd_occ4.patch, shares them):
 // the lane's 8 elements as raw 16-byte vectors, direction-aware stores, DPP row scans, packed-fma and LDS-barrier wrappers.
 #pragma once
 #include "vms_common.h"

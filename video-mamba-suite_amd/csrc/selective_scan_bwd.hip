@@ -406,7 +406,7 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
                mult16(q.du_d_stride, es) && mult16(q.ddelta_batch_stride, es) && mult16(q.ddelta_d_stride, es);
     if (p.z) vec = vec && aligned16(q.dz) && mult16(q.dz_batch_stride, es) && mult16(q.dz_d_stride, es);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_OCC4 && p.segments >= 0, "impl / segments out of range");
+    VMS_CHECK(scan_impl_valid(p.impl) && p.segments >= 0, "impl / segments out of range");
     if (p.is_complex) return launch_scan_bwd_complex(q, vec, s);
     const int level = scan_impl_level(p);
     // short rows (selective_scan_short.hip): the states are rebuilt from h = 0 in the lane, x is not read
@@ -429,7 +429,7 @@ static bool scan_bwd_dual_checks_ok(const vms_scan_bwd_params& a, const vms_scan
     if (!(a.dout && a.du && a.ddelta && a.dA && a.dB && a.dC && b.dout && b.du && b.ddelta && b.dA && b.dB && b.dC)) return false;
     if ((pa.D == nullptr) != (a.dD == nullptr) || (pb.D == nullptr) != (b.dD == nullptr)) return false;
     if ((pa.delta_bias == nullptr) != (a.ddelta_bias == nullptr) || (pb.delta_bias == nullptr) != (b.ddelta_bias == nullptr)) return false;
-    if (pa.impl < VMS_IMPL_AUTO || pa.impl > VMS_IMPL_OCC4 || pb.impl != pa.impl || pa.segments < 0 || pb.segments < 0) return false;
+    if (!scan_impl_valid(pa.impl) || pb.impl != pa.impl || pa.segments < 0 || pb.segments < 0) return false;
     return scan_impl_level(pa) >= VMS_IMPL_PAIR;
 }
 

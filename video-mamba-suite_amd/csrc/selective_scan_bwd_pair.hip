@@ -1370,15 +1370,7 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
     return VMS_OK;
 }
 
-// selective_scan_bwd_occ4.hip: the same call in <= 128 VGPRs (4 waves per SIMD)
-bool scan_bwd_o4_dual_takes(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b);
-int launch_scan_bwd_o4_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream);
-#ifndef VMS_BWD_O4
-#define VMS_BWD_O4 1   /* 0 (A/B builds): no 128-VGPR kernel even where vms_scan_impl asks for it */
-#endif
-
 int launch_scan_bwd_pair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_params& b, hipStream_t stream) {
-    if (VMS_BWD_O4 && scan_bwd_o4_dual_takes(a, b)) return launch_scan_bwd_o4_dual(a, b, stream);
     switch (a.f.dtype) {
         case VMS_BF16: return launch_bpair_dual<bf16_t>(a, b, stream);
         case VMS_F16: return launch_bpair_dual<f16_t>(a, b, stream);

@@ -280,7 +280,7 @@ extern "C" int vms_selective_scan_fwd(const vms_scan_fwd_params* pp, void* strea
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool vec = scan_fwd_vec_ok(p);
     if (p.is_complex) return launch_scan_fwd_complex(p, vec, s);
-    VMS_CHECK(p.impl >= VMS_IMPL_AUTO && p.impl <= VMS_IMPL_OCC4 && p.segments >= 0, "impl / segments out of range");
+    VMS_CHECK(scan_impl_valid(p.impl) && p.segments >= 0, "impl / segments out of range");
     const int level = scan_impl_level(p);
     VMS_CHECK(p.x_has_sub != 2, "x_has_sub == 2 (the row-major layout of rounds 1-3) is no longer built");
     // short rows, many of them (TimeMamba's scans along time: seqlen 4 ... 16, batch x 196 rows per channel): a lane per row

@@ -242,8 +242,9 @@ struct PerDeviceOnce {
 void scan_fwd_sub_batches(const vms_scan_fwd_params& p, vms_scan_fwd_params& lo, vms_scan_fwd_params& hi);
 bool scan_fwd_pair_native_mixed(const vms_scan_fwd_params& p);   // selective_scan_fwd_pair.hip: reverse_from in one launch
 bool scan_bwd_pair_native_mixed(const vms_scan_bwd_params& q);   // selective_scan_bwd_pair.hip
-// scan kernel generation a call may use (vms_hip.h vms_scan_impl): AUTO = OCC4 = PAIR
-inline int scan_impl_level(const vms_scan_fwd_params& p) { return p.impl == VMS_IMPL_AUTO || p.impl == VMS_IMPL_OCC4 ? VMS_IMPL_PAIR : p.impl; }
+// scan kernel generation a call may use (vms_hip.h vms_scan_impl): AUTO = PAIR
+inline bool scan_impl_valid(int impl) { return impl == VMS_IMPL_AUTO || impl == VMS_IMPL_GENERIC || impl == VMS_IMPL_PAIR; }
+inline int scan_impl_level(const vms_scan_fwd_params& p) { return p.impl == VMS_IMPL_AUTO ? VMS_IMPL_PAIR : p.impl; }
 
 #define VMS_CHECK(cond, ...)                                              \
     do {                                                                  \

@@ -184,9 +184,9 @@ EXPORTS = (
     "vms_conv_xproj_dual", "vms_sizeof_conv_xproj_dual_params", "vms_layer_norm_bwd_finish", "vms_sum_slices",
 )
 
-ABI_VERSION = 10   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
-IMPL_AUTO, IMPL_GENERIC, IMPL_FAST, IMPL_PAIR, IMPL_ROWS, IMPL_OCC4 = 0, 1, 2, 3, 4, 5
-_IMPL_NAMES = {"g": IMPL_GENERIC, "f": IMPL_FAST, "p": IMPL_PAIR, "r": IMPL_ROWS, "o": IMPL_OCC4}
+ABI_VERSION = 11   # include/vms_hip.h VMS_ABI_VERSION: checked against libvms_hip.so and against the compiled binding
+IMPL_AUTO, IMPL_GENERIC, IMPL_PAIR = 0, 1, 3
+_IMPL_NAMES = {"g": IMPL_GENERIC, "p": IMPL_PAIR}
 
 
 class _Debug:
@@ -196,7 +196,7 @@ class _Debug:
     User-facing environment variables are only VMS_HIP_LIB (another build of the library), VMS_X_LAYOUT (checkpoint layout policy:
     1 | 3 | auto) and VMS_CHECKPOINT_LVL (the modules' recompute policy).
 
-    scan_impl        None | "generic" | "pair" | "occ4": vms_scan_impl of every scan call (vms_hip.h; None = the library's choice)
+    scan_impl        None | "generic" | "pair": vms_scan_impl of every scan call (vms_hip.h; None = the library's choice)
     force_generic    every scan on the generic kernels (the reference's full contract)
     fwd_segments     forced range count of the sequence-split forward scan (0 = the library's choice, 1 = never split)
     bwd_segments     the same for the backward scan
