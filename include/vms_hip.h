@@ -440,7 +440,7 @@ int vms_conv_xproj_dual(const vms_conv_xproj_dual_params *p, void *stream);
  * with conv1d_out recomputed from x exactly as vms_causal_conv1d_fwd computes it.  x (the conv's input), du (the scan's
  * gradient w.r.t. its input u), dx : (batch, dim, seqlen); dx_dbl : (batch, k, seqlen); all `dtype` (bf16 / fp16), unit
  * seqlen stride; w_x = x_proj.weight (k, dim) in `dtype`, any strides; conv weight (dim, width), bias (dim) or NULL in
- * `wdtype`; dconv_weight (dim, width), dconv_bias (dim), dw_x (k, dim): fp32 [zeroed] accumulators.  33 <= k <= 96.
+ * `wdtype`; dconv_weight (dim, width), dconv_bias (dim), dw_x (k, dim): fp32 [zeroed] accumulators.  1 <= k <= 96 (k <= 32 since ABI v11).
  * seqlen % 8 == 0 needs 16-byte aligned bases and strides that are multiples of 8 elements (whole-vector pieces); any other
  * seqlen runs the ragged flavour (2-byte aligned rows, the row's last piece element by element).
  * reverse / reverse_from / dx_accumulate as in vms_conv_bwd_params. */

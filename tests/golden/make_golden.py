@@ -318,6 +318,15 @@ def gen_block(mods, name, which, d_model=32, L=33, batch=2, expand=2, d_state=8,
     save(name, x=npf(x), y=npf(y), g=npf(g), dx=npf(x.grad), **arrs)
 
 
+def gen_blocks6(mods):
+    """module-level fixtures of round 6: d_inner a multiple of 32 and lengths the mixers pad to whole vectors, so that
+    the GPU test runs the dstate-4 instantiations of the fast kernels; the fixture itself is the reference's slow path on CPU"""
+    gen_block(mods, "block_vim_n4_div", "simple", d_model=64, L=81, batch=2, expand=2, d_state=4, seed=21, if_devide_out=True)
+    gen_block(mods, "block_vim_n4", "simple", d_model=32, L=1041, batch=1, expand=2, d_state=4, seed=22)
+    gen_block(mods, "block_dbm_n4", "new", d_model=64, L=96, batch=2, expand=1, d_state=4, seed=23)
+    gen_block(mods, "block_vim_e2_n16", "simple", d_model=64, L=160, batch=2, expand=2, d_state=16, seed=24)
+
+
 def gen_stack(mods, name, norm="ln", residual_in_fp32=False, n_layers=3, d_model=32, L=37, batch=2, seed=0):
     """A stack of the reference's own Block (mamba_simple.py:381-437, fused_add_norm=False: no Triton) around its ViM
     mixer (use_fast_path=False), closed the way the suite's backbones close it (final add + norm_f).  norm = "ln":
@@ -443,6 +452,11 @@ def main():
         cci, ssi = load_reference()
         gen_cscan_all(ssi)
         return
+    if os.environ.get("GOLDEN_ONLY") == "blocks6":  # round 6: d_state = 4 (the suite's CLIP ViViM, model_clip.py:945-947) and expand = 2 at d_state 16
+        cci, ssi = load_reference()
+        mods = load_reference_modules(ssi)
+        gen_blocks6(mods)
+        return
     if os.environ.get("GOLDEN_ONLY") == "stack":  # add the Block-stack fixtures without touching the others
         cci, ssi = load_reference()
         mods = load_reference_modules(ssi)
@@ -518,6 +532,7 @@ def main():
     gen_block(mods, "block_vim_div", "simple", if_devide_out=True, L=257, batch=1)
     gen_block(mods, "block_vim_norm", "norm", if_devide_out=True)
     gen_block(mods, "block_dbm", "new", expand=1)
+    gen_blocks6(mods)
     print("block stacks:")
     gen_stack(mods, "stack_ln", "ln", False, seed=11)
     gen_stack(mods, "stack_rms_fp32res", "rms", True, seed=12)

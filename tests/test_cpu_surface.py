@@ -219,6 +219,11 @@ def test_inner768_host_logic(fake_extensions, name):
     ("block_vim_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),
     ("block_vim_norm", "mamba_simple_scan_norm", dict(bimamba_type="v2", if_devide_out=True)),
     ("block_dbm", "mamba_new", dict(expand=1)),
+    # round 6: d_state = 4 (the suite's CLIP ViViM, avion/models/model_clip.py:945-947) and expand = 2 at d_state 16
+    ("block_vim_n4_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),
+    ("block_vim_n4", "mamba_simple", dict(bimamba_type="v2")),
+    ("block_dbm_n4", "mamba_new", dict(expand=1)),
+    ("block_vim_e2_n16", "mamba_simple", dict(bimamba_type="v2")),
 ])
 @pytest.mark.parametrize("fast", [True, False])
 def test_block_host_logic(fake_extensions, name, which, kw, fast):
@@ -227,7 +232,7 @@ def test_block_host_logic(fake_extensions, name, which, kw, fast):
     g = load_golden(name)
     Mamba = importlib.import_module("mamba_ssm.modules." + which).Mamba
     sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")}
-    m = Mamba(g["x"].shape[-1], d_state=8, d_conv=4, use_fast_path=fast, **({"expand": 2} | kw))
+    m = Mamba(g["x"].shape[-1], d_state=g["sd.A_log"].shape[1], d_conv=4, use_fast_path=fast, **({"expand": 2} | kw))
     assert sorted(m.state_dict().keys()) == sorted(sd.keys())
     m.load_state_dict(sd)
     x = T(g["x"], grad=True)

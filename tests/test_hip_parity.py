@@ -856,10 +856,15 @@ def test_dispatch_is_visible_and_parameter_driven(monkeypatch):
     selective_scan_cuda.bwd(*args[:8], f("g"), x, out, None, True, False)
     assert vms_hip.last_kernel() == "scan_bwd_generic"
     monkeypatch.setattr(_dbg(), "scan_impl", None)
-    # dstate 8 is outside the fast paths: the generic kernels take it, and say so
+    # dstate 8 (and 4) have their own instantiation of the LDS forward since round 6 (tests/test_small_dstate.py) ...
     A8 = -torch.rand(64, 8, device=DEV)
     B8 = torch.randn(1, 1, 8, 16384, device=DEV, dtype=torch.bfloat16)
     selective_scan_cuda.fwd(args[0], args[1], A8, B8, B8, None, None, None, True)
+    assert vms_hip.last_kernel() == "scan_fwd_pair_lds_n"
+    # ... dstate 12 is outside the fast paths: the generic kernels take it, and say so
+    A12 = -torch.rand(64, 12, device=DEV)
+    B12 = torch.randn(1, 1, 12, 16384, device=DEV, dtype=torch.bfloat16)
+    selective_scan_cuda.fwd(args[0], args[1], A12, B12, B12, None, None, None, True)
     assert vms_hip.last_kernel() == "scan_fwd_generic"
 
 
@@ -1506,6 +1511,11 @@ def test_inner768_vs_reference_fixtures(name):
     ("block_vim_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),
     ("block_vim_norm", "mamba_simple_scan_norm", dict(bimamba_type="v2", if_devide_out=True)),
     ("block_dbm", "mamba_new", dict(expand=1)),
+    # round 6: d_state = 4 (the suite's CLIP ViViM, avion/models/model_clip.py:945-947) and expand = 2 at d_state 16
+    ("block_vim_n4_div", "mamba_simple", dict(bimamba_type="v2", if_devide_out=True)),
+    ("block_vim_n4", "mamba_simple", dict(bimamba_type="v2")),
+    ("block_dbm_n4", "mamba_new", dict(expand=1)),
+    ("block_vim_e2_n16", "mamba_simple", dict(bimamba_type="v2")),
 ])
 @pytest.mark.parametrize("fast", [True, False])
 def test_block_vs_golden(name, which, kw, fast):
@@ -1515,7 +1525,7 @@ def test_block_vs_golden(name, which, kw, fast):
     g = load_golden(name)
     Mamba = importlib.import_module("mamba_ssm.modules." + which).Mamba
     sd = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")}
-    m = Mamba(g["x"].shape[-1], d_state=8, d_conv=4, use_fast_path=fast, **({"expand": 2} | kw))
+    m = Mamba(g["x"].shape[-1], d_state=g["sd.A_log"].shape[1], d_conv=4, use_fast_path=fast, **({"expand": 2} | kw))
     m.load_state_dict(sd)
     m = m.to(DEV)
     x = G(g["x"], grad=True)

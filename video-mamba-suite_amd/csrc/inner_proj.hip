@@ -1326,6 +1326,8 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
 template <typename T>
 static int dispatch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream, const int entry) {
     switch ((p.k + 15) / 16) {
+        case 1:
+        case 2: return launch_conv_bwd<T, 2>(p, stream, entry);   // k <= 32 (dt_rank + 2 d_state of the suite's d_state = 4 model: 20): one 32-deep k step
         case 3: return launch_conv_bwd<T, 3>(p, stream, entry);
         case 4: return launch_conv_bwd<T, 4>(p, stream, entry);
         case 5: return launch_conv_bwd<T, 5>(p, stream, entry);
@@ -1486,7 +1488,7 @@ extern "C" int vms_proj_conv_bwd(const vms_proj_conv_bwd_params* pp, void* strea
     VMS_CHECK(p.dtype == VMS_BF16 || p.dtype == VMS_F16, "proj_conv_bwd: 16-bit activations only (bf16 / fp16)");
     VMS_CHECK(p.wdtype == VMS_F32 || p.wdtype == VMS_F16 || p.wdtype == VMS_BF16, "conv weight dtype must be fp32/fp16/bf16");
     VMS_CHECK(p.batch > 0 && p.dim > 0 && p.seqlen > 0, "empty problem");
-    VMS_CHECK(p.k >= 33 && p.k <= 96, "proj_conv_bwd: 33 <= k <= 96");
+    VMS_CHECK(p.k >= 1 && p.k <= 96, "proj_conv_bwd: 1 <= k <= 96");
     VMS_CHECK(p.width >= 2 && p.width <= 4, "causal_conv1d only supports width between 2 and 4");
     VMS_CHECK(p.x && p.du && p.dx_dbl && p.w_x && p.conv_weight && p.dx && p.dconv_weight && p.dw_x, "x, du, dx_dbl, w_x, conv_weight, dx, dconv_weight, dw_x are required");
     VMS_CHECK(!(p.reverse && p.reverse_from), "reverse and reverse_from are exclusive");

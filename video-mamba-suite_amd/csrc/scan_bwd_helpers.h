@@ -92,9 +92,9 @@ __device__ __forceinline__ void store_stream_b(T* __restrict__ ptr, const float 
 
 // element offset (inside a row's x) of the state after the first 128 (e128 + 1) elements for state n: the 128-element
 // sub-checkpoints of x_has_sub == 1, or every 16th of the 8-element checkpoints of x_has_sub == 3 (vms_hip.h)
-__device__ __forceinline__ uint32_t x_sub_off(int e128, int n, int pitch, bool lane_ckpt) {
-    return lane_ckpt ? (uint32_t)((e128 >> 4) * pitch + 2 * kBN + ((n >> 2) * 256 + (e128 & 15) * 16 + 15) * 4 + (n & 3))
-                     : (uint32_t)((e128 >> 4) * pitch + 2 * kBN + (e128 & 15) * kBN + n);
+__device__ __forceinline__ uint32_t x_sub_off(int e128, int n, int pitch, bool lane_ckpt, int dstate) {
+    return lane_ckpt ? (uint32_t)((e128 >> 4) * pitch + 2 * dstate + ((n >> 2) * 256 + (e128 & 15) * 16 + 15) * 4 + (n & 3))
+                     : (uint32_t)((e128 >> 4) * pitch + 2 * dstate + (e128 & 15) * dstate + n);
 }
 
 template <int CTRL>

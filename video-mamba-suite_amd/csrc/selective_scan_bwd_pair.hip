@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBQ* kWave) void scan_bwd_pair_kernel(const vms_sca
         }
         // state entering chunk cc = 128-element sub-checkpoint cc-1 (vms_hip.h); lane j loads state j
         const int e128 = cc * (CH / 128) - 1;
-        const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, j, (int)p.x_chunk_stride, p.x_has_sub == 3) : 0u;
+        const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, j, (int)p.x_chunk_stride, p.x_has_sub == 3, kBN) : 0u;
         hck_next = x_b[xo];
     };
     const int cps = (n_c + n_seg - 1) / n_seg;                        // chunks per segment
@@ -480,14 +480,20 @@ template <int W> struct B4 {
 // `out` (the single-direction call); 1 = dz = dout (out + out2) dsilu(z) -- the gradient z receives through BOTH directions,
 // which is linear in the pre-gate outputs (out2 = the other direction's, same physical positions); 2 = no dz (the other
 // direction's workgroups write it).  bid / nblk: this problem's workgroup index and count inside the launch.
-template <typename T, bool HZ, bool REV, int W, bool XL, int DZM = 0>
+// NT: dstate as a compile-time value (16: the tuned instantiations) or 0 = p.dstate in {4, 8} at run time (round 6; W = 4 only: its
+// 2-state slab groups give an even number of groups per chunk for every such N, which the double-buffered slab needs).  The LDS
+// layouts keep their 16-state pitches; states >= N are neither staged nor walked, and the lanes j >= N of a row -- which hold A, the
+// carried adjoint and dA of state j -- touch no memory.
+template <typename T, bool HZ, bool REV, int W, bool XL, int DZM = 0, int NT = kBN>
 __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q, const int n_seg, const float2* __restrict__ seg_carry,
                                                     const int bid, const int nblk, const T* __restrict__ out2_b = nullptr,
                                                     const int64_t out2_batch_stride = 0, const int64_t out2_d_stride = 0,
                                                     const int sub_m = 1) {
     const vms_scan_fwd_params& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = kBK, N = kBN, CH = kCH;
+    constexpr int K = kBK, CH = kCH;
+    static_assert(NT == kBN || (NT == 0 && W == 4), "run-time dstate: 4-wave workgroups only");
+    const int N = NT ? NT : p.dstate;
     constexpr int kB4Pair = B4<W>::kPair, PPT = B4<W>::kPPT, kRows4 = B4<W>::kRows;
     lds_f4* const bc4 = (lds_f4*)smem;                                   // fp32 B / C of the chunk: [tensor][state][128]
     lds_f4* const slab4 = (lds_f4*)(smem + kBcFloats);                   // [buf][par][wave][lane] float4
@@ -524,31 +530,33 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     const float* const x_b = static_cast<const float*>(p.x);
     const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
-    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)j * p.A_dstate_stride];
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)(NT || j < N ? j : 0) * p.A_dstate_stride];
 
     float dAacc = 0.f, dD_acc = 0.f, dbias_acc = 0.f;
 
     // B / C staging of the NEXT chunk: piece (tensor, state, j) = 8 values of one state; a thread owns PPT pieces
     RawB<T, REV> stg[PPT];
     bool st_ok = false;
+    auto piece_state = [&](int h) __attribute__((always_inline)) { return (((int)threadIdx.x + W * kWave * h) >> 4) & 15; };
     auto piece_src = [&](int h) __attribute__((always_inline)) {
-        const int pid = (int)threadIdx.x + W * kWave * h, ten = pid >> 8, n = (pid >> 4) & 15;
+        const int pid = (int)threadIdx.x + W * kWave * h, ten = pid >> 8, n = NT || piece_state(h) < N ? piece_state(h) : 0;
         return ten ? Cv + (int64_t)n * p.C_dstate_stride : Bv + (int64_t)n * p.B_dstate_stride;
     };
     auto stage_issue = [&](int cc) __attribute__((always_inline)) {
         const int ll = cc * CH + j * K;
         st_ok = cc >= 0 && ll < L;
 #pragma unroll
-        for (int h = 0; h < PPT; ++h) stg[h].load(piece_src(h), REV ? L - ll - K : ll, st_ok);
+        for (int h = 0; h < PPT; ++h) stg[h].load(piece_src(h), REV ? L - ll - K : ll, st_ok && (NT || piece_state(h) < N));
     };
     auto stage_commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int h = 0; h < PPT; ++h) {
             f32x4 lo, hi;
+            const bool okh = st_ok && (NT || piece_state(h) < N);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                lo[i] = st_ok ? stg[h].at(i) : 0.f;
-                hi[i] = st_ok ? stg[h].at(4 + i) : 0.f;
+                lo[i] = okh ? stg[h].at(i) : 0.f;
+                hi[i] = okh ? stg[h].at(4 + i) : 0.f;
             }
             const int pid = (int)threadIdx.x + W * kWave * h;
             lds_f4* dst = bc4 + ((pid >> 4) * CH) / 4 + j;   // (tensor * N + state) * CH
@@ -583,7 +591,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     float hck_next = 0.f;
     // XL (x_has_sub == 3): the forward left the state after every 8 elements; a lane takes the one entering its elements
     // instead of rebuilding it (its own 8-step recurrence from zero + the row scan of the lane aggregates)
-    float xin[XL ? N : 1];
+    float xin[XL ? kBN : 1];
     // one buffer resource per batch entry (workgroup-uniform): a batch entry's x stays under 2 GiB (host)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(x_b) + (XL ? (int64_t)b * p.dim * p.n_chunks * p.x_chunk_stride : 0), 0,
@@ -618,7 +626,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         }
         if constexpr (!XL) {
             const int e128 = cc * (CH / 128) - 1;
-            const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, j, (int)p.x_chunk_stride, p.x_has_sub == 3) : 0u;
+            const uint32_t xo = cc > 0 ? o_x + x_sub_off(e128, NT || j < N ? j : 0, (int)p.x_chunk_stride, p.x_has_sub == 3, N) : 0u;
             hck_next = x_b[xo];
         }
     };
@@ -641,7 +649,8 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     request_row(c_hi - 1);
     if constexpr (XL) {
 #pragma unroll
-        for (int n0 = 0; n0 < N; n0 += 4) request_x(c_hi - 1, n0);
+        for (int n0 = 0; n0 < kBN; n0 += 4)
+            if (NT || n0 < N) request_x(c_hi - 1, n0);
     }
     stage_issue(c_hi - 1);
     stage_commit();
@@ -733,7 +742,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
             }
             // fp32 B / C of this state, shared by the workgroup's 32 rows
             const lds_f4* bsrc = bc4 + (n * CH) / 4 + j;
-            const f32x4 b0 = bsrc[0], b1 = bsrc[16], c0 = bsrc[N * CH / 4], c1 = bsrc[N * CH / 4 + 16];
+            const f32x4 b0 = bsrc[0], b1 = bsrc[16], c0 = bsrc[kBN * CH / 4], c1 = bsrc[kBN * CH / 4 + 16];   // (the LDS layout keeps its 16-state pitch)
             // 4 wave partials of the PREVIOUS pair (other slab buffer): W = 8: half of this thread's one output;
             // W = 4: all of its output of state `par`
             float rdv[4];
@@ -853,12 +862,14 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
         };
         if constexpr (XL) {   // unrolled: xin[n] is a register
 #pragma unroll
-            for (int n = 0; n < N; n += 4) {
-                do_state(n, 0);
-                do_state(n + 1, 1);
-                do_state(n + 2, 2);
-                do_state(n + 3, 3);
-                request_x(c - 1, n);
+            for (int n = 0; n < kBN; n += 4) {
+                if (NT || n < N) {
+                    do_state(n, 0);
+                    do_state(n + 1, 1);
+                    do_state(n + 2, 2);
+                    do_state(n + 3, 3);
+                    request_x(c - 1, n);
+                }
             }
         } else {
 #pragma unroll 1
@@ -916,7 +927,7 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
     if (row_ok) {
         if (q.dD && j == 0) atomicAdd(q.dD + d, dD_tot);
         if (q.ddelta_bias && j == 0) atomicAdd(q.ddelta_bias + d, db_tot);
-        atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)j * q.dA_dstate_stride, dAacc);
+        if (NT || j < N) atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)j * q.dA_dstate_stride, dAacc);
     }
 }
 
@@ -924,16 +935,16 @@ __device__ __forceinline__ void scan_bwd_pair4_body(const vms_scan_bwd_params& q
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from).  A workgroup serves one batch
 // entry: the direction is workgroup-uniform, one branch selects the body.
 // XL: x carries the forward's 8-element checkpoints (x_has_sub == 3), < 2 GiB per batch entry (one buffer resource each)
-template <typename T, bool HZ, int RM, int W, bool XL>
+template <typename T, bool HZ, int RM, int W, bool XL, int NT = kBN>
 __global__ __launch_bounds__(W* kWave, 2) void scan_bwd_pair4_kernel(const vms_scan_bwd_params q, const int n_seg, const float2* __restrict__ seg_carry,
                                                                     const int sub_m) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % q.f.batch;
-        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
-        else scan_bwd_pair4_body<T, HZ, false, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
+        if (b >= q.f.reverse_from) scan_bwd_pair4_body<T, HZ, true, W, XL, 0, NT>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
+        else scan_bwd_pair4_body<T, HZ, false, W, XL, 0, NT>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
     } else {
-        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
+        scan_bwd_pair4_body<T, HZ, RM == 1, W, XL, 0, NT>(q, n_seg, seg_carry, blockIdx.x, gridDim.x, nullptr, 0, 0, sub_m);
     }
 }
 
@@ -944,14 +955,14 @@ __global__ __launch_bounds__(W* kWave, 2) void scan_bwd_pair4_kernel(const vms_s
 // needs its 2 waves per SIMD, profiles/r03_bwd_segments.md).  Together, as 768 workgroups of W = 4 waves (one wave per SIMD
 // each, two resident per CU), the grid is 1.5 rounds whose last half-round runs one wave per SIMD at 0.7x the time:
 // 2 x 317 -> 489 us (profiles/r04_dual_bwd.md).
-template <typename T, int W, bool XL>
+template <typename T, int W, bool XL, int NT = kBN>
 __global__ __launch_bounds__(W* kWave, 2) void scan_bwd_pair4_dual_kernel(const vms_scan_bwd_params qa, const vms_scan_bwd_params qb) {
     const int half = gridDim.x >> 1;
     if ((int)blockIdx.x < half) {
-        scan_bwd_pair4_body<T, true, false, W, XL, 1>(qa, 1, nullptr, blockIdx.x, half, static_cast<const T*>(qb.f.out),
-                                                       qb.f.out_batch_stride, qb.f.out_d_stride);
+        scan_bwd_pair4_body<T, true, false, W, XL, 1, NT>(qa, 1, nullptr, blockIdx.x, half, static_cast<const T*>(qb.f.out),
+                                                           qb.f.out_batch_stride, qb.f.out_d_stride);
     } else {
-        scan_bwd_pair4_body<T, true, true, W, XL, 2>(qb, 1, nullptr, blockIdx.x - half, half);
+        scan_bwd_pair4_body<T, true, true, W, XL, 2, NT>(qb, 1, nullptr, blockIdx.x - half, half);
     }
 }
 
@@ -1135,7 +1146,7 @@ bool scan_bwd_pair_native_mixed(const vms_scan_bwd_params& q) {
 // Rule: floor(CUs / workgroups) ranges, at least 3 chunks (384 elements) per range, at most 16.
 int scan_bwd_pair_segments(const vms_scan_bwd_params& q) {
     const vms_scan_fwd_params& p = q.f;
-    if (p.seqlen % kBK != 0) return 1;
+    if (p.seqlen % kBK != 0 || p.dstate != kBN) return 1;   // (dstate 4 / 8: unsplit; the carry kernel is built for 16)
     const int n_c = (p.seqlen + kCH - 1) / kCH;
     const int n_wg = p.batch * ((p.dim + kBRows - 1) / kBRows);
     int want;
@@ -1173,22 +1184,23 @@ static int scan_bwd_carry_sub(const vms_scan_bwd_params& q, int n_seg) {
 // would scan_bwd_pair4_kernel<.., XL = true> serve the backward of this forward?  (the shape conditions of
 // scan_bwd_pair_eligible + whole-vector rows + one buffer resource over x at the 258 * dstate pitch)
 bool scan_bwd_pair_lane_ckpt_ok(const vms_scan_fwd_params& p) {
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || p.n_groups < 1 || p.dim % p.n_groups != 0) return false;
+    if (!p.is_variable_B || !p.is_variable_C || (p.dstate != kBN && p.dstate != 8 && p.dstate != 4) || p.n_groups < 1 || p.dim % p.n_groups != 0) return false;
     if ((p.dim / p.n_groups) % kBRows != 0) return false;
     // seqlen % 16 == 0: the forward's LDS kernel writes the checkpoints as whole lines; the per-wave kernel that serves other
     // lengths writes them 4 bytes at a time ((8, 768, 3144): forward 167 -> 226 us for a backward 396 -> 359 us)
     if (p.seqlen % 16 != 0) return false;
     const int64_t n_chunks = (p.seqlen + 2047) / 2048, lim = (int64_t)1 << 31;
     // a batch entry's x under 2 GiB (one buffer resource per batch entry), all of x under 2^31 elements (scan_bwd_pair_eligible)
-    return (int64_t)p.dim * n_chunks * 258 * kBN * 4 < lim && (int64_t)p.batch * p.dim * n_chunks * 258 * kBN < lim;
+    return (int64_t)p.dim * n_chunks * 258 * p.dstate * 4 < lim && (int64_t)p.batch * p.dim * n_chunks * 258 * p.dstate < lim;
 }
 
 bool scan_bwd_pair_eligible(const vms_scan_bwd_params& q, bool vec) {
     const vms_scan_fwd_params& p = q.f;
     (void)vec;  // 16-byte vector accesses need no alignment on gfx950
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kBN || !p.x || (p.x_has_sub != 1 && p.x_has_sub != 3)) return false;
+    if (!p.is_variable_B || !p.is_variable_C || (p.dstate != kBN && p.dstate != 8 && p.dstate != 4) || !p.x || (p.x_has_sub != 1 && p.x_has_sub != 3)) return false;
     const int dpg = p.dim / p.n_groups;
     if (dpg % kBRows != 0) return false;     // a workgroup's rows must share one B/C group
+    if (p.dstate != kBN && p.seqlen % kBK != 0) return false;   // dstate 4 / 8 (round 6): the whole-vector kernel only
     if (p.seqlen % kBK != 0 && p.bc_pad < kBK - p.seqlen % kBK) return false;   // ragged: B / C padding needed
     // 32-bit element offsets inside the kernel
     const int64_t lim = (int64_t)1 << 31;
@@ -1276,9 +1288,34 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
     const dim3 grid4(p.batch * ((p.dim + 4 * WK - 1) / (4 * WK)) * (grid.x / (p.batch * tiles))), block4(WK * kWave);
     // the forward's 8-element checkpoints (x_has_sub == 3), addressed through one buffer resource
     const bool xl = p.x_has_sub == 3 && (int64_t)p.dim * p.n_chunks * p.x_chunk_stride * 4 < ((int64_t)1 << 31);
+    // dstate 4 / 8: the run-time-dstate instantiation, 4-wave workgroups of 16 rows, never split
+    const bool small_n = p.dstate != kBN;
+    const dim3 grid_n(p.batch * ((p.dim + 15) / 16)), block_n(4 * kWave);
+    if (small_n && B4<4>::kSmem > 64 * 1024) {
+        static PerDeviceOnce attrn_once;
+        const hipError_t arcn = attrn_once.run([&]() -> hipError_t {
+            hipError_t e = hipSuccess;
+#define VMS_ANX(Z_, R_, X_)                                                                                              \
+            if (e == hipSuccess)                                                                                         \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_kernel<T, Z_, R_, 4, X_, 0>),       \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem)
+#define VMS_AN(Z_, R_) VMS_ANX(Z_, R_, false); VMS_ANX(Z_, R_, true)
+            VMS_AN(true, 0); VMS_AN(true, 1); VMS_AN(true, 2); VMS_AN(false, 0); VMS_AN(false, 1); VMS_AN(false, 2);
+#undef VMS_AN
+#undef VMS_ANX
+            return e;
+        });
+        if (arcn != hipSuccess) {
+            set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", (int)B4<4>::kSmem, hipGetErrorString(arcn));
+            return VMS_ERR_LAUNCH;
+        }
+    }
 #define VMS_L4(Z_, R_)                                                                                             \
     do {                                                                                                           \
-        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry, sub_m); \
+        if (small_n) {                                                                                             \
+            if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, 4, true, 0>), grid_n, block_n, B4<4>::kSmem, stream, q, 1, carry, 1); \
+            else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, 4, false, 0>), grid_n, block_n, B4<4>::kSmem, stream, q, 1, carry, 1);   \
+        } else if (xl) hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, true>), grid4, block4, smem4, stream, q, n_seg, carry, sub_m); \
         else hipLaunchKernelGGL((scan_bwd_pair4_kernel<T, Z_, R_, WK, false>), grid4, block4, smem4, stream, q, n_seg, carry, sub_m);   \
     } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
@@ -1295,7 +1332,8 @@ static int launch_bpair(const vms_scan_bwd_params& q, hipStream_t stream) {
 #undef VMS_L
 #undef VMS_L4
     VMS_LAUNCH_CHECK();
-    set_last_kernel(mixed ? (n_seg > 1 ? "scan_bwd_pair4+mixed+split" : "scan_bwd_pair4+mixed") : rag ? "scan_bwd_pair_ragged"
+    set_last_kernel(small_n ? (mixed ? "scan_bwd_pair4_n+mixed" : "scan_bwd_pair4_n")
+                        : mixed ? (n_seg > 1 ? "scan_bwd_pair4+mixed+split" : "scan_bwd_pair4+mixed") : rag ? "scan_bwd_pair_ragged"
                         : four ? (n_seg > 1 ? "scan_bwd_pair4+split" : "scan_bwd_pair4")
                                : (n_seg > 1 ? "scan_bwd_pair+split" : "scan_bwd_pair"));
     return VMS_OK;
@@ -1333,7 +1371,8 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
     // whole rounds of 8-wave workgroups at 2 waves per SIMD (the benchmark shape: 512 workgroups = 2 per CU) are the better
     // kernel (793 vs 835 us per direction there); everything else runs 4-wave workgroups, whose partial last round has one
     // wave per SIMD (profiles/r04_dual_bwd.md)
-    const bool w8 = (2 * n8) % cus == 0;
+    const bool small_n = p.dstate != kBN;                  // dstate 4 / 8: the run-time-dstate instantiation (4-wave workgroups)
+    const bool w8 = (2 * n8) % cus == 0 && !small_n;
     const bool xl = p.x_has_sub == 3;
     if (B4<8>::kSmem > 64 * 1024 || B4<4>::kSmem > 64 * 1024) {
         static PerDeviceOnce attrd_once;
@@ -1349,6 +1388,12 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 4, false>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 4, true, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_bwd_pair4_dual_kernel<T, 4, false, 0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)B4<4>::kSmem);
             return e;
         });
         if (arc != hipSuccess) {
@@ -1360,13 +1405,17 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
         const dim3 grid(2 * n8), block(8 * kWave);
         if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 8, true>), grid, block, B4<8>::kSmem, stream, a, b);
         else hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 8, false>), grid, block, B4<8>::kSmem, stream, a, b);
+    } else if (small_n) {
+        const dim3 grid(2 * p.batch * ((p.dim + 15) / 16)), block(4 * kWave);
+        if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, true, 0>), grid, block, B4<4>::kSmem, stream, a, b);
+        else hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, false, 0>), grid, block, B4<4>::kSmem, stream, a, b);
     } else {
         const dim3 grid(2 * p.batch * ((p.dim + 15) / 16)), block(4 * kWave);
         if (xl) hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, true>), grid, block, B4<4>::kSmem, stream, a, b);
         else hipLaunchKernelGGL((scan_bwd_pair4_dual_kernel<T, 4, false>), grid, block, B4<4>::kSmem, stream, a, b);
     }
     VMS_LAUNCH_CHECK();
-    set_last_kernel(w8 ? "scan_bwd_pair4_dual_w8" : "scan_bwd_pair4_dual_w4");
+    set_last_kernel(w8 ? "scan_bwd_pair4_dual_w8" : small_n ? "scan_bwd_pair4_dual_n" : "scan_bwd_pair4_dual_w4");
     return VMS_OK;
 }
 

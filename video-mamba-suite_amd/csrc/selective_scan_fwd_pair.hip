@@ -379,10 +379,16 @@ struct Raw8 {
 // XC: the state after every 8 elements goes to x (vms_hip.h x_has_sub == 3)
 // TQ: the instantiation that also holds the four-states-at-a-time form of a row's last chunk (launched only for rows that have
 // such a chunk: with the form compiled in, the whole-wave loop of (8, 1024, 8192) ran 2 % slower -- one more spilled register)
-template <typename T, bool HZ, bool REV, bool XC, bool TQ>
+// NT: dstate as a compile-time value (16: the tuned instantiation) or 0 = p.dstate in {4, 8} read at run time (round 6: the suite's
+// d_state = 4 model, avion/models/model_clip.py:945-947, ran on the generic kernels).  Everything N decides sits outside the
+// per-state body: the staged groups per chunk (N / 4), the checkpoint offsets, which lanes hold A / the running state.
+template <typename T, bool HZ, bool REV, bool XC, bool TQ, int NT>
 __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, const int n_seg, const float2* __restrict__ seg_carry) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int K = kPK, N = kPN, CS = kWave * K;
+    constexpr int K = kPK, CS = kWave * K;
+    const int N = NT ? NT : p.dstate;
+    const int NG = N / kLG;                                   // staged groups of 4 states per chunk: 4, 2 or 1
+    const int ng_sh = N == 16 ? 2 : N == 8 ? 1 : 0;           // log2(NG)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wg_per_seg = gridDim.x / n_seg;
@@ -411,7 +417,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
     float* const xck = static_cast<float*>(p.x) + ((int64_t)b * p.dim + dc) * p.n_chunks * xpitch;
     const float Dd = p.D ? static_cast<const float*>(p.D)[dc] : 0.f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[dc] : 0.f;
-    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)(lane & 15) * p.A_dstate_stride] * kLog2e;
+    const float A_mine = static_cast<const float*>(p.A)[(int64_t)dc * p.A_d_stride + (int64_t)(lane & (N - 1)) * p.A_dstate_stride] * kLog2e;
     float hreg = 0.f;
 
     const int n_kchunks = (L + CS - 1) / CS;
@@ -428,8 +434,8 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
     // t + 512: tensor pid >> 9, state (pid >> 7) & 3, positions 8 (pid & 127) .. + 7 of the chunk
     Raw8<T, REV> stg[2];
     bool st_ok[2] = {false, false};
-    auto stage_issue = [&](int gi) __attribute__((always_inline)) {   // gi = 4 chunk + state group, global order
-        const int cc = gi >> 2, n0 = (gi & 3) * kLG;
+    auto stage_issue = [&](int gi) __attribute__((always_inline)) {   // gi = NG chunk + state group, global order
+        const int cc = gi >> ng_sh, n0 = (gi & (NG - 1)) * kLG;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int pid = (int)threadIdx.x + kLW * kWave * h;
@@ -492,7 +498,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         // stores (a scheduling barrier here instead spilled 40 registers into the state loop)
         asm volatile("s_nop 1" ::"v"(va), "v"(vb));
     };
-    int gi = c_lo * 4;
+    int gi = c_lo * NG;
     stage_issue(gi);
     stage_commit(0);
     __syncthreads();
@@ -635,10 +641,10 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
             }
         };
 #pragma unroll 1
-        for (int sg = 0; sg < N / kLG; ++sg, ++gi) {
+        for (int sg = 0; sg < NG; ++sg, ++gi) {
             const int buf = gi & 1;
             if (!VMS_ABL_FWD_NOSTAGE) stage_issue(gi + 1);     // the next group (of the next chunk after the last one) travels while this one computes
-            if constexpr (XC) flush_park(sg > 0 ? c : c - 1, (sg + kLG - 1) & (kLG - 1), sg > 0 || c > c_lo);   // the group before this one
+            if constexpr (XC) flush_park(sg > 0 ? c : c - 1, (sg + NG - 1) & (NG - 1), sg > 0 || c > c_lo);   // the group before this one
             if constexpr (tail) {
                 do_quad(sg, buf);
             } else {
@@ -700,22 +706,22 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
     } else {
         for (int c = c_lo; c < c_hi; ++c) run_chunk(c, std::false_type{});
     }
-    if constexpr (XC) flush_park(c_hi - 1, kLG - 1, c_hi > c_lo);   // the last group of the last chunk
+    if constexpr (XC) flush_park(c_hi - 1, NG - 1, c_hi > c_lo);   // the last group of the last chunk
 }
 
 
 // RM: 0 = left-to-right, 1 = right-to-left, 2 = per batch entry (vms_hip.h reverse_from: entries >= p.reverse_from run
 // right-to-left).  A workgroup serves one batch entry, so the direction is workgroup-uniform: one branch, both bodies.
-template <typename T, bool HZ, int RM, bool XC, bool TQ = false>
+template <typename T, bool HZ, int RM, bool XC, bool TQ = false, int NT = kPN>
 __global__ __launch_bounds__(kLW* kWave, 4) void scan_fwd_lds_kernel(const vms_scan_fwd_params p, const int n_seg,
                                                                         const float2* __restrict__ seg_carry) {
     if constexpr (RM == 2) {
         const int wg_per_seg = gridDim.x / n_seg;
         const int b = (int)(blockIdx.x % wg_per_seg) % p.batch;
-        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true, XC, TQ>(p, n_seg, seg_carry);
-        else scan_fwd_lds_body<T, HZ, false, XC, TQ>(p, n_seg, seg_carry);
+        if (b >= p.reverse_from) scan_fwd_lds_body<T, HZ, true, XC, TQ, NT>(p, n_seg, seg_carry);
+        else scan_fwd_lds_body<T, HZ, false, XC, TQ, NT>(p, n_seg, seg_carry);
     } else {
-        scan_fwd_lds_body<T, HZ, RM == 1, XC, TQ>(p, n_seg, seg_carry);
+        scan_fwd_lds_body<T, HZ, RM == 1, XC, TQ, NT>(p, n_seg, seg_carry);
     }
 }
 
@@ -992,6 +998,7 @@ __global__ __launch_bounds__(kSW* kWave, 3) void scan_fwd_sg_kernel(const vms_sc
 // chunks (short rows -- the DBM block's 2,304 -- lose: 52 -> 72 us); whole-vector rows; one buffer resource per row
 bool scan_fwd_sg_wanted(const vms_scan_fwd_params& p) {
     if (p.seqlen % kPK != 0 || p.x_has_sub == 2 || p.segments >= 1 || p.dtype == VMS_F32) return false;   // (fp32 rows: 64 more VGPRs of B / C)
+    if (p.dstate != kPN) return false;                                                                      // one wave per 4 states of 16
     const int64_t rows = (int64_t)p.batch * p.dim, simds = 4 * (int64_t)device_cu_count();
     if (2 * rows > VMS_SG_MAX_HALVES * simds || rows * VMS_SG_MIN_ROWS < simds) return false;
 #ifndef VMS_SG_ANY_LEN
@@ -1092,7 +1099,7 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_car
 // same whatever the count, the main pass needs the occupancy the kernel was built for), at least 4 chunks (4096 elements)
 // per range; p.segments >= 1 forces a count (vms_hip.h)
 int scan_fwd_pair_segments(const vms_scan_fwd_params& p) {
-    if (p.seqlen % kPK != 0) return 1;
+    if (p.seqlen % kPK != 0 || p.dstate != kPN) return 1;   // (dstate 4 / 8: the LDS kernel unsplit; the carry kernel is built for 16)
     if (scan_fwd_sg_wanted(p)) return 1;   // served in one pass by scan_fwd_sg_kernel: no ranges, no workspace
     const int n_k = (p.seqlen + kWave * kPK - 1) / (kWave * kPK);
     const int64_t waves = (int64_t)p.batch * p.dim;
@@ -1119,7 +1126,9 @@ int64_t scan_fwd_pair_ws_bytes(const vms_scan_fwd_params& p) {
 // addresses), so `vec` (16-byte aligned bases and strides) is not required; ragged lengths need readable B / C padding
 bool scan_fwd_pair_eligible(const vms_scan_fwd_params& p, bool vec) {
     (void)vec;
-    if (!p.is_variable_B || !p.is_variable_C || p.dstate != kPN) return false;
+    if (!p.is_variable_B || !p.is_variable_C || (p.dstate != kPN && p.dstate != 8 && p.dstate != 4)) return false;
+    // dstate 4 / 8 (round 6): the LDS kernel only -- whole-vector rows whose 8-row workgroups share one B / C group
+    if (p.dstate != kPN && (p.seqlen % kPK != 0 || p.n_groups < 1 || p.dim % p.n_groups != 0 || (p.dim / p.n_groups) % kLW != 0)) return false;
     if (p.seqlen % kPK != 0 && p.bc_pad < kPK - p.seqlen % kPK) return false;
     const int64_t lim = (int64_t)1 << 31;
     auto span = [&](int64_t bs, int64_t ds) { return (p.batch - 1) * bs + (p.dim - 1) * ds + p.seqlen; };
@@ -1186,15 +1195,17 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
         static PerDeviceOnce attr_once;
         const hipError_t arc = attr_once.run([&]() -> hipError_t {
             hipError_t e = hipSuccess;
-#define VMS_AL(Z_, R_)                                                                                              \
-            if (e == hipSuccess)                                                                                    \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, false>), \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 + VMS_FWD_LDS_PAD);   \
-            if (e == hipSuccess)                                                                                    \
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, true>),  \
+#define VMS_ALN(Z_, R_, N_)                                                                                             \
+            if (e == hipSuccess)                                                                                        \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, false, N_>), \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 + VMS_FWD_LDS_PAD);       \
+            if (e == hipSuccess)                                                                                        \
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_fwd_lds_kernel<T, Z_, R_, true, true, N_>),  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024 + VMS_FWD_LDS_PAD)
+#define VMS_AL(Z_, R_) VMS_ALN(Z_, R_, kPN); VMS_ALN(Z_, R_, 0)
             VMS_AL(true, 0); VMS_AL(true, 1); VMS_AL(true, 2); VMS_AL(false, 0); VMS_AL(false, 1); VMS_AL(false, 2);
 #undef VMS_AL
+#undef VMS_ALN
             return e;
         });
         if (arc != hipSuccess) {
@@ -1209,15 +1220,20 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
 #endif
     const int tail_len = p.seqlen % (kWave * kPK);
     const bool tq = VMS_FWD_TAIL_QUAD && tail_len > 0 && tail_len <= 16 * kPK;
-#define VMS_LL(Z_, R_, S_)                                                                                         \
+#define VMS_LLN(Z_, R_, S_, N_)                                                                                    \
     do {                                                                                                           \
         if (p.x_has_sub == 3) {                                                                                    \
-            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, true>), grid_l, block_l, smem_l, stream, p, S_, carry);   \
-            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, false>), grid_l, block_l, smem_l, stream, p, S_, carry);      \
+            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, true, N_>), grid_l, block_l, smem_l, stream, p, S_, carry);   \
+            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, true, false, N_>), grid_l, block_l, smem_l, stream, p, S_, carry);      \
         } else {                                                                                                   \
-            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, true>), grid_l, block_l, smem_l, stream, p, S_, carry);  \
-            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, false>), grid_l, block_l, smem_l, stream, p, S_, carry);     \
+            if (tq) hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, true, N_>), grid_l, block_l, smem_l, stream, p, S_, carry);  \
+            else hipLaunchKernelGGL((scan_fwd_lds_kernel<T, Z_, R_, false, false, N_>), grid_l, block_l, smem_l, stream, p, S_, carry);     \
         }                                                                                                          \
+    } while (0)
+#define VMS_LL(Z_, R_, S_)                                                                                         \
+    do {                                                                                                           \
+        if (p.dstate == kPN) VMS_LLN(Z_, R_, S_, kPN);                                                             \
+        else VMS_LLN(Z_, R_, S_, 0);                                                                               \
     } while (0)
 #define VMS_L(Z_, R_)                                                                                              \
     do {                                                                                                           \
@@ -1232,10 +1248,11 @@ static int launch_pair(const vms_scan_fwd_params& p, hipStream_t stream) {
     else { if (p.z) VMS_L(true, false); else VMS_L(false, false); }
 #undef VMS_L
 #undef VMS_LL
+#undef VMS_LLN
     VMS_LAUNCH_CHECK();
     // distinct names per kernel: a shape that silently falls off the LDS kernel must be visible to callers and tests
-    set_last_kernel(mixed ? "scan_fwd_pair_lds+mixed" : rag ? "scan_fwd_pair_ragged"
-                        : lds_ok ? (n_seg > 1 ? "scan_fwd_pair_lds+split" : "scan_fwd_pair_lds")
+    set_last_kernel(mixed ? (p.dstate == kPN ? "scan_fwd_pair_lds+mixed" : "scan_fwd_pair_lds_n+mixed") : rag ? "scan_fwd_pair_ragged"
+                        : lds_ok ? (n_seg > 1 ? "scan_fwd_pair_lds+split" : p.dstate == kPN ? "scan_fwd_pair_lds" : "scan_fwd_pair_lds_n")
                                  : (n_seg > 1 ? "scan_fwd_pair+split" : "scan_fwd_pair"));
     return VMS_OK;
 }

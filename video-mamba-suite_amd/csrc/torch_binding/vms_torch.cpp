@@ -45,7 +45,7 @@ void* mptr(const OptT& t) { return t.has_value() ? t->data_ptr() : nullptr; }
 // ---- optional per-launch device timing (bench.py): two events per C-ABI call on the launch stream ---------------
 // Calls arrive from the Python thread AND from autograd's backward threads: the flag is atomic, the record list and the
 // pool of pre-created events are guarded by one mutex (held only around list / pool operations, never around a launch).
-struct Timed { const char* name; hipEvent_t e0, e1; };
+struct Timed { const char* name; hipEvent_t e0, e1; const char* kernel; };   // kernel: vms_last_kernel() behind the launch
 std::atomic<bool> g_timing{false};
 std::mutex g_timing_mu;
 std::string g_timing_only;   // non-empty: only this entry point is timed (written under g_timing_mu before g_timing is raised)
@@ -70,7 +70,7 @@ void call(const char* name, int (*fn)(const P*, void*), const P& p, const Tensor
     hipStream_t s = c10::hip::getCurrentHIPStream(ref.device().index()).stream();
     int rc;
     if (g_timing.load(std::memory_order_acquire) && (g_timing_only.empty() || g_timing_only == name)) {
-        Timed t{name, nullptr, nullptr};
+        Timed t{name, nullptr, nullptr, ""};
         {
             std::lock_guard<std::mutex> lk(g_timing_mu);
             t.e0 = take_event_locked();
@@ -79,6 +79,7 @@ void call(const char* name, int (*fn)(const P*, void*), const P& p, const Tensor
         (void)hipEventRecord(t.e0, s);
         rc = fn(&p, s);
         (void)hipEventRecord(t.e1, s);
+        t.kernel = vms_last_kernel();   // thread-local in the library, a string literal: what this very launch chose
         std::lock_guard<std::mutex> lk(g_timing_mu);
         g_timed.push_back(t);
     } else {
@@ -667,7 +668,7 @@ bool proj_conv_bwd_eligible(const Tensor& x, const Tensor& du_like, const Tensor
     return ok(x) && ok(du_like) && ok(dx_dbl_like) && ok(dx) && fits(x) && fits(du_like) && fits(dx_dbl_like) && fits(dx) &&
            w_x.scalar_type() == x.scalar_type() &&
            du_like.scalar_type() == x.scalar_type() && dx_dbl_like.scalar_type() == x.scalar_type() && dx.scalar_type() == x.scalar_type() &&
-           k >= 33 && k <= 96 && conv_w.dim() == 2 && conv_w.size(1) >= 2 && conv_w.size(1) <= 4 && is_itype(conv_w) &&
+           k >= 1 && k <= 96 && conv_w.dim() == 2 && conv_w.size(1) >= 2 && conv_w.size(1) <= 4 && is_itype(conv_w) &&
            (!conv_b.has_value() || conv_b->scalar_type() == conv_w.scalar_type());
 }
 // vms_hip.h vms_proj_conv_bwd: dw_x += dx_dbl conv1d_out^T; dx, dconv_w, dconv_b = conv1d backward of (du + w_x^T dx_dbl)
@@ -933,19 +934,24 @@ void timing_start(int64_t reserve, const std::string& only) {
     g_timing.store(true, std::memory_order_release);
 }
 // -> [(entry point, milliseconds)] in launch order; synchronises the device.  The events go back to the pool.
-std::vector<std::tuple<std::string, double>> timing_stop() {
+std::vector<std::tuple<std::string, double, std::string>> timing_stop_detail() {
     g_timing.store(false, std::memory_order_release);
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_timing_mu);
-    std::vector<std::tuple<std::string, double>> out;
+    std::vector<std::tuple<std::string, double, std::string>> out;
     for (auto& t : g_timed) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, t.e0, t.e1);
-        out.emplace_back(std::string(t.name), (double)ms);
+        out.emplace_back(std::string(t.name), (double)ms, std::string(t.kernel ? t.kernel : ""));
         g_event_pool.push_back(t.e0);
         g_event_pool.push_back(t.e1);
     }
     g_timed.clear();
+    return out;
+}
+std::vector<std::tuple<std::string, double>> timing_stop() {
+    std::vector<std::tuple<std::string, double>> out;
+    for (auto& t : timing_stop_detail()) out.emplace_back(std::get<0>(t), std::get<1>(t));
     return out;
 }
 
@@ -978,6 +984,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("scan_bwd_dual", &scan_bwd_dual);
     m.def("timing_start", &timing_start, pybind11::arg("reserve") = 0, pybind11::arg("only") = "");
     m.def("timing_stop", &timing_stop);
+    m.def("timing_stop_detail", &timing_stop_detail);   // + the kernel each launch chose (tools/suite_shapes.py)
     m.def("abi_version", []() { return vms_abi_version(); });
     m.def("last_kernel", []() { return std::string(vms_last_kernel()); });
 }
