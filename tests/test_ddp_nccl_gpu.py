@@ -21,15 +21,13 @@ def test_ddp_and_graphed_ddp_on_rccl_world1(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, os.path.join(HERE, "ddp_nccl_worker.py"), out, port]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    if r.returncode < 0:
-        # killed by a signal: round 5 saw the worker die with SIGABRT on about one cold box in eight (the NCCL watchdog thread's event
-        # queries against a graph capture in "global" mode, fixed in mamba_ssm/utils/hip_graph.py).  A signal is not an assertion of
-        # this test: keep the log where the GPU box's outputs are collected and run the worker once more; a wrong result still fails.
-        if os.environ.get("GRAFT_REPO_ROOT"):
-            d = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out")
-            os.makedirs(d, exist_ok=True)
-            open(os.path.join(d, "ddp_nccl_worker_signal.log"), "w").write(f"rc {r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}")
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode < 0 and os.environ.get("GRAFT_REPO_ROOT"):
+        # killed by a signal (round 5 saw SIGABRT on a cold box: the NCCL watchdog's event queries against a graph capture in "global"
+        # mode, fixed in mamba_ssm/utils/hip_graph.py with capture_error_mode="thread_local").  No second chance since round 6
+        # (VERDICT r5 6b): the log is kept where the GPU box's outputs are collected and the test FAILS, so the next one is seen.
+        d = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "ddp_nccl_worker_signal.log"), "w").write(f"rc {r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}")
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     res = json.load(open(out))
     assert res["backend"] == "nccl" and res["world"] == 1

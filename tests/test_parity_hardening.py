@@ -192,6 +192,10 @@ def test_parameter_gradients_full_size(oracle):
     check(per[e][2], ob["dA"], 5 * bf, "dA of one entry vs oracle")
     check(per[e][5], ob["dD"], 5 * bf, "dD of one entry vs oracle")
     check(per[e][6], ob["ddelta_bias"], 5 * bf, "ddelta_bias of one entry vs oracle")
+    # ... and element by element under the reference's own rtol / atol (test_selective_scan.py:45-51, 137-149)
+    rt = ref_tolerances(torch.bfloat16, True)
+    for k, name in ((2, "dA"), (3, "dB"), (4, "dC"), (5, "dD"), (6, "ddelta_bias")):
+        allclose_ref(per[e][k], ob[name], *rt[name], f"{name} of a whole entry at full size, the reference's rtol / atol")
     # per ROW and per state, not only relative to the tensor's largest entry: dA rows against their own scale
     dA, want = per[e][2].double().cpu().numpy(), ob["dA"]
     row_scale = np.abs(want).max(axis=1, keepdims=True)

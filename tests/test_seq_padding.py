@@ -22,6 +22,10 @@ def _rel(a, b):
 
 
 def _make(variant, d_model, **kw):
+    if variant == "dbm":   # round 6: the DBM mixer pads too (its second half is scanned right-to-left by the kernels: padding at the physical end)
+        from mamba_ssm.modules.mamba_new import Mamba
+        torch.manual_seed(0)
+        return Mamba(d_model, d_state=16, d_conv=4, expand=1, **kw).cuda()
     if variant == "vim_norm":
         from mamba_ssm.modules.mamba_simple_scan_norm import Mamba
     else:
@@ -31,8 +35,8 @@ def _make(variant, d_model, **kw):
 
 
 @pytest.mark.parametrize("checkpoint_lvl", [0, 1])
-@pytest.mark.parametrize("variant,kw", [("vim", {}), ("vim", {"if_devide_out": True}), ("vim_norm", {"if_devide_out": True})])
-@pytest.mark.parametrize("batch,seqlen,d_model", [(2, 197, 64), (1, 1569, 32), (3, 35, 48), (2, 1, 32)])
+@pytest.mark.parametrize("variant,kw", [("vim", {}), ("vim", {"if_devide_out": True}), ("vim_norm", {"if_devide_out": True}), ("dbm", {})])
+@pytest.mark.parametrize("batch,seqlen,d_model", [(2, 197, 64), (1, 1569, 32), (3, 35, 48), (2, 1, 32), (1, 188, 64), (4, 107, 32)])
 def test_padding_fp32_equals_ragged(monkeypatch, batch, seqlen, d_model, variant, kw, checkpoint_lvl):
     """fp32 end to end: the two runs differ by kernel generation only (summation order), so they agree to 1e-4 -- any value leaking
     out of the padding (a state picked up by the right-to-left scan, a gradient through the padding's delta) would show whole"""

@@ -414,7 +414,14 @@ class MambaCore(nn.Module):
         if _USE_REVERSE_KERNELS and _DBM_STACKED:
             # both halves as one node: the projection emits them stacked on the batch axis, entries >= B run right-to-left
             # (the reference stacks a flipped copy of the second half, mamba_new.py:192-213, and flips its output back)
-            batch = hidden_states.shape[0]
+            batch, seqlen = hidden_states.shape[:2]
+            # a ragged sequence runs zero-padded to whole vectors, as in the ViM mixer above (round 6: the suite's PDVC / UniVTG
+            # lengths -- 188, 107 -- ran on the ragged kernel generation and the unfused head): the padding sits at the physical end of
+            # BOTH halves (the second one is scanned right-to-left by the kernels, not flipped), xz = 0 there and delta = -inf
+            pad = self._seq_padding(hidden_states)
+            if pad:
+                hidden_states = F.pad(hidden_states, (0, 0, 0, pad))
+            valid = seqlen if pad else 0
             prep = self._prepare_params_dbm(hidden_states)
             if prep is None:
                 xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True)    # (2 B, 2 d, L)
@@ -422,15 +429,17 @@ class MambaCore(nn.Module):
                 out = mamba_inner_fn_no_out_proj(
                     xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
                     self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,
-                    checkpoint_lvl=_CHECKPOINT_LVL)                                                            # (2 B, d, L)
-                return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True)
+                    checkpoint_lvl=_CHECKPOINT_LVL, seq_valid=valid)                                           # (2 B, d, L)
+                out = out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True)
+                return out[:, :seqlen].contiguous() if pad else out
             xz2 = in_proj_fn(hidden_states, self.in_proj.weight, self.in_proj.bias, stack_halves=True, wt_prepared=prep["wt_in"])
             A = NegExpFn.apply(self.A_log, prep["A"])
             out = mamba_inner_fn_no_out_proj(
                 xz2, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, A, None, None,
                 self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True, reverse_from=batch,
-                checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"])
-            return out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True, w_prepared=prep["w_out"])
+                checkpoint_lvl=_CHECKPOINT_LVL, prepared=prep["small"], seq_valid=valid)
+            out = out_proj_fn(out, self.out_proj.weight, self.out_proj.bias, stacked_halves=True, w_prepared=prep["w_out"])
+            return out[:, :seqlen].contiguous() if pad else out
         xz = self._in_projection(hidden_states)
         xz_f, xz_b = torch.chunk(xz, 2, dim=1)
         if _USE_REVERSE_KERNELS:

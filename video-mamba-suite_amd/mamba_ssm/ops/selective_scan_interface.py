@@ -544,16 +544,17 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
     def forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                 A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
                 C_proj_bias=None, delta_softplus=True, checkpoint_lvl=1, reverse=False, reverse_from=0,
-                x_proj_prepared=None, delta_proj_prepared=None):
+                x_proj_prepared=None, delta_proj_prepared=None, seq_valid=0):
         """xz: (batch, 2*dim, seqlen) -> out_z: (batch, dim, seqlen)
         x_proj_prepared / delta_proj_prepared (extension): the two projection weights already in the autocast dtype (the block's
-        one-launch parameter preparation); used instead of casting here, no gradient (it goes to the parameters)."""
+        one-launch parameter preparation); used instead of casting here, no gradient (it goes to the parameters).
+        seq_valid (extension): 0, or the number of real positions of a zero-padded xz (_inner_forward)."""
         if x_proj_prepared is not None:
             ctx.w_dtype_override = x_proj_weight.dtype      # the PARAMETERS' dtype, not that of the prepared copies
             x_proj_weight, delta_proj_weight = x_proj_prepared, delta_proj_prepared
         return _inner_forward(ctx, xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                               None, A, None, B, C, D, delta_bias, B_proj_bias, C_proj_bias,
-                              delta_softplus, checkpoint_lvl, reverse, reverse_from=reverse_from)
+                              delta_softplus, checkpoint_lvl, reverse, reverse_from=reverse_from, seq_valid=int(seq_valid))
 
     @staticmethod
     @custom_bwd
@@ -561,7 +562,7 @@ class MambaInnerFnNoOutProj(torch.autograd.Function):
         g = _inner_backward(ctx, dout)
         return (g["dxz"], g["dconv_w"], g["dconv_b"], g["dx_proj_weight"], g["ddelta_proj_weight"],
                 g["dA"], g["dB"], g["dC"], g["dD"], g["ddelta_bias"], g["dB_proj_bias"], g["dC_proj_bias"],
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 class NegExpPairFn(torch.autograd.Function):
@@ -829,9 +830,10 @@ def bimamba_inner_fn(
 def mamba_inner_fn_no_out_proj(
     xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
     A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
-    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1, reverse_from=0, prepared=None
+    C_proj_bias=None, delta_softplus=True, reverse=False, checkpoint_lvl=1, reverse_from=0, prepared=None, seq_valid=0
 ):
     """prepared (extension): None or (x_proj_weight, delta_proj_weight) already in the autocast dtype.
+    seq_valid (extension): 0, or the number of real positions when xz[..., seq_valid:] is the caller's zero padding (_inner_forward).
     reverse (extension, default off): the node runs right-to-left over xz -- the value of
     flip(node(flip(xz))) without the flipped copies the bidirectional blocks otherwise pay for.
     reverse_from (extension): batch entries >= reverse_from run right-to-left, the others left-to-right -- the DBM block's
@@ -846,7 +848,7 @@ def mamba_inner_fn_no_out_proj(
         return selective_scan_fn(x, delta, A, B, C, D, z=z, delta_bias=delta_bias, delta_softplus=delta_softplus)
     return MambaInnerFnNoOutProj.apply(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight,
                                        A, B, C, D, delta_bias, B_proj_bias, C_proj_bias, delta_softplus,
-                                       checkpoint_lvl, reverse, reverse_from, *(prepared or ()))
+                                       checkpoint_lvl, reverse, reverse_from, *(prepared or (None, None)), int(seq_valid))
 
 
 # ---- unfused references built from the public ops (dispatch to the HIP ops on GPU tensors) --------
