@@ -18,7 +18,18 @@
 
 namespace vms {
 
+// timing-only ablations (wrong results): tools/variant.sh <tag> -DVMS_ABL_SHORT_NOATOM=1 / -DVMS_ABL_SHORT_NORS=1
+#ifndef VMS_ABL_SHORT_NOATOM
+#define VMS_ABL_SHORT_NOATOM 0
+#endif
+#ifndef VMS_ABL_SHORT_NORS
+#define VMS_ABL_SHORT_NORS 0
+#endif
+#ifndef VMS_SHORT_BC_LDS
+#define VMS_SHORT_BC_LDS 1   /* 0 (A/B builds): every state loads and widens its own B / C rows from global memory, as until round 5 */
+#endif
 constexpr int kSN = 16;        // dstate
+constexpr int kSN_ = kSN;
 constexpr int kSMaxL = 16;     // longest row served
 
 bool scan_short_eligible(const vms_scan_fwd_params& p) {
@@ -68,6 +79,57 @@ __device__ __forceinline__ void load_row(const T* __restrict__ row, int L, bool 
         for (int i = 0; i < LP; ++i) v[i] = ok && i < L ? static_cast<float>(row[REV ? L - 1 - i : i]) : 0.f;
     }
 }
+// A batch entry's B and C (this wave's: they are wave-uniform) as fp32 in LOGICAL order in a wave-private LDS block,
+// [tensor][state][LP], staged ONCE per wave (round 6).  Until then every state of the loop loaded and widened its two rows from
+// global memory right where it needed them: 16 exposed L2 round trips per wave and 2 LP conversions per state -- the backward's
+// VALU pipe was 42 % busy at 4 waves per SIMD ((1568, 768, 8): 243 us per direction against ~100 of issue time).  Now one
+// load instruction per wave (lane -> one 16-byte vector of one (tensor, state) row) fills the block and a state reads its rows
+// with broadcast ds_read_b128 (all lanes one address: no bank conflicts, ~100 cycles instead of an L2 round trip).
+template <typename T, int LP, bool REV, bool VEC>
+__device__ __forceinline__ void stage_bc_short(float* __restrict__ blk, const T* __restrict__ Bp, const T* __restrict__ Cp,
+                                               const int64_t bs, const int64_t cs, const int L, const int lane) {
+    if constexpr (VEC) {
+        constexpr int EPV = 16 / sizeof(T), VPR = LP / EPV, NV = 2 * kSN_ * VPR;
+#pragma unroll
+        for (int v0 = 0; v0 < NV; v0 += 64) {
+            const int v = v0 + lane;
+            if (NV % 64 == 0 || v < NV) {
+                const int ten = v / (kSN_ * VPR), n = (v / VPR) % kSN_, k = v % VPR;
+                const T* row = ten ? Cp + (int64_t)n * cs : Bp + (int64_t)n * bs;
+                float o[EPV];
+                if (k * EPV < L) {
+                    const vec_t<T, EPV> t = *reinterpret_cast<const vec_t<T, EPV>*>(row + (REV ? L - (k + 1) * EPV : k * EPV));
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) o[e] = static_cast<float>(t[REV ? EPV - 1 - e : e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) o[e] = 0.f;
+                }
+                float4* dst = reinterpret_cast<float4*>(blk + (ten * kSN_ + n) * LP + k * EPV);
+#pragma unroll
+                for (int q = 0; q < EPV / 4; ++q) dst[q] = float4{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+            }
+        }
+    } else {
+        for (int idx = lane; idx < 2 * kSN_ * LP; idx += 64) {
+            const int ten = idx / (kSN_ * LP), n = (idx / LP) % kSN_, i = idx % LP;
+            const T* row = ten ? Cp + (int64_t)n * cs : Bp + (int64_t)n * bs;
+            blk[idx] = i < L ? static_cast<float>(row[REV ? L - 1 - i : i]) : 0.f;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private: the wave's LDS instructions complete in order
+    __builtin_amdgcn_wave_barrier();
+}
+template <int LP>
+__device__ __forceinline__ void read_bc_short(const float* __restrict__ blk, const int ten, const int n, float (&v)[LP]) {
+    const float4* src = reinterpret_cast<const float4*>(blk + (ten * kSN_ + n) * LP);
+#pragma unroll
+    for (int q = 0; q < LP / 4; ++q) {
+        const float4 t = src[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
 template <typename T, int LP, bool REV, bool VEC>
 __device__ __forceinline__ void store_row(T* __restrict__ row, int L, const float (&v)[LP]) {
     if constexpr (VEC) {
@@ -158,6 +220,8 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
     // lane, 128 bytes apart -- the forward moved 383 MB for 192 MB of results at (1568, 768, 8) and spent most of its 190 us on
     // it; the final states go through LDS ([row][state], 17-float pitch) and leave as eight 1 KB-contiguous stores per wave.
     __shared__ float hs[4][64 * 17];
+    __shared__ __attribute__((aligned(16))) float bcs[4][2 * kSN * LP];   // this wave's B / C as fp32 (stage_bc_short)
+    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane);
     const bool x16 = (xpitch & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
     const bool xdense = x16 && xpitch == 2 * N;
 #pragma unroll 1
@@ -168,8 +232,13 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
             const int n = n0 + k;
             const float An = Af[(int64_t)n * p.A_dstate_stride] * kLog2e;
             float Bv[LP], Cv[LP];
-            load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
-            load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+            if (VMS_SHORT_BC_LDS) {
+                read_bc_short<LP>(bcs[wave], 0, n, Bv);
+                read_bc_short<LP>(bcs[wave], 1, n, Cv);
+            } else {
+                load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
+                load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+            }
             float h = 0.f;
 #pragma unroll
             for (int i = 0; i < LP; ++i) {
@@ -243,6 +312,8 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
     const float Dd = p.D ? static_cast<const float*>(p.D)[d] : 0.f;
     const float bias = p.delta_bias ? static_cast<const float*>(p.delta_bias)[d] : 0.f;
     float* wsr = ws ? ws + (int64_t)b * 18 * p.dim + d : nullptr;
+    __shared__ __attribute__((aligned(16))) float bcs[4][2 * kSN * LP];   // this wave's B / C as fp32 (stage_bc_short)
+    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane);
     float dl[LP], uv[LP], dy[LP], sg[LP], dua[LP], dda[LP];
     float dD = 0.f;
     load_row<T, LP, REV, VEC>(dt, L, true, dl);
@@ -286,8 +357,13 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
     for (int n = 0; n < N; ++n) {
         const float Araw = Af[(int64_t)n * p.A_dstate_stride], An = Araw * kLog2e;
         float a[LP], x[LP], Bv[LP], Cv[LP];
-        load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
-        load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+        if (VMS_SHORT_BC_LDS) {
+            read_bc_short<LP>(bcs[wave], 0, n, Bv);
+            read_bc_short<LP>(bcs[wave], 1, n, Cv);
+        } else {
+            load_row<T, LP, REV, VEC>(Bp + (int64_t)n * p.B_dstate_stride, L, true, Bv);
+            load_row<T, LP, REV, VEC>(Cp + (int64_t)n * p.C_dstate_stride, L, true, Cv);
+        }
         float h = 0.f;
 #pragma unroll
         for (int i = 0; i < LP; ++i) {
@@ -310,8 +386,13 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
         if (wsr) wsr[(int64_t)n * p.dim] = dA;
         else atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)n * q.dA_dstate_stride, dA);
         float z[LP / 2];
+#if VMS_ABL_SHORT_NORS   /* timing only: no wave reduction */
+#pragma unroll
+        for (int m = 0; m < LP / 2; ++m) z[m] = vals[4 * m] + vals[4 * m + 1] + vals[4 * m + 2] + vals[4 * m + 3];
+#else
         wave_reduce_scatter<2 * LP>(vals, z);
-        if ((lane & 15) == 15) {       // lane 16 r + 15 of z[m]: the wave's sum of value 4 m + {0, 2, 1, 3}[r]
+#endif
+        if (!VMS_ABL_SHORT_NOATOM && (lane & 15) == 15) {       // lane 16 r + 15 of z[m]: the wave's sum of value 4 m + {0, 2, 1, 3}[r]
             const int r = lane >> 4, sub = r == 1 ? 2 : r == 2 ? 1 : r;
 #pragma unroll
             for (int m = 0; m < LP / 2; ++m) {
@@ -320,6 +401,10 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
                 if (i < L) atomicAdd(dst + (REV ? L - 1 - i : i), z[m]);
             }
         }
+#if VMS_ABL_SHORT_NOATOM
+#pragma unroll
+        for (int m = 0; m < LP / 2; ++m) asm volatile("" ::"v"(z[m]));
+#endif
     }
     float dbias = 0.f;
 #pragma unroll
