@@ -324,6 +324,17 @@ class MambaCore(nn.Module):
         if got is None:
             mode = _vms.x_mode_for_shape(hidden_states.shape[0], self.d_inner, hidden_states.shape[1], self.d_state, hidden_states.device)
             got = cache[key] = "coarse" if mode == 1 else "fine"
+            cache[key, "age"] = 0
+        elif got == "fine" and not torch.cuda.is_current_stream_capturing():
+            # The first decision is taken at step 1 -- before optimizer state, later layers' activations and the backward's buffers
+            # exist.  A ONE-WAY downgrade keeps it honest without the per-forward allocator query: every 64th forward
+            # of this shape the condition is checked again, and once it fails the shape stays on the small layout ("fine" is never
+            # re-entered: the kernel choice does not flip back and forth).  Per rank, from the local allocator: ranks of a
+            # data-parallel job may differ in the low-order bits of their gradients, which the averaging absorbs.
+            age = cache[key, "age"] = cache.get((key, "age"), 0) + 1
+            if age % 64 == 0 and _vms.x_mode_for_shape(hidden_states.shape[0], self.d_inner, hidden_states.shape[1], self.d_state,
+                                                       hidden_states.device) == 1:
+                got = cache[key] = "coarse"
         return got
 
     def reset_checkpoint_policy(self):

@@ -28,26 +28,29 @@ def _autocast_dtype():
 
 
 _SUM_SLICES = True   # False (tests / A/B: monkeypatch.setattr): torch's reduction instead of vms_sum_slices
-_mm_out_dtype_ok = [None]   # does torch.mm(a, b, out_dtype=torch.float32) work for 16-bit operands on this build / device?
+_mm_out_dtype_ok = {}   # (device index, dtype) -> does torch.mm(a, b, out_dtype=torch.float32) work for these operands on this build / device?
 
 
 def _mm_out_dtype(like):
     """Probed ONCE, explicitly, on tiny operands of the caller's dtype and device (outside any stream capture): an unrelated first
     failure of a real call -- an out-of-memory error is a RuntimeError too -- must not flip the kernel path of every later weight
     gradient, and the batched branch of _in_proj_param_grads must not depend on which node ran first."""
-    if _mm_out_dtype_ok[0] is None:
+    key = (like.device.index, like.dtype)   # per device and operand dtype (ADVICE r5: one global answer served fp16 after a bf16 probe)
+    if key not in _mm_out_dtype_ok:
         if torch.cuda.is_current_stream_capturing():
-            return False   # decided at the first call outside a capture; inside one the cast form is always valid
+            # decided at the first call outside a capture; inside one the cast form is always valid.  GraphedStep's warm-up steps run
+            # the same nodes eagerly first, so a captured step and the eager steps around it take the same path.
+            return False
         try:
             t = torch.ones(16, 16, device=like.device, dtype=like.dtype)
             torch.mm(t, t, out_dtype=torch.float32)
             torch.bmm(t[None], t[None], out_dtype=torch.float32)
-            _mm_out_dtype_ok[0] = True
+            _mm_out_dtype_ok[key] = True
         except torch.cuda.OutOfMemoryError:
             raise
         except (RuntimeError, TypeError):
-            _mm_out_dtype_ok[0] = False
-    return _mm_out_dtype_ok[0]
+            _mm_out_dtype_ok[key] = False
+    return _mm_out_dtype_ok[key]
 
 
 def _mm_wgrad(a, b, w_dtype):

@@ -213,7 +213,16 @@ class _Debug:
     no_param_prep    every node prepares its own parameters instead of one vms_param_prep launch per block
     no_seq_pad       ragged sequences as they come instead of padded to whole vectors inside the mixer
     no_seq_pad_tiles pad to the next multiple of 16 only (not up to whole 256-token GEMM tiles)
+
+    WHEN a switch is read: scan_impl, force_generic, *_segments, mfma_proj, no_fused_tail, no_inner_ext and no_torch_ext are
+    read at every call -- setting the attribute takes effect at once.  The others are IMPORT-TIME switches: the layers copy them into
+    module constants when they are first imported (selective_scan_interface._DUAL_BWD / _DUAL_CONV / _CONV_XPROJ / _PROJ_KRED,
+    modules._core._USE_REVERSE_KERNELS / _DBM_STACKED / _PARAM_PREP / _SEQ_PAD / _SEQ_PAD_TILES), so only VMS_DEBUG (parsed before
+    those imports) or a monkeypatch of the module constant itself changes them -- which is what the tests do.
     """
+    _SWITCHES = ("scan_impl", "force_generic", "fwd_segments", "bwd_segments", "no_torch_ext", "no_inner_ext", "mfma_proj", "no_fused_tail",
+                 "no_proj_kred", "no_dual_bwd", "no_dual_conv", "no_conv_xproj", "no_reverse", "dbm_two_nodes", "no_param_prep", "no_seq_pad",
+                 "no_seq_pad_tiles")
     scan_impl = None
     force_generic = False
     fwd_segments = 0
@@ -235,7 +244,7 @@ class _Debug:
     def __init__(self, spec=""):
         for item in filter(None, (t.strip() for t in spec.split(","))):
             k, _, v = item.partition("=")
-            if not hasattr(type(self), k):
+            if k not in self._SWITCHES:   # (an explicit list: hasattr() also accepted __doc__, __init__, ...)
                 raise ValueError(f"VMS_DEBUG: unknown switch {k!r} (see vms_hip.debug.__doc__)")
             cur = getattr(type(self), k)
             if k == "scan_impl":
