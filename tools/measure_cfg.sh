@@ -7,17 +7,22 @@
 tag=$1; shift
 if [ $# -eq 0 ]; then set -- stack long dbm; fi
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$tag; mkdir -p $O
-declare -A DUAL=( [block]=dual [stack]=dual [long]=dual [dbm]= )
-declare -A SHAPE=( [block]=8,1024,8192,16 [stack]=8,768,3136,16 [long]=1,768,65536,16 [dbm]=4,512,2304,16 )
+# block_coarse (round 6): the headline block with the 128-element checkpoint layout (VMS_X_LAYOUT=1: what a memory-filling training job
+# gets from the "auto" policy) -- the traffic profile of bench.py's `block_coarse_checkpoints` extra line
+declare -A DUAL=( [block]=dual [block_coarse]=dual [stack]=dual [long]=dual [dbm]= )
+declare -A SHAPE=( [block]=8,1024,8192,16 [block_coarse]=8,1024,8192,16 [stack]=8,768,3136,16 [long]=1,768,65536,16 [dbm]=4,512,2304,16 )
 A="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY"
 B="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
 D="GRBM_GUI_ACTIVE GRBM_COUNT"
-for cfg in "$@"; do
+for cfg0 in "$@"; do
   cd $R
-  python bench.py --config $cfg --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > $O/${cfg}_bench.json
+  cfg=$cfg0; unset VMS_X_LAYOUT
+  if [ $cfg0 = block_coarse ]; then export VMS_X_LAYOUT=1; fi
+  bcfg=${cfg%_coarse}
+  python bench.py --config $bcfg --no-cpu-baseline --no-extra-configs 2>/dev/null | tail -1 > $O/${cfg}_bench.json
   KB_SHAPE=${SHAPE[$cfg]} python tools/kbench.py fwd bwd ${DUAL[$cfg]} 2>&1 | grep -v amdgpu.ids > $O/${cfg}_kbench.txt
   cd /tmp && export TMPDIR=/tmp
-  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $cfg --steps 10 --warmup 20 --no-projections --no-cpu-baseline --no-extra-configs > $O/${cfg}_prof.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $O/prof -o p --output-format csv -- python $R/bench.py --config $bcfg --steps 10 --warmup 20 --no-projections --no-cpu-baseline --no-extra-configs > $O/${cfg}_prof.log 2>&1
   python $R/tools/prof_summary.py $O/prof/p_kernel_stats.csv 30 > $O/${cfg}_kernel_stats.md
   python $R/tools/step_trace.py $O/prof/p_kernel_trace.csv 10 > $O/${cfg}_step_trace.txt 2>/dev/null
   rm -rf $O/prof
