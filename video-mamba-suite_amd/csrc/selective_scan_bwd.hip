@@ -34,6 +34,8 @@ bool scan_bwd_short_eligible(const vms_scan_bwd_params& q);                     
 bool scan_short_takes(const vms_scan_fwd_params& p);
 int launch_scan_bwd_short(const vms_scan_bwd_params& q, hipStream_t stream);
 int64_t scan_bwd_short_ws_bytes(const vms_scan_bwd_params& q);
+int scan_short_nseg(const vms_scan_fwd_params& p);
+bool scan_bwd_short_has_ws(const vms_scan_bwd_params& q);
 
 constexpr int kBwdRows = 4;
 constexpr int kTilePad = 65;  // tile index = i * 65 + lane : conflict-free ds_add, 2-way flush
@@ -410,7 +412,9 @@ extern "C" int vms_selective_scan_bwd(const vms_scan_bwd_params* qq, void* strea
     if (p.is_complex) return launch_scan_bwd_complex(q, vec, s);
     const int level = scan_impl_level(p);
     // short rows (selective_scan_short.hip): the states are rebuilt from h = 0 in the lane, x is not read
-    if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_bwd_short_eligible(q)) return launch_scan_bwd_short(q, s);
+    // (segmented rows, 17 .. 64 elements, need the workspace for the adjoint carries: without it the generic kernel below takes them)
+    if (level >= VMS_IMPL_PAIR && p.x_has_sub == 0 && scan_bwd_short_eligible(q) && (scan_short_nseg(p) == 1 || scan_bwd_short_has_ws(q)))
+        return launch_scan_bwd_short(q, s);
     if (level >= VMS_IMPL_PAIR && scan_bwd_pair_eligible(q, vec)) return launch_scan_bwd_pair(q, s);
     set_last_kernel("scan_bwd_generic");
     switch (p.dtype) {

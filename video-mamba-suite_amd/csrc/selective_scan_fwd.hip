@@ -200,6 +200,8 @@ int launch_scan_fwd_pair(const vms_scan_fwd_params& p, hipStream_t stream);
 int launch_scan_fwd_complex(const vms_scan_fwd_params& p, bool vec, hipStream_t stream);   // selective_scan_complex.hip
 bool scan_short_eligible(const vms_scan_fwd_params& p);                                      // selective_scan_short.hip
 bool scan_short_takes(const vms_scan_fwd_params& p);
+bool scan_short_takes_shape(const vms_scan_fwd_params& p);
+int64_t scan_short_x_pitch(const vms_scan_fwd_params& p);
 int launch_scan_fwd_short(const vms_scan_fwd_params& p, hipStream_t stream);
 
 bool scan_fwd_vec_ok(const vms_scan_fwd_params& p) {
@@ -316,7 +318,8 @@ extern "C" int64_t vms_scan_x_pitch(const vms_scan_fwd_params* pp, int32_t mode)
     if (mode == 0) return 2 * (int64_t)p.dstate;
     // the lane-per-row kernels of short sequences keep no checkpoints: the reference's x and nothing behind it (the 8-element
     // layout costs 16.5 KB per row whatever its length: 20 GB per scan at (1568, 8, 768))
-    if (vms::scan_short_takes(p)) return 2 * (int64_t)p.dstate;
+    // (rows of 17 .. 64 elements run as segments of 16 chained through x: 2 N + (segments - 1) N, selective_scan_short.hip)
+    if (vms::scan_short_takes_shape(p)) return vms::scan_short_x_pitch(p);
     if ((mode == 3 || mode == -1) && vms::scan_bwd_pair_lane_ckpt_ok(p)) return 258 * (int64_t)p.dstate;
     return 18 * (int64_t)p.dstate;
 }
