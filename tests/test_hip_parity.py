@@ -903,6 +903,42 @@ def test_kernel_choice_per_shape(shape, fwd_name, bwd_name):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("b,L,d,N,fwd_name,bwd_name", [
+    # the (model, shape) pairs of tools/suite_shapes.py (profiles/r06_suite_shapes.md) at the scan level: no suite shape on a generic
+    # scan kernel or on the ragged generation; lengths as the mixers pad them (785 -> 800, 3137 -> 3152, 188 -> 192)
+    (32, 800, 384, 4, "scan_fwd_pair_lds_n", "scan_bwd_pair4_n"),        # CLIP ViViM, d_state = 4 (model_clip.py:945-947), 4 frames
+    (8, 3152, 384, 4, "scan_fwd_pair_lds_n", "scan_bwd_pair4_n"),        # ... 16 frames
+    (8, 1584, 384, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # ViViM tiny, 8 frames + cls
+    (8, 3152, 768, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # ViViM small, 16 frames
+    (1568, 8, 768, 16, "scan_fwd_short", "scan_bwd_short"),              # TimeMamba along time, 8 frames
+    (1568, 16, 768, 16, "scan_fwd_short", "scan_bwd_short"),             # ... 16 frames
+    (8, 1568, 768, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # TimeMamba joint
+    (1, 6000, 128, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # TAS, batch 1
+    (1, 192, 1024, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # PDVC, 188 tokens padded
+    (32, 112, 512, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),           # UniVTG, 107 tokens padded
+    (16, 32, 2048, 16, "scan_fwd_short+segments", "scan_bwd_short+segments"),   # LSTR work memory: 17 .. 64 elements, many rows
+    (16, 512, 2048, 16, "scan_fwd_pair_lds", "scan_bwd_pair4"),          # LSTR long memory
+])
+def test_kernel_choice_suite_shapes(b, L, d, N, fwd_name, bwd_name):
+    import selective_scan_cuda
+    import vms_hip
+    dt = torch.bfloat16
+    torch.manual_seed(0)
+    u = torch.randn(b, d, L, device=DEV, dtype=dt)
+    delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(dt)
+    A = -torch.rand(d, N, device=DEV)
+    Bm = torch.randn(b, 1, N, L, device=DEV, dtype=dt)
+    Cm = torch.randn(b, 1, N, L, device=DEV, dtype=dt)
+    z = torch.randn(b, d, L, device=DEV, dtype=dt)
+    out, x, _ = selective_scan_cuda.fwd(u, delta, A, Bm, Cm, None, z, None, True)
+    got = vms_hip.last_kernel()
+    assert (got if "segments" in fwd_name else got.split("+")[0]) == fwd_name, got
+    selective_scan_cuda.bwd(u, delta, A, Bm, Cm, None, z, None, torch.randn_like(u), x, out, None, True, False)
+    got = vms_hip.last_kernel()
+    assert (got if "segments" in bwd_name else got.split("+")[0]) == bwd_name, got
+    torch.cuda.synchronize()
+
+
 def test_tensors_beyond_31_bit_offsets_take_the_generic_kernels(oracle):
     """The paired kernels address with 32-bit element offsets; a problem whose tensors span >= 2^31 elements must not
     fail or wrap: it runs on the generic kernels (64-bit strides) and vms_last_kernel() says so.  Rows sampled against
