@@ -210,12 +210,13 @@ int64_t vms_scan_x_elems(const vms_scan_fwd_params *p);
 /* the x pitch (floats between x[b,d,c,:] and x[b,d,c+1,:]) to allocate for this problem; only sizes and flags of *p are
  * read.  mode 0: 2*dstate (the reference's tensor, selective_scan.cpp:313: no fast backward); 1: 18*dstate (x_has_sub == 1);
  * 3 or -1 (the library's choice for a forward whose backward will run): 258*dstate (x_has_sub == 3) when the backward
- * kernel that uses it takes the problem (variable B / C, dstate 16, (dim / n_groups) % 32 == 0), seqlen % 16 == 0 (the
+ * kernel that uses it takes the problem (variable B / C, dstate 16 -- or, ABI v11, 8 or 4 --, (dim / n_groups) % 32 == 0), seqlen % 16 == 0 (the
  * forward kernel that writes the checkpoints as whole lines) and x stays under 2 GiB per batch entry and 2^31 elements in all, else 18*dstate.  The caller sets x_chunk_stride to the
  * pitch and x_has_sub to 3 / 1 / 0 for pitch >= 258*dstate / >= 18*dstate / less.
  * Short sequences with many rows (seqlen <= 16, batch*dim >= 4096, variable B / C, dstate 16, (dim / n_groups) % 64 == 0: the suite's
  * TimeMamba scans along time) are served by lane-per-row kernels that keep no checkpoints (csrc/selective_scan_short.hip): every mode
- * answers 2*dstate for them, and with x_has_sub == 0 both vms_selective_scan_fwd and _bwd take that path (the backward rebuilds a row's
+ * answers 2*dstate for them (ABI v11, modes other than 0: 2*dstate + (ceil(seqlen / 16) - 1)*dstate for rows of 17 .. 64 elements, which run as chained 16-element
+ * segments: x[b,d,0, 2*dstate + s*dstate + n] = state n after segment s), and with x_has_sub == 0 both vms_selective_scan_fwd and _bwd take that path (the backward rebuilds a row's
  * states and wants vms_scan_bwd_workspace_bytes() = batch*18*dim floats for its sums over the batch; without them it uses atomics). */
 int64_t vms_scan_x_pitch(const vms_scan_fwd_params *p, int32_t mode);
 
