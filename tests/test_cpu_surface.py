@@ -589,7 +589,10 @@ def test_x_pitch_short_rows_keep_the_reference_shape():
     assert pitch(1568, 768, 8) == 32 and pitch(1568, 768, 16) == 32 and pitch(1568, 768, 8, mode=1) == 32
     assert pitch(1568, 768, 8, reverse_from=784) == 32                 # both halves of a mixed-direction batch
     big = (18 * 16, 258 * 16)                                          # room for the long-row kernels' checkpoints
-    assert pitch(1568, 768, 32) in big                                 # longer than the short kernels serve
+    # rows of 17 .. 64 elements (round 6): chained 16-element segments, the states between them behind the reference-shaped slots
+    assert pitch(1568, 768, 32) == 32 + 16 and pitch(1568, 768, 64) == 32 + 3 * 16 and pitch(1568, 768, 17, mode=1) == 32 + 16
+    assert pitch(1568, 768, 32, mode=0) == 32                          # (no backward intended: the reference's own pitch)
+    assert pitch(1568, 768, 80) in big                                 # longer than the lane-per-row kernels serve
     assert pitch(4, 768, 16) in big                                    # too few rows
     assert pitch(1568, 768, 8, is_variable_B=0) in big                 # constant B
     assert pitch(1568, 768, 8, impl=vms_hip.IMPL_GENERIC) in big       # the caller forced another kernel generation
