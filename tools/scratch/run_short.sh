@@ -1,4 +1,5 @@
-for s in 1568,768,8 1568,768,16 1568,768,4; do
-for lib in default tools/build/libvms_s_nolds.so default tools/build/libvms_s_nolds.so; do
-  if [ $lib = default ]; then KB_SHAPE=$s python tools/kb_short.py 2>&1 | grep "scan_" | sed "s/^/new   /"; else VMS_HIP_LIB=$lib KB_SHAPE=$s python tools/kb_short.py 2>&1 | grep "scan_" | sed "s|^|old   |"; fi
+for s in 1568,768,8 1568,768,16; do
+for rep in 1 2; do
+  KB_SHAPE=$s python tools/kb_short.py 2>&1 | grep "scan_bwd" | sed "s/^/lds-rs   /"
+  VMS_HIP_LIB=tools/build/libvms_s_swaps.so KB_SHAPE=$s python tools/kb_short.py 2>&1 | grep "scan_bwd" | sed "s|^|swaps    |"
 done; done
