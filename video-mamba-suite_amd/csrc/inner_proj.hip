@@ -927,6 +927,22 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
 #ifndef VMS_CXP_XCD
 #define VMS_CXP_XCD 0   /* 1 (A/B builds): neighbouring position tiles on one XCD (see above) */
 #endif
+// timing-only ablations (wrong results), round 6: tools/variant.sh <tag> -DVMS_ABL_CXP_NOBAR=1 / _NOSTORE=1 / _NOCONV=1 / _NOMMA=1 / _NOHALO=1
+#ifndef VMS_ABL_CXP_NOBAR
+#define VMS_ABL_CXP_NOBAR 0
+#endif
+#ifndef VMS_ABL_CXP_NOSTORE
+#define VMS_ABL_CXP_NOSTORE 0
+#endif
+#ifndef VMS_ABL_CXP_NOCONV
+#define VMS_ABL_CXP_NOCONV 0
+#endif
+#ifndef VMS_ABL_CXP_NOMMA
+#define VMS_ABL_CXP_NOMMA 0
+#endif
+#ifndef VMS_ABL_CXP_NOHALO
+#define VMS_ABL_CXP_NOHALO 0
+#endif
     const int lid = VMS_CXP_XCD ? ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     if (lid >= n_wg) return;
     const int b = lid / n_tl;
@@ -968,8 +984,8 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
             const int off = (int)(((int64_t)k * p.x_c_stride + l) * 2);
             st.m[ps] = __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(x_rs, ok ? off : kOOB, 0, 0));
             // positions l - 4 .. l - 1 (the tile's first piece) and l + 8 .. l + 11 (its last): zeros outside the row
-            st.el[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, ok && ipc == 0 && l > 0 ? off - 8 : kOOB, 0, 0));
-            st.er[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, ok && ipc == PPR - 1 && l + 8 < L ? off + 16 : kOOB, 0, 0));
+            st.el[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, !VMS_ABL_CXP_NOHALO && ok && ipc == 0 && l > 0 ? off - 8 : kOOB, 0, 0));
+            st.er[ps] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x_rs, !VMS_ABL_CXP_NOHALO && ok && ipc == PPR - 1 && l + 8 < L ? off + 16 : kOOB, 0, 0));
         }
     };
     auto tap_val = [&](int off_elems, const __amdgpu_buffer_rsrc_t& rs, bool ok) __attribute__((always_inline)) -> float {
@@ -1051,12 +1067,12 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
                     acc = fmaf(taps_a[kk], xv[i + kk], acc);
                     acc_b = fmaf(taps_b[kk], xv[i + 6 - kk], acc_b);
                 }
-                float ra = acc * sigmoidf_(acc), rb = acc_b * sigmoidf_(acc_b);
+                float ra = VMS_ABL_CXP_NOCONV ? acc : acc * sigmoidf_(acc), rb = VMS_ABL_CXP_NOCONV ? acc_b : acc_b * sigmoidf_(acc_b);
                 asm volatile("" : "+v"(ra), "+v"(rb));   // as conv_fwd_dual_kernel: narrowed from the rounded fp32 value
                 oa[i] = static_cast<T>(ra);
                 ob[i] = static_cast<T>(rb);
             }
-            const bool ok = k < K && l < L;
+            const bool ok = k < K && l < L && !VMS_ABL_CXP_NOSTORE;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, oa), oa_rs, ok ? (int)(((int64_t)k * p.out_c_stride + l) * 2) : kOOB, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, ob), ob_rs, ok ? (int)(((int64_t)k * q.c.out_b_c_stride + l) * 2) : kOOB, 0, 0);
             *reinterpret_cast<lds_s16x8*>(in_a + r * INP + 8 * ipc) = __builtin_bit_cast(s16x8, oa);
@@ -1105,10 +1121,12 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
         // them at the next step's w_store leaves those x requests in flight)
         w_load(sw, kb + 1, kb + 2);
         x_load(st, kb + 2);
-        __syncthreads();                // both conv1d tiles and the W blocks are in LDS
-        product(in_a, w_a, acc_a);
-        product(in_b, w_b, acc_b);
-        __syncthreads();                // every wave has read them
+        if (!VMS_ABL_CXP_NOBAR) __syncthreads();                // both conv1d tiles and the W blocks are in LDS
+        if (!VMS_ABL_CXP_NOMMA) {
+            product(in_a, w_a, acc_a);
+            product(in_b, w_b, acc_b);
+        }
+        if (!VMS_ABL_CXP_NOBAR) __syncthreads();                // every wave has read them
     };
     for (int kb = 0; kb < nkb; kb += 2) {
         step(sa, kb);
