@@ -46,6 +46,12 @@ template <> struct Mfma32<f16_t> {
     }
 };
 
+#ifndef VMS_PCB_ST_AUX
+#define VMS_PCB_ST_AUX 0   /* the same for proj_conv_bwd's dx stores */
+#endif
+#ifndef VMS_CXP_ST_AUX
+#define VMS_CXP_ST_AUX 0   /* cache policy bits of the conv1d_out stores (A/B builds: 1 = sc0, 2 = nt / streaming, 3) */
+#endif
 constexpr int kPBufFlags = 0x00020000;   // gfx9 raw buffer, 32-bit data format (as causal_conv1d.hip)
 constexpr int kPT = 256;           // threads per workgroup (4 waves)
 constexpr int kTL = 64;            // positions per tile
@@ -484,7 +490,7 @@ __device__ __forceinline__ void proj_conv_bwd_body(const vms_proj_conv_bwd_param
     auto st8 = [&](const __amdgpu_buffer_rsrc_t& rs, int64_t row, int tl, bool ok, const s16x8& v) __attribute__((always_inline)) {
         const int pl = REV ? L - tl - 8 : tl;
         if (!RAG || L - tl >= 8 || !ok) {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, v), rs, ok ? (int)((row + pl) * 2) : kOOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, v), rs, ok ? (int)((row + pl) * 2) : kOOB, 0, VMS_PCB_ST_AUX);
         } else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -1073,8 +1079,8 @@ __global__ __launch_bounds__(kPT, 2) void conv_xproj_dual_kernel(const vms_conv_
                 ob[i] = static_cast<T>(rb);
             }
             const bool ok = k < K && l < L && !VMS_ABL_CXP_NOSTORE;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, oa), oa_rs, ok ? (int)(((int64_t)k * p.out_c_stride + l) * 2) : kOOB, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, ob), ob_rs, ok ? (int)(((int64_t)k * q.c.out_b_c_stride + l) * 2) : kOOB, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, oa), oa_rs, ok ? (int)(((int64_t)k * p.out_c_stride + l) * 2) : kOOB, 0, VMS_CXP_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pu32x4, ob), ob_rs, ok ? (int)(((int64_t)k * q.c.out_b_c_stride + l) * 2) : kOOB, 0, VMS_CXP_ST_AUX);
             *reinterpret_cast<lds_s16x8*>(in_a + r * INP + 8 * ipc) = __builtin_bit_cast(s16x8, oa);
             *reinterpret_cast<lds_s16x8*>(in_b + r * INP + 8 * ipc) = __builtin_bit_cast(s16x8, ob);
         }

@@ -17,6 +17,9 @@
 #include "vms_common.h"
 #include <type_traits>
 
+#ifndef VMS_FWD_ST_NT
+#define VMS_FWD_ST_NT 0   /* 1 (A/B builds): out / out_z leave as streaming (nt) stores */
+#endif
 namespace vms {
 
 constexpr int kPN = 16;  // dstate
@@ -75,7 +78,8 @@ __device__ __forceinline__ void store_p(T* __restrict__ ptr, const float (&in)[k
         V t;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[REV ? kPK - 1 - (v * EPV + e) : v * EPV + e]);
-        reinterpret_cast<V*>(ptr)[v] = t;
+        if (VMS_FWD_ST_NT) __builtin_nontemporal_store(t, reinterpret_cast<V*>(ptr) + v);
+        else reinterpret_cast<V*>(ptr)[v] = t;
     }
 }
 
