@@ -1,14 +1,14 @@
 mkdir -p gpurun_out/r06h
 cp video-mamba-suite_amd/vms_hip/libvms_hip.so /tmp/libvms_orig.so
 for rep in 1 2 3; do
-for v in v_base v_cxp v_cxp_pcb v_all; do
+for v in v_base v_x8aux0 v_bwdld v_fwdld; do
   cp tools/build/libvms_$v.so video-mamba-suite_amd/vms_hip/libvms_hip.so
   python bench.py --config block --no-cpu-baseline --no-projections --no-extra-configs 2>/dev/null | tail -1 > gpurun_out/r06h/${v}_$rep.json
 done; done
 cp /tmp/libvms_orig.so video-mamba-suite_amd/vms_hip/libvms_hip.so
 python - <<'PY'
 import json
-for v in ("v_base","v_cxp","v_cxp_pcb","v_all"):
+for v in ("v_base","v_x8aux0","v_bwdld","v_fwdld"):
     ms=[]; ks={}
     for r in (1,2,3):
         d=json.load(open(f"gpurun_out/r06h/{v}_{r}.json"))

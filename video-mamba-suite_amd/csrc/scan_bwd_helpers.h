@@ -3,6 +3,9 @@
 #pragma once
 #include "vms_common.h"
 
+#ifndef VMS_BWD_LOAD_NT
+#define VMS_BWD_LOAD_NT 1   /* 0 (A/B builds): the backward's row data as ordinary loads */
+#endif
 namespace vms {
 
 constexpr int kBN = 16;   // dstate
@@ -36,7 +39,7 @@ struct RawB {
         const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
 #pragma unroll
         for (int i = 0; i < kBK / EPV; ++i) {
-            v[i] = __builtin_nontemporal_load(&vp[i]);
+            v[i] = VMS_BWD_LOAD_NT ? __builtin_nontemporal_load(&vp[i]) : vp[i];
         }
     }
     // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad

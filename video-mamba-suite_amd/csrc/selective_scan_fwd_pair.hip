@@ -17,6 +17,9 @@
 #include "vms_common.h"
 #include <type_traits>
 
+#ifndef VMS_FWD_LD_NT
+#define VMS_FWD_LD_NT 0
+#endif
 #ifndef VMS_FWD_ST_NT
 #define VMS_FWD_ST_NT 0   /* 1 (A/B builds): out / out_z leave as streaming (nt) stores */
 #endif
@@ -39,6 +42,12 @@ struct RawP {
         const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
 #pragma unroll
         for (int i = 0; i < kPK / EPV; ++i) v[i] = vp[i];
+    }
+    // row data this launch touches once (u, delta, z): VMS_FWD_LD_NT=1 (A/B builds) loads it as streaming data
+    __device__ __forceinline__ void load_row(const T* __restrict__ base, uint32_t off, bool valid) {
+        const vec_t<T, EPV>* vp = reinterpret_cast<const vec_t<T, EPV>*>(base + (valid ? off : 0u));
+#pragma unroll
+        for (int i = 0; i < kPK / EPV; ++i) v[i] = VMS_FWD_LD_NT ? __builtin_nontemporal_load(&vp[i]) : vp[i];
     }
     // signed offset: a partly valid vector of a padded B / C row may start before the row (REV) -- vms_hip.h bc_pad.
     // `safe`: where a lane beyond the row reads instead -- the piece of the row's FIRST lane, which the padding covers: offset 0
@@ -358,7 +367,10 @@ __global__ __launch_bounds__(kPRows* kWave, VMS_PAIR_MINWAVES) void scan_fwd_pai
 #ifndef VMS_ABL_FWD_NOSTAGE
 #define VMS_ABL_FWD_NOSTAGE 0
 #endif
-constexpr int kX8Aux = 2;                    // cache policy of the checkpoint stores: nt (streaming); none of the bits changes their cost
+#ifndef VMS_X8_AUX
+#define VMS_X8_AUX 2
+#endif
+constexpr int kX8Aux = VMS_X8_AUX;                    // cache policy of the checkpoint stores: nt (streaming); none of the bits changes their cost
 constexpr int kLW = 8;                       // waves (rows) per workgroup
 constexpr int kLG = 4;                       // states per staged group
 constexpr int kLGroupFloats = 2 * kLG * kWave * kPK;   // [tensor][state % 4][1024]
@@ -523,8 +535,8 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         float sdl = 0.f;
         {
             RawP<T, REV> t0, t1;
-            t0.load(u_b, o_u + pl0, ok);
-            t1.load(dt_b, o_dt + pl0, ok);
+            t0.load_row(u_b, o_u + pl0, ok);
+            t1.load_row(dt_b, o_dt + pl0, ok);
             // per element-PAIR (round 3): packed adds / multiplies around the transcendentals
             const float Dq = tail && lane >= 16 ? 0.f : Dd;   // tail: the four rows' y are summed, D u counts once
             const f2 bias2 = f2{bias, bias}, Dd2 = f2{Dq, Dq};
@@ -676,7 +688,7 @@ __device__ __forceinline__ void scan_fwd_lds_body(const vms_scan_fwd_params& p, 
         if (st_okk) store_p<T, REV>(out_b + (o_out + pl0), y);
         if (HZ) {
             RawP<T, REV> tz;
-            tz.load(z_b, o_z + pl0, ok);
+            tz.load_row(z_b, o_z + pl0, ok);
 #pragma unroll
             for (int k = 0; k < K / 2; ++k) {
                 const f2 g = y2[k] * silu2_p(f2{tz.at(2 * k), tz.at(2 * k + 1)});
