@@ -363,3 +363,41 @@ def test_segmented_rows_mixed_directions_and_module(monkeypatch):
     assert _rel(y1, y0) <= 2e-2 and _rel(dx1, dx0) <= 2e-2
     for k in g0:
         assert _rel(g1[k], g0[k]) <= 3e-2, (k, _rel(g1[k], g0[k]))
+
+
+# ---- dstate 4 / 8 on the lane-per-row kernels (round 6: dstate is read at run time) ----------------------------------------------
+@pytest.mark.parametrize("itype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("N", [4, 8])
+@pytest.mark.parametrize("b,d,L", [(64, 64, 8), (33, 128, 16), (70, 64, 13), (64, 64, 32), (80, 64, 50)])
+def test_short_rows_small_dstate(oracle, b, d, L, N, itype, reverse):
+    import selective_scan_cuda
+    import vms_hip
+    torch.manual_seed(N * 100 + L)
+    u = torch.randn(b, d, L, device=DEV).to(itype)
+    z = torch.randn(b, d, L, device=DEV).to(itype)
+    delta = (0.5 * torch.rand(b, d, L, device=DEV)).to(itype)
+    A = -0.5 * torch.rand(d, N, device=DEV) - 0.1
+    B = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    C = torch.randn(b, 1, N, L, device=DEV).to(itype)
+    D = torch.randn(d, device=DEV)
+    bias = 0.5 * torch.rand(d, device=DEV)
+    dout = torch.randn(b, d, L, device=DEV).to(itype)
+    seg = "+segments" if L > 16 else ""
+    res = selective_scan_cuda.fwd(u, delta, A, B, C, D, z, bias, True, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_fwd_short" + seg, vms_hip.last_kernel()
+    out, x = res[0], res[1]
+    assert x.shape == (b, d, 1, 2 * N) and x.stride(2) == 2 * N + N * ((L + 15) // 16 - 1)
+    f = lambda t: t.detach().float().cpu().numpy()
+    lf = (lambda t: t.flip(-1)) if reverse else (lambda t: t)
+    o = oracle.scan_fwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), True, prec="f64")
+    tol = 1e-3 if itype == torch.float32 else 1e-2
+    assert _rel(lf(out), o["out"]) <= tol and _rel(lf(res[2]), o["out_z"]) <= tol and _rel(x, o["x"]) <= 1e-3
+    g = selective_scan_cuda.bwd(u, delta, A, B, C, D, z, bias, dout, x, out, None, True, False, reverse=reverse)
+    assert vms_hip.last_kernel() == "scan_bwd_short" + seg, vms_hip.last_kernel()
+    ob = oracle.scan_bwd(f(lf(u)), f(lf(delta)), f(A), f(lf(B)), f(lf(C)), f(D), f(lf(z)), f(bias), f(lf(dout)), True, prec="f64")
+    for name, got in zip(NAMES, g):
+        want = ob[name]
+        gg = lf(got) if got.ndim >= 3 and got.shape[-1] == L else got
+        wide = 5 if name in ("dA", "dD", "ddelta_bias", "dB", "dC") else 2
+        assert _rel(gg, want) <= tol * wide, (name, _rel(gg, want))

@@ -29,7 +29,7 @@ namespace vms {
 #ifndef VMS_SHORT_BC_LDS
 #define VMS_SHORT_BC_LDS 1   /* 0 (A/B builds): every state loads and widens its own B / C rows from global memory, as until round 5 */
 #endif
-constexpr int kSN = 16;        // dstate
+constexpr int kSN = 16;        // the largest dstate served (the LDS layouts' pitch); dstate 4 and 8 too since round 6 (read at run time)
 constexpr int kSN_ = kSN;
 constexpr int kSMaxL = 16;     // elements a lane holds in registers = one SEGMENT of a row
 constexpr int kSMaxSeg = 4;    // segments per row (round 6): rows of 17 .. 64 elements as up to four launches of the same kernels
@@ -46,7 +46,7 @@ int64_t scan_short_x_pitch(const vms_scan_fwd_params& p) { return 2 * (int64_t)p
 
 // the problem's shape alone (what vms_scan_x_pitch decides on: the pitch is its answer, not its input)
 static bool scan_short_shape_ok(const vms_scan_fwd_params& p) {
-    if (p.is_complex || !p.is_variable_B || !p.is_variable_C || p.dstate != kSN || p.seqlen < 1 || p.seqlen > kSMaxL * kSMaxSeg) return false;
+    if (p.is_complex || !p.is_variable_B || !p.is_variable_C || (p.dstate != kSN && p.dstate != 8 && p.dstate != 4) || p.seqlen < 1 || p.seqlen > kSMaxL * kSMaxSeg) return false;
     if (p.n_chunks != 1 || p.n_groups < 1 || p.dim % p.n_groups != 0 || p.x_has_sub == 2) return false;
     if (p.reverse_from > 0 && p.reverse_from < p.batch) return false;   // (the entry points split mixed directions into two problems)
     // the backward's wave sums of dB / dC need whole waves inside one (batch entry, group); forward and backward go together
@@ -108,14 +108,15 @@ __device__ __forceinline__ void load_row(const T* __restrict__ row, int L, bool 
 // with broadcast ds_read_b128 (all lanes one address: no bank conflicts, ~100 cycles instead of an L2 round trip).
 template <typename T, int LP, bool REV, bool VEC>
 __device__ __forceinline__ void stage_bc_short(float* __restrict__ blk, const T* __restrict__ Bp, const T* __restrict__ Cp,
-                                               const int64_t bs, const int64_t cs, const int L, const int lane) {
+                                               const int64_t bs, const int64_t cs, const int L, const int lane, const int N) {
     if constexpr (VEC) {
-        constexpr int EPV = 16 / sizeof(T), VPR = LP / EPV, NV = 2 * kSN_ * VPR;
+        constexpr int EPV = 16 / sizeof(T), VPR = LP / EPV, NVmax = 2 * kSN_ * VPR;
+        const int NV = 2 * N * VPR;                  // (the block keeps its 16-state pitch; states >= N are not staged)
 #pragma unroll
-        for (int v0 = 0; v0 < NV; v0 += 64) {
+        for (int v0 = 0; v0 < NVmax; v0 += 64) {
             const int v = v0 + lane;
-            if (NV % 64 == 0 || v < NV) {
-                const int ten = v / (kSN_ * VPR), n = (v / VPR) % kSN_, k = v % VPR;
+            if (v < NV) {
+                const int ten = v / (N * VPR), n = (v / VPR) % N, k = v % VPR;
                 const T* row = ten ? Cp + (int64_t)n * cs : Bp + (int64_t)n * bs;
                 float o[EPV];
                 if (k * EPV < L) {
@@ -132,10 +133,10 @@ __device__ __forceinline__ void stage_bc_short(float* __restrict__ blk, const T*
             }
         }
     } else {
-        for (int idx = lane; idx < 2 * kSN_ * LP; idx += 64) {
-            const int ten = idx / (kSN_ * LP), n = (idx / LP) % kSN_, i = idx % LP;
+        for (int idx = lane; idx < 2 * N * LP; idx += 64) {
+            const int ten = idx / (N * LP), n = (idx / LP) % N, i = idx % LP;
             const T* row = ten ? Cp + (int64_t)n * cs : Bp + (int64_t)n * bs;
-            blk[idx] = i < L ? static_cast<float>(row[REV ? L - 1 - i : i]) : 0.f;
+            blk[(ten * kSN_ + n) * LP + i] = i < L ? static_cast<float>(row[REV ? L - 1 - i : i]) : 0.f;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // wave-private: the wave's LDS instructions complete in order
@@ -203,7 +204,7 @@ __device__ __forceinline__ void wave_reduce_scatter(float (&v)[V], float (&z)[V 
 // final state goes (-1: the reference-shaped slots of the row's one chunk)
 template <typename T, bool HZ, bool REV, int LP, bool VEC>
 __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_params p, const int h_in, const int h_out) {
-    constexpr int N = kSN;
+    const int N = p.dstate;
     // a wave = 64 consecutive channels of ONE batch entry and ONE group (dim / n_groups is a multiple of 64): uniform B / C addresses;
     // the workgroup's 4 waves = the same channels of 4 CONSECUTIVE batch entries: in the blocks' channel-slowest layout those rows
     // are neighbours in memory (4 x 32 bytes = one line), so the line a wave touches is the line its three neighbours touch
@@ -244,9 +245,9 @@ __global__ __launch_bounds__(256) void scan_fwd_short_kernel(const vms_scan_fwd_
     // it; the final states go through LDS ([row][state], 17-float pitch) and leave as eight 1 KB-contiguous stores per wave.
     __shared__ float hs[4][64 * 17];
     __shared__ __attribute__((aligned(16))) float bcs[4][2 * kSN * LP];   // this wave's B / C as fp32 (stage_bc_short)
-    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane);
+    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane, N);
     const bool x16 = (xpitch & 3) == 0 && (reinterpret_cast<uintptr_t>(p.x) & 15) == 0;
-    const bool xdense = x16 && xpitch == 2 * N && h_out < 0;
+    const bool xdense = x16 && xpitch == 2 * N && h_out < 0 && N == kSN;   // (the LDS transposition below is laid out for 16 states)
 #pragma unroll 1
     for (int n0 = 0; n0 < N; n0 += 2) {
         float hq[2];
@@ -323,7 +324,7 @@ template <typename T, bool HZ, bool REV, int LP, bool VEC>
 __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_params q, float* __restrict__ ws, float* __restrict__ gcar,
                                                              const int h_in, const int flags, const int next_off) {
     const vms_scan_fwd_params& p = q.f;
-    constexpr int N = kSN;
+    const int N = p.dstate;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dblocks = p.dim / 64;
     const int d = ((int)blockIdx.x % dblocks) * 64 + lane;
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(256) void scan_bwd_short_kernel(const vms_scan_bwd_
         if (p.delta_softplus) dl_nx = softplusf_(dl_nx);
     }
     __shared__ __attribute__((aligned(16))) float bcs[4][2 * kSN * LP];   // this wave's B / C as fp32 (stage_bc_short)
-    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane);
+    if (VMS_SHORT_BC_LDS) stage_bc_short<T, LP, REV, VEC>(bcs[wave], Bp, Cp, p.B_dstate_stride, p.C_dstate_stride, L, lane, N);
     float dl[LP], uv[LP], dy[LP], sg[LP], dua[LP], dda[LP];
     float dD = 0.f;
     load_row<T, LP, REV, VEC>(dt, L, true, dl);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void short_reduce_kernel(const float* __restri
     float v = 0.f;
     for (int b = b0; b < b1; ++b) v += ws[(int64_t)b * per_chunk + idx];
     const int slot = (int)(idx / p.dim), d = (int)(idx - (int64_t)slot * p.dim);
-    if (slot < 16) atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)slot * q.dA_dstate_stride, v);
+    if (slot < 16) { if (slot < p.dstate) atomicAdd(q.dA + (int64_t)d * q.dA_d_stride + (int64_t)slot * q.dA_dstate_stride, v); }
     else if (slot == 16) { if (q.dD) atomicAdd(q.dD + d, v); }
     else if (q.ddelta_bias) atomicAdd(q.ddelta_bias + d, v);
 }
