@@ -1315,6 +1315,9 @@ static int launch_conv_bwd(const vms_proj_conv_bwd_params& p, hipStream_t stream
     auto grid_of = [&](int t) { return 8 * (int64_t)((((n_tiles + t - 1) / t) * p.batch + 7) / 8) * d_tiles; };
     while (tpw < n_tiles && grid_of(tpw) > want && 2 * grid_of(tpw) < 3 * want) ++tpw;
     if (p.tiles_per_wg > 0) tpw = p.tiles_per_wg;
+#ifdef VMS_PCB_TPW
+    tpw = VMS_PCB_TPW;            /* A/B builds: tiles per workgroup of vms_proj_conv_bwd */
+#endif
     if (tpw > n_tiles) tpw = n_tiles;
     const int n_rng = (n_tiles + tpw - 1) / tpw;
     const int2 pg = make_int2(n_rng, d_tiles);

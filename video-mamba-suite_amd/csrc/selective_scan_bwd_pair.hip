@@ -1372,7 +1372,10 @@ static int launch_bpair_dual(const vms_scan_bwd_params& a, const vms_scan_bwd_pa
     // kernel (793 vs 835 us per direction there); everything else runs 4-wave workgroups, whose partial last round has one
     // wave per SIMD (profiles/r04_dual_bwd.md)
     const bool small_n = p.dstate != kBN;                  // dstate 4 / 8: the run-time-dstate instantiation (4-wave workgroups)
-    const bool w8 = (2 * n8) % cus == 0 && !small_n;
+#ifndef VMS_DUAL_FORCE_W4
+#define VMS_DUAL_FORCE_W4 0   /* 1 (A/B builds): 4-wave workgroups also for whole rounds of 8-wave ones */
+#endif
+    const bool w8 = (2 * n8) % cus == 0 && !small_n && !VMS_DUAL_FORCE_W4;
     const bool xl = p.x_has_sub == 3;
     if (B4<8>::kSmem > 64 * 1024 || B4<4>::kSmem > 64 * 1024) {
         static PerDeviceOnce attrd_once;
