@@ -3,6 +3,9 @@
 #pragma once
 #include "vms_common.h"
 
+#ifndef VMS_BWD_ST_NT
+#define VMS_BWD_ST_NT 1     /* 0 (A/B builds): du / ddelta leave as ordinary stores */
+#endif
 #ifndef VMS_BWD_LOAD_NT
 #define VMS_BWD_LOAD_NT 1   /* 0 (A/B builds): the backward's row data as ordinary loads */
 #endif
@@ -89,7 +92,8 @@ __device__ __forceinline__ void store_stream_b(T* __restrict__ ptr, const float 
         V t;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) t[e] = static_cast<T>(in[REV ? kBK - 1 - (v * EPV + e) : v * EPV + e]);
-        __builtin_nontemporal_store(t, reinterpret_cast<V*>(ptr) + v);
+        if (VMS_BWD_ST_NT) __builtin_nontemporal_store(t, reinterpret_cast<V*>(ptr) + v);
+        else reinterpret_cast<V*>(ptr)[v] = t;
     }
 }
 
